@@ -1,0 +1,117 @@
+"""Pins the CPU oracle (oracle/avc_oracle.py) to outputs of the REAL reference.
+
+tests/golden/*.npz were produced by oracle/make_golden.py, which imports
+/root/reference/model.py and drives it with a restated solver.py:81-97 step
+(real torch.optim.Adam + clip_grad_norm_).  The reference has no tests of its
+own, so these fixtures are the parity pins.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import avc_oracle as O
+
+
+def _stats(t):
+    from oracle.make_golden import tensor_stats
+    return tensor_stats(t)
+
+
+CASES = [
+    ("train_m80_t128_b2", lambda: O.stock_config(80)),
+    ("train_m80_t128_b4_s1", lambda: O.stock_config(80)),
+    ("train_m80_t256_b1", lambda: O.stock_config(80)),
+    ("train_m512_t128_b1", lambda: O.stock_config(512)),
+    ("train_tiny_t32_b2", O.tiny_config),
+    ("train_tiny_t24_b3", O.tiny_config),
+]
+
+
+def _close_stats(a, b, rtol, atol):
+    # columns: l2, sum, absmax, then sampled entries
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name,cfgf", CASES)
+def test_train_case_matches_reference(name, cfgf, golden_dir):
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfgf()
+    B, T, seed, n_steps = int(g["B"]), int(g["T"]), int(g["seed"]), int(g["n_steps"])
+    sd = O.make_state_dict(cfg, seed)
+    x, eps = O.make_inputs(cfg, B, T, seed)
+    # the regenerated inputs are the ones the reference saw
+    np.testing.assert_allclose(_stats(x), g["x_stats"], rtol=0, atol=0)
+    np.testing.assert_allclose(_stats(eps), g["eps_stats"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.stack([_stats(v) for v in sd.values()]), g["w_stats"], rtol=0, atol=0)
+    names = [k for k, _ in O.param_spec(cfg)]
+    assert len(names) == 2 * (len(names) // 2)
+    opt = O.make_opt(sd, cfg)
+    for step in range(n_steps):
+        meta, outs, grads_clipped = O.ae_step(x, eps, sd, opt, cfg, 1.0)
+        # Step 0 is a strict pin.  From step 1 on, Adam's first update is
+        # sign-like (m/sqrt(v) = +-1), so elements whose gradient is ~0 +- fp
+        # noise move by +-lr differently in any two implementations and the
+        # trajectories decorrelate at the 1e-3 level (measured: reference vs
+        # this oracle, 24 elements after step 0) -> loose tolerances there.
+        tl, tg, tp = (2e-5, 1e-4, 2e-4) if step == 0 else (2e-3, 5e-3, 2e-3)
+        assert meta["loss_rec"] == pytest.approx(float(g[f"loss_rec_{step}"]), rel=tl)
+        assert meta["loss_kl"] == pytest.approx(float(g[f"loss_kl_{step}"]), rel=tl)
+        assert meta["grad_norm"] == pytest.approx(float(g[f"grad_norm_{step}"]), rel=tg)
+        if step == 0:
+            if "dec" in g:
+                for k in ("mu", "log_sigma", "emb", "dec"):
+                    np.testing.assert_allclose(outs[k].numpy(), g[k], rtol=1e-4, atol=2e-5)
+            ostats = np.stack([_stats(outs[k]) for k in ("mu", "log_sigma", "emb", "dec")])
+            _close_stats(ostats, g["out_stats"], rtol=1e-4, atol=2e-5)
+        pstats = np.stack([_stats(sd[k]) for k in names])
+        ref = g[f"param_stats_{step}"]
+        # per-tensor L2 norm of every parameter after the step
+        np.testing.assert_allclose(pstats[:, 0], ref[:, 0], rtol=tp, atol=1e-6)
+        # sampled entries: all but a handful (sign-flipped ~0-gradient elements, +-2*lr) agree
+        bad = np.abs(pstats[:, 3:] - ref[:, 3:]) > (2e-6 + 1e-4 * np.abs(ref[:, 3:]))
+        assert bad.mean() < (5e-3 if step == 0 else 0.5)
+        assert np.abs(pstats[:, 3:] - ref[:, 3:]).max() < 4 * cfg["optimizer"]["lr"] * (step + 1)
+
+
+def test_unclipped_gradients_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "train_tiny_t32_b2.npz"))
+    cfg = O.tiny_config()
+    sd = O.make_state_dict(cfg, int(g["seed"]))
+    x, eps = O.make_inputs(cfg, int(g["B"]), int(g["T"]), int(g["seed"]))
+    outs, grads = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    names = [k for k, _ in O.param_spec(cfg)]
+    gs = np.stack([_stats(grads[k]) for k in names])
+    ref = g["grad_stats"]
+    # per-tensor L2 norms within 1e-4 relative (abs 1e-6 for the analytically-zero bias grads)
+    np.testing.assert_allclose(gs[:, 0], ref[:, 0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gs[:, 3:], ref[:, 3:], rtol=2e-3, atol=2e-6)
+    for k in g.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(grads[k[5:]].numpy(), g[k], rtol=1e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,cfgf", [("infer_m80_t100_c77", lambda: O.stock_config(80)),
+                                       ("infer_tiny_t37_c19", O.tiny_config)])
+def test_inference_matches_reference(name, cfgf, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfgf()
+    seed = int(g["seed"])
+    sd = O.make_state_dict(cfg, seed)
+    x, _ = O.make_inputs(cfg, 1, int(g["Ts"]), seed)
+    xc, _ = O.make_inputs(cfg, 1, int(g["Tc"]), seed + 7)
+    dec = O.ae_inference(x, xc, sd, cfg)
+    emb = O.speaker_encoder(xc, sd, cfg)
+    assert tuple(dec.shape) == tuple(g["dec"].shape)  # T' = 8*ceil(T/8) style growth, SURVEY §3.3
+    np.testing.assert_allclose(dec.numpy(), g["dec"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=1e-4, atol=2e-5)
+
+
+def test_short_input_raises_like_reference():
+    cfg = O.stock_config(80)
+    sd = O.make_state_dict(cfg, 0)
+    x, _ = O.make_inputs(cfg, 1, 16, 0)
+    with pytest.raises(RuntimeError, match="Padding size"):
+        O.content_encoder(x, sd, cfg)
