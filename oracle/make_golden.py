@@ -85,7 +85,7 @@ def run_case(model_mod, name, cfg, B, T, seed, n_steps, full_outputs=True):
             for k in ("speaker_encoder.output_layer.bias", "content_encoder.mean_layer.bias",
                       "decoder.conv_affine_layers.0.bias", "decoder.out_conv_layer.bias",
                       "speaker_encoder.conv_bank.0.bias", "decoder.first_conv_layers.0.bias"):
-                out["grad/" + k] = grads[k].grad.detach().numpy()
+                out["grad/" + k] = grads[k].grad.detach().clone().numpy()
         gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=o["grad_norm"])
         opt.step()
         out[f"loss_rec_{step}"] = float(loss_rec)
