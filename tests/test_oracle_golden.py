@@ -112,6 +112,6 @@ def test_inference_matches_reference(name, cfgf, golden_dir):
 def test_short_input_raises_like_reference():
     cfg = O.stock_config(80)
     sd = O.make_state_dict(cfg, 0)
-    x, _ = O.make_inputs(cfg, 1, 16, 0)
+    x, eps = O.make_inputs(cfg, 1, 16, 0)  # T <= 16 -> the decoder's k=5 conv sees T_l = 2
     with pytest.raises(RuntimeError, match="Padding size"):
-        O.content_encoder(x, sd, cfg)
+        O.ae_forward(x, eps, sd, cfg)
