@@ -1,0 +1,77 @@
+// Shared device/host definitions for the AdaIN-VC gfx950 kernels.
+// Activations are [B, C, T] fp32 with T contiguous (the reference's layout,
+// model.py); every kernel takes explicit element strides so that the
+// transposed [B,T,M] view handed over by data_utils.py:14-16 needs no copy.
+#pragma once
+#include <stdint.h>
+
+#define AVC_MAX_GROUPS 8
+#define AVC_THREADS 256
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- residual / gradient-join modes used by conv epilogues and row kernels
+enum {
+    AVC_RES_NONE = 0,
+    AVC_RES_IDENTITY = 1,   // r[t]
+    AVC_RES_AVGPOOL2 = 2,   // fwd: F.avg_pool1d(k=2, ceil_mode=True)  (model.py:248,319)
+    AVC_RES_POOLT = 3,      // bwd of AVGPOOL2: g[t/2] * (0.5 | 1 for a clipped last window)
+    AVC_RES_UPT = 4,        // bwd of nearest x2: g[2t] + g[2t+1]        (model.py:61-63)
+    AVC_RES_UP2 = 5,        // fwd nearest x2: r[t/2]
+};
+
+struct ConvSrc {
+    const float* ptr;
+    long sb, sc;  // element strides of batch / channel
+    int st;       // element stride of time
+    int ps;       // pixel-(un)shuffle factor: channel c lives at (c/ps)*sc + (c%ps)  (model.py:52-59)
+};
+
+struct ConvGroup {
+    const float* wp;    // packed weights [nchunk][KS][CK][Mp]
+    const float* bias;  // [M] or null
+    float* out;         // primary output (may be null)
+    float* out2;        // secondary output (may be null)
+    const float* res;   // residual / gradient-join source (may be null)
+    const float* mask;  // secondary = value * (mask > 0)      (ReLU backward)
+    int KS, padL, padR, nchunk;
+};
+
+struct ConvArgs {
+    ConvSrc x;
+    int B, Cred, Tsrc;
+    int mode;    // 0 = forward correlation with reflect padding, 1 = dgrad (zero-extended, zero-upsampled dy)
+    int stride;  // forward stride / dgrad upsampling factor
+    int mirror;  // dgrad only: add the reflect-padding adjoint (fold) inside the B-fragment fetch
+    int M, Mp, Tout;
+    long ob, oc;
+    int ot, ops;  // output strides (+ pixel-shuffle store factor), shared by out/out2/mask
+    int act;      // 0 none, 1 relu
+    int res_mode, res_to_primary;
+    long rb, rc;
+    int rt, Tres;
+    int CK;
+    int ngroups;
+    ConvGroup g[AVC_MAX_GROUPS];
+};
+
+struct WgradArgs {
+    ConvSrc x;    // conv input  [B, Cin, Tin]   (reflect padded on the fly)
+    ConvSrc dy;   // output grad [B, Cout, Tout]
+    int B, Cin, Cout, Tin, Tout;
+    int KS, padL, stride;
+    int chunks_per_sample, total_chunks, chunks_per_wg, Tc, spc;  // K-split geometry (32 columns per chunk)
+    float* slab;   // [nsplit][Cout][Cin][KS] partial sums
+    float* dbslab; // [nsplit][Cout] partial bias sums (may be null)
+    long slab_stride, db_stride;
+    int wrow0;     // row offset (bank/grouped layers write a sub-block)
+};
+
+static inline __host__ __device__ int avc_reflect(int v, int T) {
+    // F.pad(mode='reflect'): mirror without repeating the edge (model.py:28-30)
+    if (v < 0) v = -v;
+    if (v >= T) v = 2 * (T - 1) - v;
+    return v;
+}
+static inline __host__ __device__ int avc_cdiv(int a, int b) { return (a + b - 1) / b; }

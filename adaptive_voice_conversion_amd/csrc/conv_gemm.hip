@@ -1,0 +1,396 @@
+// Implicit-GEMM Conv1d for gfx950 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves both directions of every convolution / Linear of the
+// AdaIN-VC autoencoder (reference: model.py:21-32 pad_layer + nn.Conv1d /
+// nn.Linear call sites at :223-224,:241-247,:256-259,:268,:276,:304-322,:348-370):
+//
+//   out[b, m, t] = sum_{c, j} Wp[c, j, m] * src_ext[b, c, t*s + j]
+//
+//   mode 0 (forward):  src_ext = reflect-padded input, never materialised — the
+//                      LDS tile loader mirrors the halo indices.
+//   mode 1 (dgrad):    src_ext = zero-extended, zero-upsampled dy; weights are
+//                      packed transposed + tap-flipped.  The adjoint of the
+//                      reflect padding (the "fold") is applied inside the
+//                      B-fragment fetch: a column near an edge adds the LDS
+//                      windows of its mirror images before the MFMA, so dx is
+//                      produced directly with T columns and no padded buffer.
+//
+// Tiling: workgroup = 4 waves (2x2), wave tile = (32*WM) x (32*WN), K-chunks of
+// CK reduction channels x KS taps staged through LDS (weights arrive pre-packed
+// in LDS-image order; the source tile is loaded once per chunk and serves all
+// KS taps through shifted windows).  Register-staged double buffering, one
+// barrier per chunk.  Epilogue fuses bias, ReLU, pixel-shuffle store, the
+// residual join (identity / ceil-mode avg-pool / their adjoints) and the ReLU
+// mask of the backward pass.
+#include <hip/hip_runtime.h>
+
+#include "avc_common.h"
+#include "avc_internal.h"
+
+#define AVC_CONV_MAXA 8
+#define AVC_CONV_MAXX 17
+
+struct ConvGeom {
+    int b0, t0, SPT, ncols, SEG, seg_p0, ROWDATA, ROW;
+};
+
+static inline __host__ __device__ ConvGeom conv_geom(int mode, int stride, int Tout, int KS, int BN, int tile) {
+    ConvGeom q;
+    if (Tout >= BN) {
+        int tps = avc_cdiv(Tout, BN);
+        q.b0 = tile / tps;
+        q.t0 = (tile % tps) * BN;
+        q.SPT = 1;
+        q.ncols = BN;
+    } else {
+        q.SPT = BN / Tout;
+        q.b0 = tile * q.SPT;
+        q.t0 = 0;
+        q.ncols = Tout;
+    }
+    if (mode == 0) {
+        q.SEG = (q.ncols - 1) * stride + KS;
+        q.seg_p0 = q.t0 * stride;
+    } else {
+        // main window + both mirror windows of the reflect-padding adjoint (a column
+        // within padR of the end may sit in the last-but-one tile: +(KS-1) slack)
+        q.SEG = q.ncols + 3 * (KS - 1);
+        q.seg_p0 = q.t0;
+    }
+    q.ROWDATA = q.SPT * q.SEG;
+    q.ROW = q.ROWDATA + KS;  // trailing KS zeros: the "null window" of inactive mirror terms / masked columns
+    return q;
+}
+
+static inline __device__ float conv_load_res(const ConvArgs& a, const float* res, int b, int m, int t) {
+    const float* base = res + (long)b * a.rb + (long)m * a.rc;
+    switch (a.res_mode) {
+        case AVC_RES_IDENTITY:
+            return base[(long)t * a.rt];
+        case AVC_RES_AVGPOOL2: {
+            int i0 = 2 * t, i1 = 2 * t + 1;
+            float v0 = base[(long)i0 * a.rt];
+            if (i1 < a.Tres) return (v0 + base[(long)i1 * a.rt]) * 0.5f;
+            return v0;  // clipped window of ceil_mode: divisor 1
+        }
+        case AVC_RES_POOLT: {
+            float gsrc = base[(long)(t >> 1) * a.rt];
+            bool single = (a.Tout & 1) && (t == a.Tout - 1);
+            return single ? gsrc : gsrc * 0.5f;
+        }
+        case AVC_RES_UPT:
+            return base[(long)(2 * t) * a.rt] + base[(long)(2 * t + 1) * a.rt];
+        default:
+            return 0.f;
+    }
+}
+
+template <int WM, int WN>
+__global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    HIP_DYNAMIC_SHARED(float, smem)
+    const ConvGroup g = a.g[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    const int KS = g.KS, padL = g.padL, padR = g.padR, CK = a.CK, nchunk = g.nchunk;
+    const int Tout = a.Tout;
+    const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
+    const int ROW = q.ROW;
+    const int m_tile0 = blockIdx.y * BM;
+
+    const int AS = KS * CK * BM;  // floats per A stage
+    const int XS = CK * ROW;      // floats per X stage
+    float* As = smem;
+    float* Xs = smem + 2 * AS;
+    int* srcpos = (int*)(smem + 2 * AS + 2 * XS);
+
+    // ---- per-position source offsets (same for every channel chunk)
+    for (int p = tid; p < ROW; p += AVC_THREADS) {
+        int sp = -1;
+        if (p < q.ROWDATA) {
+            int seg = p / q.SEG, qq = p - seg * q.SEG;
+            int b = q.b0 + seg;
+            int pp = q.seg_p0 + qq;
+            if (b < a.B) {
+                if (a.mode == 0) {
+                    int v = pp - padL;
+                    int r = avc_reflect(v, a.Tsrc);
+                    if (r >= 0 && r < a.Tsrc) sp = (int)(b * a.x.sb + (long)r * a.x.st);
+                } else {
+                    int v = pp - (KS - 1);
+                    if (v >= 0) {
+                        int vs = v / a.stride;
+                        if (vs * a.stride == v && vs < a.Tsrc) sp = (int)(b * a.x.sb + (long)vs * a.x.st);
+                    }
+                }
+            }
+        }
+        srcpos[p] = sp;
+    }
+
+    // ---- per-lane column bases into an LDS row
+    int cb[WN], cbl[WN], cbr[WN], colb[WN], colt[WN];
+    bool colv[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        int n = wave_n * (32 * WN) + wn * 32 + li;
+        int bl, t;
+        bool v;
+        if (q.SPT == 1 && Tout >= BN) {
+            bl = 0;
+            t = q.t0 + n;
+            v = (t < Tout) && (q.b0 < a.B);
+        } else {
+            bl = n / Tout;
+            t = n - bl * Tout;
+            v = (bl < q.SPT) && (q.b0 + bl < a.B);
+        }
+        colb[wn] = q.b0 + bl;
+        colt[wn] = t;
+        colv[wn] = v;
+        int base = q.ROWDATA, bL = q.ROWDATA, bR = q.ROWDATA;
+        if (v) {
+            if (a.mode == 0) {
+                base = bl * q.SEG + (t - q.t0) * a.stride;
+            } else {
+                base = bl * q.SEG + (t - q.t0) + padL;
+                if (a.mirror) {
+                    if (t >= 1 && t <= padL) bL = bl * q.SEG + (padL - t - q.seg_p0);
+                    if (t >= Tout - 1 - padR && t <= Tout - 2) bR = bl * q.SEG + (2 * (Tout - 1) - t + padL - q.seg_p0);
+                }
+            }
+        }
+        cb[wn] = base;
+        cbl[wn] = bL;
+        cbr[wn] = bR;
+    }
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    float4 areg[AVC_CONV_MAXA];
+    float xreg[AVC_CONV_MAXX];
+    const int nA4 = KS * CK * (BM / 4);
+    const int nX = CK * ROW;
+
+    __syncthreads();  // srcpos visible
+
+    auto load_regs = [&](int chunk) {
+        const float* wsrc = g.wp + (long)chunk * KS * CK * a.Mp + m_tile0;
+#pragma unroll
+        for (int it = 0; it < AVC_CONV_MAXA; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nA4) {
+                int row = e / (BM / 4), c4 = e - row * (BM / 4);
+                areg[it] = *(const float4*)(wsrc + (long)row * a.Mp + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < AVC_CONV_MAXX; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nX) {
+                int r = e / ROW, p = e - r * ROW;
+                int sp = srcpos[p];
+                int c = chunk * CK + r;
+                float v = 0.f;
+                if (sp >= 0 && c < a.Cred) {
+                    long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
+                    v = a.x.ptr[(long)sp + coff];
+                }
+                xreg[it] = v;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float* Ad = As + buf * AS;
+        float* Xd = Xs + buf * XS;
+#pragma unroll
+        for (int it = 0; it < AVC_CONV_MAXA; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nA4) *(float4*)(Ad + e * 4) = areg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < AVC_CONV_MAXX; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nX) Xd[e] = xreg[it];
+        }
+    };
+
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int a_lane = wave_m * (32 * WM) + li;
+    const int half = CK >> 1;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const bool more = (chunk + 1 < nchunk);
+        if (more) load_regs(chunk + 1);
+        const float* Ab = As + (chunk & 1) * AS;
+        const float* Xb = Xs + (chunk & 1) * XS;
+        for (int tap = 0; tap < KS; ++tap) {
+            const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
+            const float* Xrow = Xb + h * ROW + tap;
+#pragma unroll 4
+            for (int c2 = 0; c2 < half; ++c2) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) av[wm] = Arow[(2 * c2) * BM + wm * 32];
+                const float* xr = Xrow + (2 * c2) * ROW;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) {
+                    float v = xr[cb[wn]];
+                    if (a.mirror) v = v + xr[cbl[wn]] + xr[cbr[wn]];
+                    bv[wn] = v;
+                }
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn)
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm], bv[wn], acc[wm][wn], 0, 0, 0);
+            }
+        }
+        if (more) store_lds((chunk + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        if (!colv[wn]) continue;
+        const int b = colb[wn], t = colt[wn];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m_tile0 + wave_m * (32 * WM) + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= a.M) continue;
+                float v = acc[wm][wn][r];
+                if (g.bias) v += g.bias[m];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                long o;
+                if (a.ops == 1)
+                    o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
+                else
+                    o = (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
+                float rr = 0.f;
+                if (a.res_mode != AVC_RES_NONE) rr = conv_load_res(a, g.res, b, m, t);
+                if (a.res_to_primary) v += rr;
+                if (g.out) g.out[o] = v;
+                if (g.out2) {
+                    float v2 = a.res_to_primary ? v : v + rr;
+                    if (g.mask) v2 = (g.mask[o] > 0.f) ? v2 : 0.f;
+                    g.out2[o] = v2;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// weight packing: W[Cout][Cin][KS] (state_dict layout) -> LDS-image order
+//   fwd  : Wp[chunk][j][r][m]  = W[m][chunk*CK + r][j]
+//   dgrad: Wp[chunk][j][r][m]  = W[chunk*CK + r][m][KS-1-j]   (transposed, tap-flipped)
+// Several source tensors of identical shape can be stacked along the forward
+// output-channel axis (the 12 AdaIN affine Linears, the mu/log_sigma heads).
+// --------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs p) {
+    long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
+    for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < total; e += (long)gridDim.x * AVC_THREADS) {
+        int m = (int)(e % p.Mp);
+        long rest = e / p.Mp;
+        int r = (int)(rest % p.CK);
+        rest /= p.CK;
+        int j = (int)(rest % p.KS);
+        int chunk = (int)(rest / p.KS);
+        int red = chunk * p.CK + r;
+        float v = 0.f;
+        if (!p.dgrad) {
+            if (m < p.M && red < p.Cin) {
+                int s = m / p.rows_per_src, mm = m - s * p.rows_per_src;
+                v = p.src[s][((long)mm * p.Cin + red) * p.KS + j];
+            }
+        } else {
+            if (m < p.M && red < p.Cout) {
+                int s = red / p.rows_per_src, rr = red - s * p.rows_per_src;
+                v = p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
+            }
+        }
+        p.dst[e] = v;
+    }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? 8 : (KS >= 2 ? 16 : 32); }
+
+static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
+    size_t worst = 0;
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
+        size_t AS = (size_t)a.g[gi].KS * a.CK * BM, XS = (size_t)a.CK * q.ROW;
+        size_t bytes = (2 * AS + 2 * XS + q.ROW) * 4;
+        worst = bytes > worst ? bytes : worst;
+    }
+    return worst + 16;
+}
+
+static int conv_ntiles_n(const ConvArgs& a, int BN) {
+    if (a.Tout >= BN) return a.B * avc_cdiv(a.Tout, BN);
+    int spt = BN / a.Tout;
+    return avc_cdiv(a.B, spt);
+}
+
+// returns 0 on success, negative on unsupported geometry
+int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
+    if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
+    if (a.Mp % 128 != 0 || a.CK % 2 != 0) return -2;
+    for (int gi = 0; gi < a.ngroups; ++gi)
+        if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
+    int tile = force_tile;
+    if (tile == 0) {
+        long t22 = (long)(a.Mp / 128) * conv_ntiles_n(a, 128) * a.ngroups;
+        long t21 = (long)(a.Mp / 128) * conv_ntiles_n(a, 64) * a.ngroups;
+        if (t22 >= 512)
+            tile = 22;
+        else if (t21 >= 384)
+            tile = 21;
+        else
+            tile = 11;
+    }
+    int BM = (tile == 11) ? 64 : 128;
+    int BN = (tile == 22) ? 128 : 64;
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
+        if ((long)a.CK * q.ROW > (long)AVC_THREADS * AVC_CONV_MAXX) return -3;
+        if ((long)a.g[gi].KS * a.CK * (BM / 4) > (long)AVC_THREADS * AVC_CONV_MAXA) return -4;
+    }
+    size_t lds = conv_lds_bytes(a, BM, BN);
+    if (lds > 160 * 1024) return -5;
+    dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups), block(AVC_THREADS);
+    if (tile == 22)
+        hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, block, lds, stream, a);
+    else if (tile == 21)
+        hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, block, lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+int avc_launch_pack(const PackArgs& p, hipStream_t stream) {
+    long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
+    int blocks = (int)((total + AVC_THREADS * 4 - 1) / (AVC_THREADS * 4));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(AVC_THREADS), 0, stream, p);
+    return (int)hipGetLastError();
+}

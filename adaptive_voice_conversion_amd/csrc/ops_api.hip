@@ -1,0 +1,89 @@
+// Op-level C-ABI entry points (declared in include/avc_hip.h): one function per
+// kernel family and direction, raw device pointers + explicit sizes + stream.
+// Used by the op-level parity tests and by external callers that want single
+// kernels; the whole-model path goes through engine.hip.
+#include <hip/hip_runtime.h>
+
+#include "avc_common.h"
+#include "avc_internal.h"
+
+extern "C" {
+
+long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
+    int CK = avc_conv_ck(KS);
+    int red = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+    int nchunk = avc_cdiv(red, CK), Mp = avc_cdiv(M, 128) * 128;
+    return (long)nchunk * KS * CK * Mp;
+}
+
+int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Cout, int Cin, int KS, int dgrad,
+                    float* dst, void* stream) {
+    if (nsrc < 1 || nsrc > 12 || nsrc * rows_per_src != Cout) return -1;
+    PackArgs p;
+    for (int i = 0; i < nsrc; ++i) p.src[i] = srcs[i];
+    p.nsrc = nsrc;
+    p.rows_per_src = rows_per_src;
+    p.Cout = Cout;
+    p.Cin = Cin;
+    p.KS = KS;
+    p.dgrad = dgrad;
+    p.CK = avc_conv_ck(KS);
+    int red = dgrad ? Cout : Cin;
+    p.M = dgrad ? Cin : Cout;
+    p.nchunk = avc_cdiv(red, p.CK);
+    p.Mp = avc_cdiv(p.M, 128) * 128;
+    p.dst = dst;
+    return avc_launch_pack(p, (hipStream_t)stream);
+}
+
+// y = act(conv1d(reflect_pad(x), W) + bias) [; y2 = y + resmap(res)]      (model.py:21-32)
+int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp,
+                   const float* bias, int Cout, int KS, int stride, int act, float* out, long ob, long oc, int ot,
+                   int ops, const float* res, int res_mode, long rb, long rc, int rt, int Tres, float* out2,
+                   int tile, void* stream) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
+    a.B = B; a.Cred = Cin; a.Tsrc = Tin;
+    a.mode = 0; a.stride = stride; a.mirror = 0;
+    int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
+    a.M = Cout; a.Mp = avc_cdiv(Cout, 128) * 128;
+    a.Tout = (Tin + padL + padR - KS) / stride + 1;
+    a.ob = ob; a.oc = oc; a.ot = ot; a.ops = ops;
+    a.act = act;
+    a.res_mode = res_mode; a.res_to_primary = 0;
+    a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
+    a.CK = avc_conv_ck(KS);
+    a.ngroups = 1;
+    a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = out; a.g[0].out2 = out2; a.g[0].res = res; a.g[0].mask = nullptr;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.CK);
+    return avc_launch_conv(a, (hipStream_t)stream, tile);
+}
+
+// dx = conv1d_input_grad(dy) including the adjoint of the reflect padding
+//   [+ resT(res)] ; dx2 = dx * (mask > 0)
+int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int B, int Cout, int Tdy, const float* wpd,
+                     int Cin, int KS, int stride, int Tin, float* dx, long ob, long oc, int ot, const float* res,
+                     int res_mode, long rb, long rc, int rt, int Tres, float* dx2, const float* mask, int tile,
+                     void* stream) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
+    a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
+    a.mode = 1; a.stride = stride;
+    int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
+    a.mirror = (KS > 1) ? 1 : 0;
+    a.M = Cin; a.Mp = avc_cdiv(Cin, 128) * 128;
+    a.Tout = Tin;
+    a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
+    a.act = 0;
+    a.res_mode = res_mode; a.res_to_primary = 1;
+    a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
+    a.CK = avc_conv_ck(KS);
+    a.ngroups = 1;
+    a.g[0].wp = wpd; a.g[0].bias = nullptr; a.g[0].out = dx; a.g[0].out2 = dx2; a.g[0].res = res; a.g[0].mask = mask;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.CK);
+    return avc_launch_conv(a, (hipStream_t)stream, tile);
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// Lane-level CPU simulator of the subset of HIP used by csrc/*.hip.
+//
+// TEST INFRASTRUCTURE ONLY.  There is no GPU in the build container, so the
+// kernel *logic* (index maps, LDS layouts, MFMA fragment maps, barriers) is
+// debugged by compiling the very same .hip sources for the host with
+//     clang++ -x c++ -include tests/emu/hip_emu.h ...
+// Every HIP thread becomes a fiber; __syncthreads / wave shuffles / MFMA are
+// rendezvous points.  The resulting libavc_emu.so is loaded only by tests/ —
+// the product loader (adaptive_voice_conversion_amd/_lib.py) never looks at it.
+#pragma once
+#define AVC_EMU 1
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+
+namespace emu {
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void block_barrier();
+void wave_sync();
+void* dyn_smem();
+void* wave_buf();  // 64 x 16-byte slots shared by the current wave
+int lane();
+int wave_lanes();
+
+template <class T>
+static inline T exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 16, "slot");
+    char* buf = (char*)wave_buf();
+    memcpy(buf + 16 * lane(), &v, sizeof(T));
+    wave_sync();
+    T r;
+    int n = wave_lanes();
+    if (src_lane < 0 || src_lane >= n) src_lane = lane();
+    memcpy(&r, buf + 16 * src_lane, sizeof(T));
+    wave_sync();
+    return r;
+}
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)   (cdna_hip_programming.md §3)
+static inline f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
+    float2* buf = (float2*)wave_buf();  // 16-byte slots -> use as float2 at stride 2
+    int l = lane();
+    buf[2 * l] = make_float2(a, b);
+    wave_sync();
+    int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av = buf[2 * (row + 32 * k)].x;
+            float bv = buf[2 * (col + 32 * k)].y;
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C: col=l&15,row=4*(l>>4)+r
+static inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
+    float2* buf = (float2*)wave_buf();
+    int l = lane();
+    buf[2 * l] = make_float2(a, b);
+    wave_sync();
+    int col = l & 15, q = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * q + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(buf[2 * (row + 16 * k)].x, buf[2 * (col + 16 * k)].y, acc);
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+}  // namespace emu
+
+#define __syncthreads() emu::block_barrier()
+#define __builtin_amdgcn_s_barrier() emu::block_barrier()
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4((a), (b), (c))
+
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int l = emu::lane();
+    int src = l ^ mask;
+    if ((src / width) != (l / width)) src = l;
+    return emu::exchange(v, src);
+}
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = emu::lane();
+    int src = l + (int)d;
+    if ((src / width) != (l / width)) src = l;
+    return emu::exchange(v, src);
+}
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    int l = emu::lane();
+    return emu::exchange(v, (l / width) * width + (src % width));
+}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::exchange(v, 0); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float __fsqrt_rn(float a) { return sqrtf(a); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline void __threadfence() {}
+
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_smem();
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

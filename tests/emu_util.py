@@ -1,0 +1,41 @@
+"""Loads the CPU lane-level simulation of the HIP kernels (tests/emu/libavc_emu.so).
+
+Test infrastructure only: the product loader never touches this library.  The
+library is rebuilt from adaptive_voice_conversion_amd/csrc/*.hip when stale.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "adaptive_voice_conversion_amd", "csrc")
+SO = os.path.join(ROOT, "tests", "emu", "libavc_emu.so")
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    srcs = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "tests", "emu", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(s) > t for s in srcs if not s.endswith(".so"))
+
+
+def emu_lib():
+    global _lib
+    if _lib is None:
+        if _stale():
+            subprocess.check_call([os.path.join(CSRC, "build_emu.sh")])
+        _lib = ctypes.CDLL(SO)
+    return _lib
+
+
+def P(t):
+    """device-pointer argument for a (CPU) torch tensor or None"""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+L = ctypes.c_long
+I = ctypes.c_int
