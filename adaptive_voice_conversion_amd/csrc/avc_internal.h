@@ -15,3 +15,8 @@ struct PackArgs {
 extern "C" int avc_conv_ck(int KS);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
+
+void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+                    int* chunks_per_wg, int* nsplit);
+int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
+int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream);

@@ -1,0 +1,226 @@
+// Weight gradient of the reflect-padded Conv1d on the fp32 MFMA
+// (reference: autograd of model.py:21-32; dW[co,ci,j] = sum_{b,t} dy[b,co,t] * xpad[b,ci,t*s+j]).
+//
+// GEMM view: M = co, N = (ci, tap), K = (b, t).  A workgroup owns a 64co x 64ci
+// x KS tile (4 waves, each 32co x 32ci x KS accumulators) and a contiguous range
+// of 32-column K-chunks; partial tiles go to a slab [split][Cout][Cin][KS] that a
+// second kernel sums in a fixed order (deterministic, no atomics).  The bias
+// gradient (row sums of dy) is produced by the ci-tile-0 workgroups from the dy
+// tile they already hold in LDS.
+#include <hip/hip_runtime.h>
+
+#include "avc_common.h"
+#include "avc_internal.h"
+
+#define WG_DYROW 33
+#define WG_MAXX 20
+
+static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
+    return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
+}
+
+template <int KS>
+__global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1, li = lane & 31, h = lane >> 5;
+    const int ci_tiles = avc_cdiv(a.Cin, 64);
+    const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
+    const int z = blockIdx.y;
+    const int Tc = a.Tc, spc = a.spc;
+    const int XSEG = (Tc - 1) * a.stride + KS;
+    const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
+    float* dyT = smem;                  // [64][WG_DYROW]
+    float* xT = smem + 64 * WG_DYROW;   // [64][XROW]
+    const int nX = 64 * XROW;
+    const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float dbsum = 0.f;
+
+    float dreg[8], xreg[WG_MAXX];
+    auto load_regs = [&](int chunk) {
+        int cb, t0;
+        if (spc == 1) {
+            cb = chunk / a.chunks_per_sample;
+            t0 = (chunk % a.chunks_per_sample) * 32;
+        } else {
+            cb = chunk * spc;
+            t0 = 0;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int e = tid + it * AVC_THREADS;
+            int row = e >> 5, qcol = e & 31;
+            int sl = qcol / Tc, tl = qcol - sl * Tc;
+            int b = cb + sl, t = t0 + tl, co = co0 + row;
+            float v = 0.f;
+            if (b < a.B && t < a.Tout && co < a.Cout)
+                v = a.dy.ptr[(long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st];
+            dreg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < WG_MAXX; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nX) {
+                int row = e / XROW, pp = e - row * XROW;
+                int sl = pp / XSEG, p = pp - sl * XSEG;
+                int b = cb + sl, ci = ci0 + row;
+                float v = 0.f;
+                if (sl < spc && b < a.B && ci < a.Cin) {
+                    int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
+                    if (r >= 0 && r < a.Tin) v = a.x.ptr[(long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st];
+                }
+                xreg[it] = v;
+            }
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int e = tid + it * AVC_THREADS;
+            dyT[(e >> 5) * WG_DYROW + (e & 31)] = dreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WG_MAXX; ++it) {
+            int e = tid + it * AVC_THREADS;
+            if (e < nX) xT[e] = xreg[it];
+        }
+    };
+
+    const int c_begin = z * a.chunks_per_wg;
+    int c_end = c_begin + a.chunks_per_wg;
+    if (c_end > a.total_chunks) c_end = a.total_chunks;
+
+    if (c_begin < c_end) load_regs(c_begin);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        store_lds();
+        __syncthreads();
+        if (chunk + 1 < c_end) load_regs(chunk + 1);
+        const float* arow = dyT + (wave_m * 32 + li) * WG_DYROW;
+        const float* brow = xT + (wave_n * 32 + li) * XROW;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            int qcol = 2 * s + h;
+            int sl = qcol / Tc, tl = qcol - sl * Tc;
+            float av = arow[qcol];
+            const float* bp = brow + sl * XSEG + tl * a.stride;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j], acc[j], 0, 0, 0);
+        }
+        if (do_db) {
+            const float* dr = dyT + (tid >> 2) * WG_DYROW + (tid & 3) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dbsum += dr[k];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: partial tile -> slab[z][co][ci][j]
+    float* slab = a.slab + (long)z * a.slab_stride;
+    const int ci = ci0 + wave_n * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout && ci < a.Cin) {
+            float* dst = slab + ((long)co * a.Cin + ci) * KS;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) dst[j] = acc[j][r];
+        }
+    }
+    if (do_db) {
+        dbsum += __shfl_xor(dbsum, 1);
+        dbsum += __shfl_xor(dbsum, 2);
+        int co = co0 + (tid >> 2);
+        if ((tid & 3) == 0 && co < a.Cout) a.dbslab[(long)z * a.db_stride + co] = dbsum;
+    }
+}
+
+// out[e] = sum_z slab[z*stride + e]   (fixed order -> deterministic)
+struct ReduceSeg {
+    const float* slab;
+    float* dst;
+    long stride;
+    int n, nsplit;
+};
+struct ReduceArgs {
+    ReduceSeg seg[16];
+    int nseg;
+};
+
+__global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceArgs a) {
+    const ReduceSeg s = a.seg[blockIdx.y];
+    for (int e = blockIdx.x * AVC_THREADS + threadIdx.x; e < s.n; e += gridDim.x * AVC_THREADS) {
+        float v = 0.f;
+        for (int zz = 0; zz < s.nsplit; ++zz) v += s.slab[(long)zz * s.stride + e];
+        s.dst[e] = v;
+    }
+}
+
+// --------------------------------------------------------------------------
+void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+                    int* chunks_per_wg, int* nsplit) {
+    if (Tout >= 32) {
+        *Tc = 32;
+        *spc = 1;
+        *chunks_per_sample = avc_cdiv(Tout, 32);
+        *total_chunks = B * *chunks_per_sample;
+    } else {
+        int p = 1;
+        while (p < Tout) p <<= 1;
+        *Tc = p;
+        *spc = 32 / p;
+        *chunks_per_sample = 1;
+        *total_chunks = avc_cdiv(B, *spc);
+    }
+    int tiles = avc_cdiv(Cout, 64) * avc_cdiv(Cin, 64);
+    int want = 512 / tiles;
+    if (want < 1) want = 1;
+    if (want > *total_chunks) want = *total_chunks;
+    *chunks_per_wg = avc_cdiv(*total_chunks, want);
+    *nsplit = avc_cdiv(*total_chunks, *chunks_per_wg);
+}
+
+template <int KS>
+static void launch_wgrad_ks(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS>), grid, dim3(AVC_THREADS), lds, stream, a);
+}
+
+int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
+    if (a.KS < 1 || a.KS > 8) return -1;
+    if (a.padL >= a.Tin) return -6;
+    int XSEG = (a.Tc - 1) * a.stride + a.KS;
+    int XROW = (a.spc * XSEG) | 1;
+    if (64 * XROW > AVC_THREADS * WG_MAXX) return -3;
+    size_t lds = (size_t)(64 * WG_DYROW + 64 * XROW) * 4 + 16;
+    dim3 grid(avc_cdiv(a.Cout, 64) * avc_cdiv(a.Cin, 64), nsplit);
+    switch (a.KS) {
+        case 1: launch_wgrad_ks<1>(a, grid, lds, stream); break;
+        case 2: launch_wgrad_ks<2>(a, grid, lds, stream); break;
+        case 3: launch_wgrad_ks<3>(a, grid, lds, stream); break;
+        case 4: launch_wgrad_ks<4>(a, grid, lds, stream); break;
+        case 5: launch_wgrad_ks<5>(a, grid, lds, stream); break;
+        case 6: launch_wgrad_ks<6>(a, grid, lds, stream); break;
+        case 7: launch_wgrad_ks<7>(a, grid, lds, stream); break;
+        default: launch_wgrad_ks<8>(a, grid, lds, stream); break;
+    }
+    return (int)hipGetLastError();
+}
+
+int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream) {
+    ReduceArgs r;
+    r.nseg = 1;
+    r.seg[0].slab = slab;
+    r.seg[0].dst = dst;
+    r.seg[0].stride = stride;
+    r.seg[0].n = n;
+    r.seg[0].nsplit = nsplit;
+    int blocks = avc_cdiv(n, AVC_THREADS);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1), dim3(AVC_THREADS), 0, stream, r);
+    return (int)hipGetLastError();
+}

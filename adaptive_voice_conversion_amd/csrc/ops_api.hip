@@ -86,4 +86,33 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     return avc_launch_conv(a, (hipStream_t)stream, tile);
 }
 
+// workspace (floats) needed by avc_conv1d_wgrad for the split-K slabs
+long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
+    int Tc, spc, cps, tot, cpw, nsplit;
+    avc_wgrad_plan(B, Cin, Cout, Tout, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
+    return (long)nsplit * ((long)Cout * Cin * KS + Cout);
+}
+
+// dW[co,ci,j] = sum_{b,t} dy[b,co,t] * reflect_pad(x)[b,ci,t*s+j] ; db[co] = sum dy[b,co,t]
+int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* dy, long syb, long syc, int syt, int yps,
+                     int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride, float* dW, float* db, float* ws,
+                     void* stream) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
+    a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
+    a.KS = KS; a.padL = KS / 2; a.stride = stride;
+    int nsplit;
+    avc_wgrad_plan(B, Cin, Cout, Tout, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+    long wsz = (long)Cout * Cin * KS;
+    a.slab = ws; a.slab_stride = wsz;
+    a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;
+    int rc = avc_launch_wgrad(a, nsplit, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, (hipStream_t)stream);
+    if (rc || !db) return rc;
+    return avc_launch_reduce(a.dbslab, a.db_stride, nsplit, Cout, db, (hipStream_t)stream);
+}
+
 }  // extern "C"

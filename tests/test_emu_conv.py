@@ -145,3 +145,38 @@ def test_conv_dgrad_join_and_mask():
     assert rc == 0
     torch.testing.assert_close(dx, ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dx2, ref * (a_prev > 0), rtol=1e-5, atol=1e-5)
+
+
+WG = [
+    # B, Cin, Cout, T, KS, stride
+    (2, 16, 32, 32, 5, 1),
+    (3, 24, 40, 20, 5, 2),
+    (2, 70, 33, 21, 5, 2),
+    (1, 16, 32, 70, 5, 1),
+    (2, 8, 32, 19, 8, 1),
+    (2, 8, 32, 17, 2, 1),
+    (1, 40, 32, 33, 1, 1),
+    (9, 16, 32, 3, 5, 1),
+    (1, 16, 130, 200, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", WG)
+def test_conv_wgrad_matches_autograd(B, Cin, Cout, T, KS, stride):
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(B * 31 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = O.pad_conv(x, w, b, stride)
+    dy = torch.randn(y.shape, generator=g)
+    dw_ref, db_ref = torch.autograd.grad(y, [w, b], dy)
+    lib.avc_conv1d_wgrad_ws_floats.restype = ctypes.c_long
+    ws = torch.full((lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, y.shape[2], KS),), float("nan"))
+    dW = torch.full((Cout, Cin, KS), float("nan"))
+    db = torch.full((Cout,), float("nan"))
+    rc = lib.avc_conv1d_wgrad(P(x), L(x.stride(0)), L(x.stride(1)), I(1), P(dy), L(dy.stride(0)), L(dy.stride(1)), I(1),
+                              1, B, Cin, Cout, T, y.shape[2], KS, stride, P(dW), P(db), P(ws), None)
+    assert rc == 0
+    torch.testing.assert_close(dW, dw_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db, db_ref, rtol=1e-4, atol=1e-4)
