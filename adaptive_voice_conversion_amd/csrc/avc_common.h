@@ -68,6 +68,49 @@ struct WgradArgs {
     int wrow0;     // row offset (bank/grouped layers write a sub-block)
 };
 
+struct INFwdArgs {
+    const float* y;   // conv output rows [R][T]
+    float* out;       // relu((y-mean)*rstd*gamma+beta) [+ resmap(res)]
+    float* mean;      // [R] saved for backward
+    float* rstd;      // [R]
+    const float* cond;  // AdaIN affine [B][cond_sb]: beta = cond[off + c], gamma = cond[off + C + c]; null = plain IN
+    long cond_sb;
+    int cond_off;
+    const float* res;   // residual rows [R][Tres] (contiguous) or null
+    int res_mode, Tres;
+    int R, C, T, relu;
+};
+
+struct INBwdArgs {
+    const float* g;   // dL/d(out) rows [R][T]
+    const float* y;   // conv output (pre-norm), as in forward
+    const float* mean;
+    const float* rstd;
+    const float* cond;
+    long cond_sb;
+    int cond_off;
+    float* dy;        // dL/dy
+    float* dcond;     // [B][dcond_sb]: dbeta -> [off + c], dgamma -> [off + C + c]; null for plain IN
+    long dcond_sb;
+    int dcond_off;
+    int R, C, T, relu;
+};
+
+struct AdamArgs {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    float* vmax;
+    long n;
+    const float* partial;  // per-block sums of g^2
+    int npartial;
+    float grad_prescale;   // 1/world_size after a summing all-reduce, else 1
+    float max_norm, weight_decay, beta1, beta2, eps, sqrt_bc2, step_size;
+    int amsgrad, write_clipped;
+    float* gnorm_out;
+};
+
 static inline __host__ __device__ int avc_reflect(int v, int T) {
     // F.pad(mode='reflect'): mirror without repeating the edge (model.py:28-30)
     if (v < 0) v = -v;

@@ -20,3 +20,19 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* 
                     int* chunks_per_wg, int* nsplit);
 int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
 int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream);
+
+int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
+int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);
+int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int M, int T, float* dst, long db, long dc,
+                         hipStream_t s);
+int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hipStream_t s);
+int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, hipStream_t s);
+int avc_launch_reparam_fwd(const float* muls, const float* eps, int B, int C, int Tb, float* z, hipStream_t s);
+int avc_launch_latent_bwd(const float* muls, const float* eps, const float* dz, const float* dmuls_up, int B, int C,
+                          int Tb, float lambda_kl_over_n, float* dmuls, hipStream_t s);
+int avc_loss_blocks(long n);
+int avc_launch_loss(const float* dec, const float* x, long sxb, long sxc, int sxt, int B, int M, int T, const float* muls,
+                    int C, int Tb, float lambda_rec, float* ddec, float* partial, float* losses, hipStream_t s);
+int avc_adam_blocks(long n);
+int avc_launch_sumsq(const float* g, long n, float* partial, hipStream_t s);
+int avc_launch_clip_adam(const AdamArgs& a, hipStream_t s);

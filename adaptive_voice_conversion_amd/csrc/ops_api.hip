@@ -3,6 +3,7 @@
 // Used by the op-level parity tests and by external callers that want single
 // kernels; the whole-model path goes through engine.hip.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -113,6 +114,47 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, (hipStream_t)stream);
     if (rc || !db) return rc;
     return avc_launch_reduce(a.dbslab, a.db_stride, nsplit, Cout, db, (hipStream_t)stream);
+}
+
+// out = relu((y - mean_T)/sqrt(var_T + 1e-5) * gamma + beta) [+ resmap(res)]; saves mean/rstd
+int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu,
+                     const float* res, int res_mode, int Tres, float* out, float* mean, float* rstd, void* stream) {
+    INFwdArgs a;
+    a.y = y; a.out = out; a.mean = mean; a.rstd = rstd;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
+    a.R = B * C; a.C = C; a.T = T; a.relu = relu;
+    return avc_launch_in_fwd(a, (hipStream_t)stream);
+}
+
+int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const float* rstd, int B, int C, int T,
+                     const float* cond, long cond_sb, int cond_off, int relu, float* dy, float* dcond, long dcond_sb,
+                     int dcond_off, void* stream) {
+    INBwdArgs a;
+    a.g = g; a.y = y; a.mean = mean; a.rstd = rstd;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.dy = dy; a.dcond = dcond; a.dcond_sb = dcond_sb; a.dcond_off = dcond_off;
+    a.R = B * C; a.C = C; a.T = T; a.relu = relu;
+    return avc_launch_in_bwd(a, (hipStream_t)stream);
+}
+
+long avc_clip_adam_ws_floats(long n) { return avc_adam_blocks(n); }
+
+// clip_grad_norm_(max_norm) + Adam(amsgrad, coupled weight decay) on flat buffers; step is 1-based
+int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long n, int step, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int amsgrad, float max_norm, float grad_prescale,
+                       int write_clipped, float* ws, float* gnorm_out, void* stream) {
+    int rc = avc_launch_sumsq(g, n, ws, (hipStream_t)stream);
+    if (rc) return rc;
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.vmax = vmax; a.n = n;
+    a.partial = ws; a.npartial = avc_adam_blocks(n);
+    a.grad_prescale = grad_prescale; a.max_norm = max_norm; a.weight_decay = weight_decay;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.sqrt_bc2 = (float)sqrt(bc2); a.step_size = (float)((double)lr / bc1);
+    a.amsgrad = amsgrad; a.write_clipped = write_clipped; a.gnorm_out = gnorm_out;
+    return avc_launch_clip_adam(a, (hipStream_t)stream);
 }
 
 }  // extern "C"
