@@ -1,0 +1,74 @@
+"""ctypes binding of libavc_hip.so (the C ABI of include/avc_hip.h).
+
+The product path has NO fallback: if the gfx950 extension is missing or fails
+to load, importing code gets a RuntimeError telling how to build it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libavc_hip.so")
+_lib = None
+
+MAX_BLOCKS = 8
+
+
+class EncoderCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("c_in", "c_h", "c_out", "kernel_size", "bank_size", "bank_scale", "c_bank",
+                                            "n_conv_blocks", "n_dense_blocks")] + [("subsample", ctypes.c_int * MAX_BLOCKS)]
+
+
+class DecoderCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("c_in", "c_cond", "c_h", "c_out", "kernel_size", "n_conv_blocks")] + \
+               [("upsample", ctypes.c_int * MAX_BLOCKS)]
+
+
+class ModelCfg(ctypes.Structure):
+    _fields_ = [("spk", EncoderCfg), ("enc", EncoderCfg), ("dec", DecoderCfg)]
+
+
+c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+
+def declare(lib):
+    """Attach prototypes (so that 64-bit strides/pointers are marshalled correctly)."""
+    lib.avc_version.restype = c_int
+    lib.avc_last_error.restype = ctypes.c_char_p
+    lib.avc_plan_create.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.avc_plan_destroy.argtypes = [c_void_p]
+    lib.avc_plan_destroy.restype = None
+    lib.avc_plan_num_params.argtypes = [c_void_p]
+    lib.avc_plan_param_floats.argtypes = [c_void_p]
+    lib.avc_plan_param_floats.restype = c_long
+    lib.avc_plan_param_info.argtypes = [c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long), ctypes.POINTER(c_int * 3)]
+    lib.avc_plan_workspace_floats.argtypes = [c_void_p]
+    lib.avc_plan_workspace_floats.restype = c_long
+    lib.avc_plan_buffer.argtypes = [c_void_p, ctypes.c_char_p]
+    lib.avc_plan_buffer.restype = c_long
+    lib.avc_plan_out_len.argtypes = [c_void_p]
+    lib.avc_plan_latent_len.argtypes = [c_void_p]
+    lib.avc_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
+                                c_void_p, c_void_p, c_void_p]
+    lib.avc_loss.argtypes = [c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p, c_void_p]
+    lib.avc_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]
+    lib.avc_clip_adam_ws_floats.argtypes = [c_long]
+    lib.avc_clip_adam_ws_floats.restype = c_long
+    lib.avc_clip_adam_step.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_float] * 5 + [c_int, c_float, c_float, c_int,
+                                                                                        c_void_p, c_void_p, c_void_p]
+    return lib
+
+
+def load():
+    """The gfx950 library, or a loud failure (never a CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or adaptive_voice_conversion_amd/csrc/build.sh)")
+        try:
+            _lib = declare(ctypes.CDLL(LIB_PATH))
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    return _lib

@@ -35,7 +35,8 @@ struct ConvGroup {
     float* out2;        // secondary output (may be null)
     const float* res;   // residual / gradient-join source (may be null)
     const float* mask;  // secondary = value * (mask > 0)      (ReLU backward)
-    int KS, padL, padR, nchunk;
+    int KS, padL, padR, nchunk, CK;
+    int pad_[3];
 };
 
 struct ConvArgs {
@@ -51,7 +52,6 @@ struct ConvArgs {
     int res_mode, res_to_primary;
     long rb, rc;
     int rt, Tres;
-    int CK;
     int ngroups;
     ConvGroup g[AVC_MAX_GROUPS];
 };
@@ -68,6 +68,12 @@ struct WgradArgs {
     int wrow0;     // row offset (bank/grouped layers write a sub-block)
 };
 
+struct ReduceSeg {
+    const float* slab;
+    float* dst;
+    long stride;
+    int n, nsplit;
+};
 struct INFwdArgs {
     const float* y;   // conv output rows [R][T]
     float* out;       // relu((y-mean)*rstd*gamma+beta) [+ resmap(res)]

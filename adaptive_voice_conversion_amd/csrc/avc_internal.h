@@ -36,3 +36,8 @@ int avc_launch_loss(const float* dec, const float* x, long sxb, long sxc, int sx
 int avc_adam_blocks(long n);
 int avc_launch_sumsq(const float* g, long n, float* partial, hipStream_t s);
 int avc_launch_clip_adam(const AdamArgs& a, hipStream_t s);
+int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream);
+struct avc_plan;
+int avc_backward_impl(const avc_plan*, const float*, const float*, long, long, int, const float*, long, long, int,
+                      const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t, bool,
+                      long*);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int li = lane & 31, h = lane >> 5;
 
-    const int KS = g.KS, padL = g.padL, padR = g.padR, CK = a.CK, nchunk = g.nchunk;
+    const int KS = g.KS, padL = g.padL, padR = g.padR, CK = g.CK, nchunk = g.nchunk;
     const int Tout = a.Tout;
     const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
     const int ROW = q.ROW;
@@ -337,7 +337,7 @@ static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     size_t worst = 0;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
-        size_t AS = (size_t)a.g[gi].KS * a.CK * BM, XS = (size_t)a.CK * q.ROW;
+        size_t AS = (size_t)a.g[gi].KS * a.g[gi].CK * BM, XS = (size_t)a.g[gi].CK * q.ROW;
         size_t bytes = (2 * AS + 2 * XS + q.ROW) * 4;
         worst = bytes > worst ? bytes : worst;
     }
@@ -353,7 +353,7 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
-    if (a.Mp % 128 != 0 || a.CK % 2 != 0) return -2;
+    if (a.Mp % 128 != 0) return -2;
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
     int tile = force_tile;
@@ -371,8 +371,9 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     int BN = (tile == 22) ? 128 : 64;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
-        if ((long)a.CK * q.ROW > (long)AVC_THREADS * AVC_CONV_MAXX) return -3;
-        if ((long)a.g[gi].KS * a.CK * (BM / 4) > (long)AVC_THREADS * AVC_CONV_MAXA) return -4;
+        if (a.g[gi].CK % 2 != 0) return -2;
+        if ((long)a.g[gi].CK * q.ROW > (long)AVC_THREADS * AVC_CONV_MAXX) return -3;
+        if ((long)a.g[gi].KS * a.g[gi].CK * (BM / 4) > (long)AVC_THREADS * AVC_CONV_MAXA) return -4;
     }
     size_t lds = conv_lds_bytes(a, BM, BN);
     if (lds > 160 * 1024) return -5;

@@ -141,12 +141,6 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
 }
 
 // out[e] = sum_z slab[z*stride + e]   (fixed order -> deterministic)
-struct ReduceSeg {
-    const float* slab;
-    float* dst;
-    long stride;
-    int n, nsplit;
-};
 struct ReduceArgs {
     ReduceSeg seg[16];
     int nseg;
@@ -208,6 +202,21 @@ int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
         case 7: launch_wgrad_ks<7>(a, grid, lds, stream); break;
         default: launch_wgrad_ks<8>(a, grid, lds, stream); break;
     }
+    return (int)hipGetLastError();
+}
+
+int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {
+    if (n < 1 || n > 16) return -1;
+    ReduceArgs r;
+    r.nseg = n;
+    int maxn = 0;
+    for (int i = 0; i < n; ++i) {
+        r.seg[i] = segs[i];
+        maxn = segs[i].n > maxn ? segs[i].n : maxn;
+    }
+    int blocks = avc_cdiv(maxn, AVC_THREADS);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, n), dim3(AVC_THREADS), 0, stream, r);
     return (int)hipGetLastError();
 }
 

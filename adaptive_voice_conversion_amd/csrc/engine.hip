@@ -1,0 +1,941 @@
+// Whole-model orchestration of the AdaIN-VC autoencoder on gfx950: builds the
+// launch plan for one (B, T, T_cond) shape and issues the forward / backward
+// kernel sequences on the caller's stream.
+//
+// Reference being replaced (never copied): AE.forward / AE.inference
+// (model.py:380-391), SpeakerEncoder.forward (:265-277), ContentEncoder.forward
+// (:301-323), Decoder.forward (:347-371) and their autograd; the loss of
+// solver.py:84-88.  Parameter order = state_dict registration order.
+//
+// HBM layout: one caller-owned fp32 workspace.  Packed weights, every saved
+// activation ([B,C,T], T contiguous), IN statistics, gradient temporaries and
+// the split-K slabs of the weight gradients live at fixed offsets decided at
+// plan creation; nothing is allocated, freed or synchronised here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "avc_common.h"
+#include "avc_hip.h"
+#include "avc_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int rc, const char* what) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s (rc=%d)", what, rc);
+    g_err = buf;
+    return rc;
+}
+#define RUN(expr)                                  \
+    do {                                           \
+        int _rc = (expr);                          \
+        if (_rc != 0) return fail(_rc, #expr);     \
+    } while (0)
+
+extern "C" const char* avc_last_error(void) { return g_err.c_str(); }
+extern "C" int avc_version(void) { return 100; }
+
+struct ParamT {
+    long off, numel;
+    int d[3];
+};
+
+struct LayerP {
+    int Cout = 0, Cin = 0, KS = 1, stride = 1;
+    int nsrc = 1, rows = 0;
+    int w[12], b[12];
+    long wpf = -1, wpd = -1, bpk = -1;
+    int CK = 8, nchunk_f = 0, nchunk_d = 0, Mp_f = 0, Mp_d = 0, dgM = 0;
+    bool need_dgrad = true;
+};
+
+struct EncNet {
+    avc_encoder_cfg c;
+    int nb = 0, CC = 0, n = 0, nd = 0;
+    int T[AVC_MAX_BLOCKS + 1];
+    std::vector<int> bank, c1, c2, dn1, dn2;
+    int in_conv = -1, outl = -1, heads = -1;
+    long cat = -1, dcat = -1, h0 = -1;              // h0: speaker relu(in_conv) / content y0
+    long out[AVC_MAX_BLOCKS + 1];                   // block outputs (out[0] = after in_conv stage)
+    long a1[AVC_MAX_BLOCKS], a2[AVC_MAX_BLOCKS];    // speaker: relu outputs; content: a1 = relu(IN(y1))
+    long y1[AVC_MAX_BLOCKS], y2[AVC_MAX_BLOCKS];    // content conv outputs (pre-norm)
+    long st0 = -1, st1[AVC_MAX_BLOCKS], st2[AVC_MAX_BLOCKS];  // IN stats: mean at off, rstd at off + B*C
+    long pooled = -1, d1[AVC_MAX_BLOCKS], d2[AVC_MAX_BLOCKS], hd[AVC_MAX_BLOCKS + 1];
+};
+
+struct DecNet {
+    avc_decoder_cfg c;
+    int n = 0;
+    int T[AVC_MAX_BLOCKS + 1];
+    std::vector<int> c1, c2;
+    int in_conv = -1, affine = -1, out_conv = -1;
+    long z = -1, cond = -1, dcond = -1, y0 = -1;
+    long out[AVC_MAX_BLOCKS + 1], y1[AVC_MAX_BLOCKS], a1[AVC_MAX_BLOCKS], y2[AVC_MAX_BLOCKS];
+    long st0 = -1, st1[AVC_MAX_BLOCKS], st2[AVC_MAX_BLOCKS];
+};
+
+struct avc_plan {
+    avc_model_cfg cfg;
+    int B, T, Tc, M, Tb, Tout;
+    std::vector<ParamT> params;
+    long param_floats = 0;
+    std::vector<LayerP> layers;
+    EncNet spk, enc;
+    DecNet dec;
+    long ws_top = 0;
+    std::map<std::string, long> named;
+    // shared gradient temporaries
+    long gA = -1, gB = -1, gC = -1, dyA = -1, dyB = -1;
+    long muls = -1, dmuls = -1, emb = -1, demb = -1, decb = -1, ddec = -1, dz = -1;
+    long losses = -1, loss_partial = -1;
+    long slab = -1, slab_floats = 0;
+    long dhA = -1, dhB = -1, dzA = -1, dzB = -1;
+
+    long alloc(long n) {
+        long o = ws_top;
+        ws_top += (n + 63) / 64 * 64;
+        return o;
+    }
+    const float* par(const float* params_, int idx) const { return params_ + params[idx].off; }
+};
+
+// --------------------------------------------------------------------------
+// plan construction
+// --------------------------------------------------------------------------
+static int add_param(avc_plan* p, int d0, int d1, int d2) {
+    ParamT t;
+    t.d[0] = d0;
+    t.d[1] = d1;
+    t.d[2] = d2;
+    t.numel = (long)d0 * (d1 > 0 ? d1 : 1) * (d2 > 0 ? d2 : 1);
+    t.off = p->param_floats;
+    p->param_floats += (t.numel + 3) / 4 * 4;
+    p->params.push_back(t);
+    return (int)p->params.size() - 1;
+}
+
+static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool conv3d) {
+    LayerP L;
+    L.Cout = Cout;
+    L.Cin = Cin;
+    L.KS = KS;
+    L.stride = stride;
+    L.nsrc = 1;
+    L.rows = Cout;
+    L.w[0] = add_param(p, Cout, Cin, conv3d ? KS : 0);
+    L.b[0] = add_param(p, Cout, 0, 0);
+    p->layers.push_back(L);
+    return (int)p->layers.size() - 1;
+}
+
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM) {
+    L.CK = avc_conv_ck(L.KS);
+    L.nchunk_f = avc_cdiv(L.Cin, L.CK);
+    L.nchunk_d = avc_cdiv(L.Cout, L.CK);
+    L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
+    L.need_dgrad = need_dgrad;
+    L.dgM = dgM > 0 ? dgM : L.Cin;
+    L.Mp_d = avc_cdiv(L.dgM, 128) * 128;
+    L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
+    if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CK * L.Mp_d);
+    if (L.nsrc > 1) L.bpk = p->alloc((long)32 * L.Mp_f);
+}
+
+static int validate_enc(const avc_encoder_cfg& c, bool spk) {
+    if (c.c_in < 1 || c.c_h < 1 || c.c_out < 1 || c.c_bank < 1) return -1;
+    if (c.kernel_size < 1 || c.kernel_size > 8) return -1;
+    if (c.bank_scale < 1 || c.bank_size < c.bank_scale || c.bank_size > 8) return -1;
+    if (c.bank_size / c.bank_scale > AVC_MAX_GROUPS) return -1;
+    if (c.n_conv_blocks < 1 || c.n_conv_blocks > AVC_MAX_BLOCKS) return -1;
+    if (spk && (c.n_dense_blocks < 0 || c.n_dense_blocks > AVC_MAX_BLOCKS)) return -1;
+    for (int l = 0; l < c.n_conv_blocks; ++l)
+        if (c.subsample[l] != 1 && c.subsample[l] != 2) return -1;
+    return 0;
+}
+
+static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, bool spk) {
+    e.c = c;
+    e.n = c.n_conv_blocks;
+    e.nd = spk ? c.n_dense_blocks : 0;
+    for (int k = c.bank_scale; k <= c.bank_size; k += c.bank_scale) e.bank.push_back(add_layer(p, c.c_bank, c.c_in, k, 1, true));
+    e.nb = (int)e.bank.size();
+    e.CC = c.c_bank * (c.bank_size / c.bank_scale) + c.c_in;
+    e.in_conv = add_layer(p, c.c_h, e.CC, 1, 1, true);
+    for (int l = 0; l < e.n; ++l) e.c1.push_back(add_layer(p, c.c_h, c.c_h, c.kernel_size, 1, true));
+    for (int l = 0; l < e.n; ++l) e.c2.push_back(add_layer(p, c.c_h, c.c_h, c.kernel_size, c.subsample[l], true));
+    if (spk) {
+        for (int l = 0; l < e.nd; ++l) e.dn1.push_back(add_layer(p, c.c_h, c.c_h, 1, 1, false));
+        for (int l = 0; l < e.nd; ++l) e.dn2.push_back(add_layer(p, c.c_h, c.c_h, 1, 1, false));
+        e.outl = add_layer(p, c.c_out, c.c_h, 1, 1, false);
+    } else {
+        // mean_layer + std_layer stacked into one 2*c_out head (model.py:297-298,321-322)
+        int mean = add_layer(p, c.c_out, c.c_h, 1, 1, true);
+        LayerP& L = p->layers[mean];
+        int wi = add_param(p, c.c_out, c.c_h, 1), bi = add_param(p, c.c_out, 0, 0);
+        L.nsrc = 2;
+        L.rows = c.c_out;
+        L.Cout = 2 * c.c_out;
+        L.w[1] = wi;
+        L.b[1] = bi;
+        e.heads = mean;
+    }
+}
+
+extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out) {
+    if (!cfg || !out || B < 1 || T < 1) return fail(-1, "avc_plan_create: bad arguments");
+    if (T_cond <= 0) T_cond = T;
+    if (validate_enc(cfg->spk, true) || validate_enc(cfg->enc, false)) return fail(-2, "avc_plan_create: unsupported encoder config");
+    const avc_decoder_cfg& dc = cfg->dec;
+    if (dc.n_conv_blocks < 1 || dc.n_conv_blocks > AVC_MAX_BLOCKS || 2 * dc.n_conv_blocks > 12 || dc.kernel_size < 1 || dc.kernel_size > 8)
+        return fail(-2, "avc_plan_create: unsupported decoder config");
+    for (int l = 0; l < dc.n_conv_blocks; ++l)
+        if (dc.upsample[l] != 1 && dc.upsample[l] != 2) return fail(-2, "avc_plan_create: upsample must be 1 or 2");
+    if (cfg->spk.c_in != cfg->enc.c_in || cfg->enc.c_in != dc.c_out || dc.c_in != cfg->enc.c_out || dc.c_cond != cfg->spk.c_out)
+        return fail(-2, "avc_plan_create: inconsistent channel sizes between the three networks");
+
+    avc_plan* p = new avc_plan();
+    p->cfg = *cfg;
+    p->B = B;
+    p->T = T;
+    p->Tc = T_cond;
+    p->M = cfg->enc.c_in;
+
+    // ---- parameters in reference registration order
+    build_enc_params(p, p->spk, cfg->spk, true);
+    build_enc_params(p, p->enc, cfg->enc, false);
+    DecNet& d = p->dec;
+    d.c = dc;
+    d.n = dc.n_conv_blocks;
+    d.in_conv = add_layer(p, dc.c_h, dc.c_in, 1, 1, true);
+    for (int l = 0; l < d.n; ++l) d.c1.push_back(add_layer(p, dc.c_h, dc.c_h, dc.kernel_size, 1, true));
+    for (int l = 0; l < d.n; ++l) d.c2.push_back(add_layer(p, dc.c_h * dc.upsample[l], dc.c_h, dc.kernel_size, 1, true));
+    {
+        int a0 = add_layer(p, 2 * dc.c_h, dc.c_cond, 1, 1, false);
+        LayerP& L = p->layers[a0];
+        L.nsrc = 2 * d.n;
+        L.rows = 2 * dc.c_h;
+        L.Cout = 2 * dc.c_h * L.nsrc;
+        for (int i = 1; i < L.nsrc; ++i) {
+            L.w[i] = add_param(p, 2 * dc.c_h, dc.c_cond, 0);
+            L.b[i] = add_param(p, 2 * dc.c_h, 0, 0);
+        }
+        d.affine = a0;
+    }
+    d.out_conv = add_layer(p, dc.c_out, dc.c_h, 1, 1, true);
+
+    // ---- time schedules + reflect-pad validity (reference raises the same way)
+    auto sched_enc = [&](EncNet& e, int T0) -> int {
+        e.T[0] = T0;
+        int maxpad = e.c.bank_size / 2;
+        if (maxpad >= T0) return -1;
+        for (int l = 0; l < e.n; ++l) {
+            if (e.c.kernel_size / 2 >= e.T[l]) return -1;
+            e.T[l + 1] = avc_cdiv(e.T[l], e.c.subsample[l]);
+        }
+        return 0;
+    };
+    if (sched_enc(p->spk, T_cond) || sched_enc(p->enc, T)) {
+        delete p;
+        return fail(-6, "Padding size should be less than the corresponding input dimension");
+    }
+    p->Tb = p->enc.T[p->enc.n];
+    d.T[0] = p->Tb;
+    for (int l = 0; l < d.n; ++l) {
+        if (dc.kernel_size / 2 >= d.T[l]) {
+            delete p;
+            return fail(-6, "Padding size should be less than the corresponding input dimension");
+        }
+        d.T[l + 1] = d.T[l] * dc.upsample[l];
+    }
+    p->Tout = d.T[d.n];
+
+    // ---- packed weights
+    for (int id : p->spk.bank) finish_layer(p, p->layers[id], false, 0);
+    finish_layer(p, p->layers[p->spk.in_conv], true, p->spk.CC - p->spk.c.c_in);
+    for (int l = 0; l < p->spk.n; ++l) {
+        finish_layer(p, p->layers[p->spk.c1[l]], true, 0);
+        finish_layer(p, p->layers[p->spk.c2[l]], true, 0);
+    }
+    for (int l = 0; l < p->spk.nd; ++l) {
+        finish_layer(p, p->layers[p->spk.dn1[l]], true, 0);
+        finish_layer(p, p->layers[p->spk.dn2[l]], true, 0);
+    }
+    finish_layer(p, p->layers[p->spk.outl], true, 0);
+    for (int id : p->enc.bank) finish_layer(p, p->layers[id], false, 0);
+    finish_layer(p, p->layers[p->enc.in_conv], true, p->enc.CC - p->enc.c.c_in);
+    for (int l = 0; l < p->enc.n; ++l) {
+        finish_layer(p, p->layers[p->enc.c1[l]], true, 0);
+        finish_layer(p, p->layers[p->enc.c2[l]], true, 0);
+    }
+    finish_layer(p, p->layers[p->enc.heads], true, 0);
+    finish_layer(p, p->layers[d.in_conv], true, 0);
+    for (int l = 0; l < d.n; ++l) {
+        finish_layer(p, p->layers[d.c1[l]], true, 0);
+        finish_layer(p, p->layers[d.c2[l]], true, 0);
+    }
+    finish_layer(p, p->layers[d.affine], true, 0);
+    finish_layer(p, p->layers[d.out_conv], true, 0);
+
+    // ---- activations
+    const long Bl = B;
+    auto alloc_enc = [&](EncNet& e, bool spk) {
+        const long C = e.c.c_h;
+        e.cat = p->alloc(Bl * e.CC * e.T[0]);
+        e.dcat = p->alloc(Bl * e.CC * e.T[0]);
+        e.h0 = p->alloc(Bl * C * e.T[0]);
+        e.out[0] = spk ? e.h0 : p->alloc(Bl * C * e.T[0]);
+        if (!spk) e.st0 = p->alloc(2 * Bl * C);
+        for (int l = 0; l < e.n; ++l) {
+            e.a1[l] = p->alloc(Bl * C * e.T[l]);
+            e.out[l + 1] = p->alloc(Bl * C * e.T[l + 1]);
+            if (spk) {
+                e.a2[l] = p->alloc(Bl * C * e.T[l + 1]);
+                e.y1[l] = e.y2[l] = -1;
+            } else {
+                e.a2[l] = -1;
+                e.y1[l] = p->alloc(Bl * C * e.T[l]);
+                e.y2[l] = p->alloc(Bl * C * e.T[l + 1]);
+                e.st1[l] = p->alloc(2 * Bl * C);
+                e.st2[l] = p->alloc(2 * Bl * C);
+            }
+        }
+        if (spk) {
+            e.pooled = p->alloc(C * Bl);
+            e.hd[0] = e.pooled;
+            for (int l = 0; l < e.nd; ++l) {
+                e.d1[l] = p->alloc(C * Bl);
+                e.d2[l] = p->alloc(C * Bl);
+                e.hd[l + 1] = p->alloc(C * Bl);
+            }
+        }
+    };
+    alloc_enc(p->spk, true);
+    alloc_enc(p->enc, false);
+    const long Cz = dc.c_in, Cd = dc.c_h;
+    p->muls = p->alloc(Bl * 2 * Cz * p->Tb);
+    p->dmuls = p->alloc(Bl * 2 * Cz * p->Tb);
+    p->emb = p->alloc(Bl * dc.c_cond);
+    p->demb = p->alloc(Bl * dc.c_cond);
+    d.z = p->alloc(Bl * Cz * p->Tb);
+    p->dz = p->alloc(Bl * Cz * p->Tb);
+    d.cond = p->alloc(Bl * 2 * d.n * 2 * Cd);
+    d.dcond = p->alloc(Bl * 2 * d.n * 2 * Cd);
+    d.y0 = p->alloc(Bl * Cd * d.T[0]);
+    d.out[0] = p->alloc(Bl * Cd * d.T[0]);
+    d.st0 = p->alloc(2 * Bl * Cd);
+    for (int l = 0; l < d.n; ++l) {
+        d.y1[l] = p->alloc(Bl * Cd * d.T[l]);
+        d.a1[l] = p->alloc(Bl * Cd * d.T[l]);
+        d.y2[l] = p->alloc(Bl * Cd * d.T[l + 1]);
+        d.out[l + 1] = p->alloc(Bl * Cd * d.T[l + 1]);
+        d.st1[l] = p->alloc(2 * Bl * Cd);
+        d.st2[l] = p->alloc(2 * Bl * Cd);
+    }
+    p->decb = p->alloc(Bl * p->M * p->Tout);
+    p->ddec = p->alloc(Bl * p->M * p->Tout);
+    p->losses = p->alloc(64);
+    p->loss_partial = p->alloc(2 * 1024);
+
+    // ---- gradient temporaries (sized for the largest [B, C, T] they ever hold)
+    long maxCT = 0;
+    auto upd = [&](long c, long t) { maxCT = (c * t > maxCT) ? c * t : maxCT; };
+    for (int l = 0; l <= p->spk.n; ++l) upd(p->spk.c.c_h, p->spk.T[l]);
+    for (int l = 0; l <= p->enc.n; ++l) upd(p->enc.c.c_h, p->enc.T[l]);
+    for (int l = 0; l <= d.n; ++l) upd(Cd, d.T[l]);
+    upd(p->M, p->Tout);
+    p->gA = p->alloc(Bl * maxCT);
+    p->gB = p->alloc(Bl * maxCT);
+    p->gC = p->alloc(Bl * maxCT);
+    p->dyA = p->alloc(Bl * maxCT);
+    p->dyB = p->alloc(Bl * maxCT);
+    long Cs = p->spk.c.c_h;
+    p->dhA = p->alloc(Cs * Bl);
+    p->dhB = p->alloc(Cs * Bl);
+    p->dzA = p->alloc(Cs * Bl);
+    p->dzB = p->alloc(Cs * Bl);
+
+    p->named["muls"] = p->muls;
+    p->named["emb"] = p->emb;
+    p->named["dec"] = p->decb;
+    p->named["z"] = d.z;
+    p->named["losses"] = p->losses;
+    p->named["d_dec"] = p->ddec;
+    p->named["cond"] = d.cond;
+    p->named["spk_cat"] = p->spk.cat;
+    p->named["enc_cat"] = p->enc.cat;
+    p->named["enc_out0"] = p->enc.out[0];
+    p->named["spk_out0"] = p->spk.out[0];
+    p->named["spk_pooled"] = p->spk.pooled;
+    p->named["enc_outN"] = p->enc.out[p->enc.n];
+    p->named["spk_outN"] = p->spk.out[p->spk.n];
+    p->named["dec_out0"] = d.out[0];
+    p->named["dec_outN"] = d.out[d.n];
+    p->named["d_z"] = p->dz;
+    p->named["d_muls"] = p->dmuls;
+    p->named["d_emb"] = p->demb;
+    p->named["d_cond"] = d.dcond;
+
+    // ---- split-K slabs: size them with a dry run of the backward pass
+    p->slab = p->ws_top;
+    long need = 0;
+    avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
+                      nullptr, nullptr, true, &need);
+    p->slab_floats = need;
+    p->ws_top += (need + 63) / 64 * 64;
+    *out = p;
+    return 0;
+}
+
+extern "C" void avc_plan_destroy(avc_plan* p) { delete p; }
+extern "C" int avc_plan_num_params(const avc_plan* p) { return (int)p->params.size(); }
+extern "C" long avc_plan_param_floats(const avc_plan* p) { return p->param_floats; }
+extern "C" int avc_plan_param_info(const avc_plan* p, int i, long* offset, long* numel, int dims[3]) {
+    if (i < 0 || i >= (int)p->params.size()) return -1;
+    *offset = p->params[i].off;
+    *numel = p->params[i].numel;
+    for (int k = 0; k < 3; ++k) dims[k] = p->params[i].d[k];
+    return 0;
+}
+extern "C" long avc_plan_workspace_floats(const avc_plan* p) { return p->ws_top; }
+extern "C" long avc_plan_buffer(const avc_plan* p, const char* name) {
+    auto it = p->named.find(name);
+    return it == p->named.end() ? -1 : it->second;
+}
+extern "C" int avc_plan_out_len(const avc_plan* p) { return p->Tout; }
+extern "C" int avc_plan_latent_len(const avc_plan* p) { return p->Tb; }
+
+// --------------------------------------------------------------------------
+// launch helpers
+// --------------------------------------------------------------------------
+static void set_group(ConvGroup& g, const float* wp, const float* bias, int KS, int CK, int nchunk) {
+    memset(&g, 0, sizeof(g));
+    g.wp = wp;
+    g.bias = bias;
+    g.KS = KS;
+    g.padL = KS / 2;
+    g.padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
+    g.CK = CK;
+    g.nchunk = nchunk;
+}
+
+static const float* layer_bias(const avc_plan* p, const LayerP& L, const float* params, const float* ws) {
+    return L.nsrc == 1 ? p->par(params, L.b[0]) : ws + L.bpk;
+}
+
+// forward conv of layer L on a source view; caller fills epilogue extras afterwards
+static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, const float* ws, const float* x, long sb,
+                       long sc, int st, int Bn, int Tsrc, float* out, long ob, long oc, int ot, int act) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = x; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = 1;
+    a.B = Bn; a.Cred = L.Cin; a.Tsrc = Tsrc;
+    a.mode = 0; a.stride = L.stride;
+    a.M = L.Cout; a.Mp = L.Mp_f;
+    a.ngroups = 1;
+    set_group(a.g[0], ws + L.wpf, layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+    a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
+    a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
+    a.act = act;
+    a.g[0].out = out;
+    return a;
+}
+
+static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long sb, long sc, int st, int ps, int Bn,
+                         int Tdy, int Tin, float* dx, long ob, long oc, int ot) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = dy; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = ps;
+    a.B = Bn; a.Cred = L.Cout; a.Tsrc = Tdy;
+    a.mode = 1; a.stride = L.stride; a.mirror = (L.KS > 1) ? 1 : 0;
+    a.M = L.dgM; a.Mp = L.Mp_d; a.Tout = Tin;
+    a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
+    a.res_to_primary = 1;
+    a.ngroups = 1;
+    set_group(a.g[0], ws + L.wpd, nullptr, L.KS, L.CK, L.nchunk_d);
+    a.g[0].out = dx;
+    return a;
+}
+
+static void set_res(ConvArgs& a, const float* res, int mode, long rb, long rc, int rt, int Tres) {
+    a.g[0].res = res;
+    a.res_mode = mode;
+    a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
+}
+
+struct Reducer {
+    std::vector<ReduceSeg> segs;
+    hipStream_t s;
+    bool dry;
+    int flush() {
+        for (size_t i = 0; i < segs.size(); i += 16) {
+            int n = (int)std::min<size_t>(16, segs.size() - i);
+            if (!dry) {
+                int rc = avc_launch_reduce_segs(&segs[i], n, s);
+                if (rc) return rc;
+            }
+        }
+        segs.clear();
+        return 0;
+    }
+};
+
+struct BwdCtx {
+    const avc_plan* p;
+    const float* params;
+    float* grads;
+    float* ws;
+    hipStream_t s;
+    bool dry;
+    long slab_used;
+    Reducer red;
+};
+
+// weight + bias gradient of layer L: x = forward input view, dy = output-gradient view
+static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, long xsc, int xst, const float* dy, long ysb,
+                       long ysc, int yst, int yps, int Bn, int Tin, int Tout, int row0 = 0, int rows = -1) {
+    // row0/rows: this launch covers forward output channels [row0, row0+rows) of the dy view given
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    int Cout = rows < 0 ? L.Cout : rows;
+    a.x.ptr = x; a.x.sb = xsb; a.x.sc = xsc; a.x.st = xst; a.x.ps = 1;
+    a.dy.ptr = dy; a.dy.sb = ysb; a.dy.sc = ysc; a.dy.st = yst; a.dy.ps = yps;
+    a.B = Bn; a.Cin = L.Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
+    a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
+    int nsplit;
+    avc_wgrad_plan(Bn, L.Cin, Cout, Tout, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+    long wsz = (long)Cout * L.Cin * L.KS;
+    long need = (long)nsplit * (wsz + Cout);
+    long off = c.slab_used;
+    c.slab_used += (need + 63) / 64 * 64;
+    if (c.dry) return 0;
+    a.slab = c.ws + c.p->slab + off;
+    a.slab_stride = wsz;
+    a.dbslab = a.slab + (long)nsplit * wsz;
+    a.db_stride = Cout;
+    int rc = avc_launch_wgrad(a, nsplit, c.s);
+    if (rc) return rc;
+    for (int s = 0; s < L.nsrc; ++s) {
+        ReduceSeg w;
+        w.slab = a.slab + (long)s * L.rows * L.Cin * L.KS;
+        w.dst = c.grads + c.p->params[L.w[s]].off;
+        w.stride = a.slab_stride;
+        w.n = (int)((long)L.rows * L.Cin * L.KS);
+        w.nsplit = nsplit;
+        ReduceSeg b;
+        b.slab = a.dbslab + (long)s * L.rows;
+        b.dst = c.grads + c.p->params[L.b[s]].off;
+        b.stride = a.db_stride;
+        b.n = L.rows;
+        b.nsplit = nsplit;
+        c.red.segs.push_back(w);
+        c.red.segs.push_back(b);
+    }
+    return 0;
+}
+
+static int pack_layer(const avc_plan* p, const LayerP& L, const float* params, float* ws, hipStream_t s) {
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < L.nsrc; ++i) a.src[i] = p->par(params, L.w[i]);
+    a.nsrc = L.nsrc; a.rows_per_src = L.rows;
+    a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
+    a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
+    a.dst = ws + L.wpf;
+    RUN(avc_launch_pack(a, s));
+    if (L.need_dgrad) {
+        a.dgrad = 1; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
+        a.dst = ws + L.wpd;
+        RUN(avc_launch_pack(a, s));
+    }
+    if (L.nsrc > 1) {  // stacked bias = "weight" with Cin = 1, KS = 1: first Mp floats of the image
+        PackArgs b;
+        memset(&b, 0, sizeof(b));
+        for (int i = 0; i < L.nsrc; ++i) b.src[i] = p->par(params, L.b[i]);
+        b.nsrc = L.nsrc; b.rows_per_src = L.rows;
+        b.Cout = L.Cout; b.Cin = 1; b.KS = 1;
+        b.dgrad = 0; b.CK = 32; b.nchunk = 1; b.M = L.Cout; b.Mp = L.Mp_f;
+        b.dst = ws + L.bpk;
+        RUN(avc_launch_pack(b, s));
+    }
+    return 0;
+}
+
+static int in_fwd(const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
+                  int res_mode, int Tres, float* out, float* stats, hipStream_t s) {
+    INFwdArgs a;
+    a.y = y; a.out = out; a.mean = stats; a.rstd = stats + (long)Bn * C;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1;
+    return avc_launch_in_fwd(a, s);
+}
+
+static int in_bwd(const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
+                  long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s) {
+    INBwdArgs a;
+    a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1;
+    return avc_launch_in_bwd(a, s);
+}
+
+// --------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------
+static int enc_front(const avc_plan* p, const EncNet& e, const float* params, float* ws, const float* x, long sxb,
+                     long sxc, int sxt, hipStream_t s) {
+    // conv_bank (model.py:85-91): all bank members in ONE grouped launch writing the concat buffer in place
+    const int B = p->B, T0 = e.T[0];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
+    a.B = B; a.Cred = e.c.c_in; a.Tsrc = T0;
+    a.mode = 0; a.stride = 1;
+    a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128; a.Tout = T0;
+    a.ob = (long)e.CC * T0; a.oc = T0; a.ot = 1; a.ops = 1;
+    a.act = 1;
+    a.ngroups = e.nb;
+    for (int g = 0; g < e.nb; ++g) {
+        const LayerP& L = p->layers[e.bank[g]];
+        set_group(a.g[g], ws + L.wpf, p->par(params, L.b[0]), L.KS, L.CK, L.nchunk_f);
+        a.g[g].out = ws + e.cat + (long)g * e.c.c_bank * T0;
+    }
+    RUN(avc_launch_conv(a, s, 0));
+    // raw input last (model.py:90)
+    RUN(avc_launch_copy_rows(x, sxb, sxc, sxt, B, e.c.c_in, T0, ws + e.cat + (long)e.nb * e.c.c_bank * T0, (long)e.CC * T0, T0, s));
+    return 0;
+}
+
+static int forward_impl(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                        const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
+    const int B = p->B;
+    // 0. weights -> LDS-image order (they change every optimizer step)
+    for (const LayerP& L : p->layers) RUN(pack_layer(p, L, params, ws, s));
+
+    // ---------------- speaker encoder (model.py:265-277)
+    {
+        const EncNet& e = p->spk;
+        const int C = e.c.c_h;
+        RUN(enc_front(p, e, params, ws, xc, scb, scc, sct, s));
+        {
+            const LayerP& L = p->layers[e.in_conv];
+            ConvArgs a = mk_fwd(p, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        for (int l = 0; l < e.n; ++l) {
+            const int Ti = e.T[l], To = e.T[l + 1];
+            ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
+            RUN(avc_launch_conv(a, s, 0));
+            ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a2[l], (long)C * To, To, 1, 1);
+            b.g[0].out2 = ws + e.out[l + 1];
+            set_res(b, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, (long)C * Ti, Ti, 1, Ti);
+            RUN(avc_launch_conv(b, s, 0));
+        }
+        const int Tn = e.T[e.n];
+        RUN(avc_launch_timepool_fwd(ws + e.out[e.n], B, C, Tn, ws + e.pooled, s));
+        // dense blocks on the channel-major [C][B] matrix viewed as one [1, C, T=B] sample (model.py:252-263)
+        for (int l = 0; l < e.nd; ++l) {
+            ConvArgs a = mk_fwd(p, p->layers[e.dn1[l]], params, ws, ws + e.hd[l], 0, B, 1, 1, B, ws + e.d1[l], 0, B, 1, 1);
+            RUN(avc_launch_conv(a, s, 0));
+            ConvArgs b = mk_fwd(p, p->layers[e.dn2[l]], params, ws, ws + e.d1[l], 0, B, 1, 1, B, ws + e.d2[l], 0, B, 1, 1);
+            b.g[0].out2 = ws + e.hd[l + 1];
+            set_res(b, ws + e.hd[l], AVC_RES_IDENTITY, 0, B, 1, B);
+            RUN(avc_launch_conv(b, s, 0));
+        }
+        // output layer -> emb [B][c_out] row-major
+        ConvArgs o = mk_fwd(p, p->layers[e.outl], params, ws, ws + e.hd[e.nd], 0, B, 1, 1, B, ws + p->emb, 0, 1, e.c.c_out, 0);
+        RUN(avc_launch_conv(o, s, 0));
+    }
+
+    // ---------------- content encoder (model.py:301-323)
+    {
+        const EncNet& e = p->enc;
+        const int C = e.c.c_h;
+        RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
+        {
+            ConvArgs a = mk_fwd(p, p->layers[e.in_conv], params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
+            RUN(avc_launch_conv(a, s, 0));
+            RUN(in_fwd(ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
+        }
+        for (int l = 0; l < e.n; ++l) {
+            const int Ti = e.T[l], To = e.T[l + 1];
+            ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
+            RUN(avc_launch_conv(a, s, 0));
+            RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
+            ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
+            RUN(avc_launch_conv(b, s, 0));
+            RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, Ti,
+                       ws + e.out[l + 1], ws + e.st2[l], s));
+        }
+        const int Tb = p->Tb;
+        ConvArgs h = mk_fwd(p, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
+        RUN(avc_launch_conv(h, s, 0));
+    }
+
+    // ---------------- reparameterisation (model.py:383-384) + decoder (model.py:347-371)
+    {
+        const DecNet& d = p->dec;
+        const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb;
+        RUN(avc_launch_reparam_fwd(ws + p->muls, eps, B, Cz, Tb, ws + d.z, s));
+        const long csb = (long)2 * d.n * 2 * C;
+        {   // all 2n AdaIN affine Linears as ONE GEMM on emb (they share their input)
+            ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        {
+            ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z, (long)Cz * Tb, Tb, 1, B, Tb, ws + d.y0, (long)C * Tb, Tb, 1, 0);
+            RUN(avc_launch_conv(a, s, 0));
+            RUN(in_fwd(ws + d.y0, B, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0], ws + d.st0, s));
+        }
+        for (int l = 0; l < d.n; ++l) {
+            const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
+            ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + d.y1[l], (long)C * Ti, Ti, 1, 0);
+            RUN(avc_launch_conv(a, s, 0));
+            RUN(in_fwd(ws + d.y1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l], ws + d.st1[l], s));
+            // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
+            ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + d.y2[l], (long)C * To, To, 1, 0);
+            b.ops = up;
+            RUN(avc_launch_conv(b, s, 0));
+            RUN(in_fwd(ws + d.y2[l], B, C, To, ws + d.cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l], up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                       ws + d.out[l + 1], ws + d.st2[l], s));
+        }
+        const int To = p->Tout;
+        ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n], (long)C * To, To, 1, B, To, ws + p->decb, (long)p->M * To, To, 1, 0);
+        RUN(avc_launch_conv(o, s, 0));
+    }
+    return 0;
+}
+
+extern "C" int avc_forward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                           const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, void* stream) {
+    if (!p || !params || !x || !ws) return fail(-1, "avc_forward: null argument");
+    if (!x_cond) {
+        x_cond = x; scb = sxb; scc = sxc; sct = sxt;
+    }
+    return forward_impl(p, params, x, sxb, sxc, sxt, x_cond, scb, scc, sct, eps, ws, (hipStream_t)stream);
+}
+
+extern "C" int avc_loss(const avc_plan* p, const float* x, long sxb, long sxc, int sxt, float lambda_rec, float* ws,
+                        void* stream) {
+    if (p->Tout != p->T) return fail(-7, "avc_loss: L1Loss needs dec and x of equal length (T % 8 == 0 for the stock config)");
+    RUN(avc_launch_loss(ws + p->decb, x, sxb, sxc, sxt, p->B, p->M, p->T, ws + p->muls, p->dec.c.c_in, p->Tb, lambda_rec,
+                        ws + p->ddec, ws + p->loss_partial, ws + p->losses, (hipStream_t)stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------
+// backward
+// --------------------------------------------------------------------------
+static int enc_back_front(BwdCtx& c, const EncNet& e, const float* x, long sxb, long sxc, int sxt, const float* dy_in) {
+    // dy_in: gradient wrt the in_conv output [B, C, T0]
+    const avc_plan* p = c.p;
+    const int B = p->B, C = e.c.c_h, T0 = e.T[0];
+    float* ws = c.ws;
+    const LayerP& L = p->layers[e.in_conv];
+    RUN(wgrad_layer(c, L, ws + e.cat, (long)e.CC * T0, T0, 1, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0));
+    if (!c.dry) {
+        // d(cat) for the bank channels only, masked by the bank ReLU (cat > 0)
+        ConvArgs a = mk_dgrad(L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, (long)e.CC * T0, T0, 1);
+        a.g[0].out2 = ws + e.dcat;
+        a.g[0].mask = ws + e.cat;
+        RUN(avc_launch_conv(a, c.s, 0));
+    }
+    for (int g = 0; g < e.nb; ++g) {
+        const LayerP& Lb = p->layers[e.bank[g]];
+        RUN(wgrad_layer(c, Lb, x, sxb, sxc, sxt, ws + e.dcat + (long)g * e.c.c_bank * T0, (long)e.CC * T0, T0, 1, 1, B, T0, T0));
+    }
+    return 0;
+}
+
+int avc_backward_impl(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt, const float* xc,
+                      long scb, long scc, int sct, const float* eps, const float* d_dec, const float* d_muls_up,
+                      const float* d_emb_up, float lambda_kl, float* grads, float* ws, hipStream_t s, bool dry,
+                      long* slab_need) {
+    BwdCtx c;
+    c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
+    c.red.s = s; c.red.dry = dry;
+    const int B = p->B;
+    float* gA = ws + p->gA;
+    float* gB = ws + p->gB;
+    float* gC = ws + p->gC;
+    float* dyA = ws + p->dyA;
+    float* dyB = ws + p->dyB;
+    auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
+
+    // ---------------- decoder
+    {
+        const DecNet& d = p->dec;
+        const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb, To = p->Tout;
+        const long csb = (long)2 * d.n * 2 * C;
+        const float* ddec = d_dec ? d_dec : ws + p->ddec;
+        const LayerP& Lo = p->layers[d.out_conv];
+        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(Lo, ws, ddec, (long)p->M * To, To, 1, 1, B, To, To, gA, (long)C * To, To, 1);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        for (int l = d.n - 1; l >= 0; --l) {
+            const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
+            const LayerP& L1 = p->layers[d.c1[l]];
+            const LayerP& L2 = p->layers[d.c2[l]];
+            if (!dry) RUN(in_bwd(gA, ws + d.y2[l], ws + d.st2[l], B, C, T2, ws + d.cond, csb, (2 * l + 1) * 2 * C, dyA, ws + d.dcond, s));
+            // dyA is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, up, up, B, Ti, Ti, gB, (long)C * Ti, Ti, 1);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L2, ws + d.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, up, up, B, Ti, Ti));
+            if (!dry) RUN(in_bwd(gB, ws + d.y1[l], ws + d.st1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, dyB, ws + d.dcond, s));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                set_res(a, gA, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L1, ws + d.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
+            rot();
+        }
+        const LayerP& Li = p->layers[d.in_conv];
+        if (!dry) RUN(in_bwd(gA, ws + d.y0, ws + d.st0, B, C, Tb, nullptr, 0, 0, dyA, nullptr, s));
+        RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(Li, ws, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb, ws + p->dz, (long)Cz * Tb, Tb, 1);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
+        const LayerP& La = p->layers[d.affine];
+        RUN(wgrad_layer(c, La, ws + p->emb, 0, 1, d.c.c_cond, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(La, ws, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B, ws + p->demb, 0, 1, d.c.c_cond);
+            if (d_emb_up) set_res(a, d_emb_up, AVC_RES_IDENTITY, 0, 1, d.c.c_cond, B);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        // latent: KL term + reparameterisation (solver.py:86, model.py:384)
+        if (!dry) {
+            float lk = lambda_kl / (float)((long)B * Cz * Tb);
+            RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Cz, Tb, lk, ws + p->dmuls, s));
+        }
+    }
+
+    // ---------------- content encoder
+    {
+        const EncNet& e = p->enc;
+        const int C = e.c.c_h, Tb = p->Tb, Co2 = 2 * e.c.c_out;
+        const LayerP& Lh = p->layers[e.heads];
+        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        for (int l = e.n - 1; l >= 0; --l) {
+            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
+            const LayerP& L1 = p->layers[e.c1[l]];
+            const LayerP& L2 = p->layers[e.c2[l]];
+            if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            if (!dry) RUN(in_bwd(gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
+            rot();
+        }
+        if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
+        RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
+    }
+
+    // ---------------- speaker encoder
+    {
+        const EncNet& e = p->spk;
+        const int C = e.c.c_h;
+        float* dhA = ws + p->dhA;
+        float* dhB = ws + p->dhB;
+        float* dzA = ws + p->dzA;
+        float* dzB = ws + p->dzB;
+        const LayerP& Lo = p->layers[e.outl];
+        // output layer: x = h[nd] ([1,C,B]), dy = d_emb ([B][c_out] row-major)
+        RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(Lo, ws, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B, dhA, 0, B, 1);
+            if (e.nd > 0) {
+                a.g[0].out2 = dzA;
+                a.g[0].mask = ws + e.d2[e.nd - 1];
+            }
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        for (int l = e.nd - 1; l >= 0; --l) {
+            const LayerP& D1 = p->layers[e.dn1[l]];
+            const LayerP& D2 = p->layers[e.dn2[l]];
+            RUN(wgrad_layer(c, D2, ws + e.d1[l], 0, B, 1, dzA, 0, B, 1, 1, 1, B, B));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(D2, ws, dzA, 0, B, 1, 1, 1, B, B, nullptr, 0, B, 1);
+                a.g[0].out2 = dzB;
+                a.g[0].mask = ws + e.d1[l];
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, D1, ws + e.hd[l], 0, B, 1, dzB, 0, B, 1, 1, 1, B, B));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(D1, ws, dzB, 0, B, 1, 1, 1, B, B, dhB, 0, B, 1);
+                set_res(a, dhA, AVC_RES_IDENTITY, 0, B, 1, B);
+                if (l > 0) {
+                    a.g[0].out2 = dzA;
+                    a.g[0].mask = ws + e.d2[l - 1];
+                }
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            float* t = dhA; dhA = dhB; dhB = t;
+        }
+        // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
+        const int Tn = e.T[e.n];
+        if (!dry) RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, C, Tn, gA, dyA, s));
+        for (int l = e.n - 1; l >= 0; --l) {
+            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
+            const LayerP& L1 = p->layers[e.c1[l]];
+            const LayerP& L2 = p->layers[e.c2[l]];
+            // dyA = G_{l+1} * (a2 > 0)
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, nullptr, (long)C * Ti, Ti, 1);
+                a.g[0].out2 = dyB;
+                a.g[0].mask = ws + e.a1[l];
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                a.g[0].out2 = dyA;  // next: dy2 of block l-1, or d(in_conv out) for l == 0
+                a.g[0].mask = (l > 0) ? ws + e.a2[l - 1] : ws + e.h0;
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
+            rot();
+        }
+        RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
+    }
+    RUN(c.red.flush());
+    if (slab_need) *slab_need = c.slab_used;
+    return 0;
+}
+
+extern "C" int avc_backward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                            const float* x_cond, long scb, long scc, int sct, const float* eps, const float* d_dec,
+                            const float* d_muls_up, const float* d_emb_up, float lambda_kl, float* grads, float* ws,
+                            void* stream) {
+    if (!p || !params || !x || !ws || !grads) return fail(-1, "avc_backward: null argument");
+    if (!x_cond) {
+        x_cond = x; scb = sxb; scc = sxc; sct = sxt;
+    }
+    return avc_backward_impl(p, params, x, sxb, sxc, sxt, x_cond, scb, scc, sct, eps, d_dec, d_muls_up, d_emb_up, lambda_kl,
+                             grads, ws, (hipStream_t)stream, false, nullptr);
+}

@@ -54,10 +54,10 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.act = act;
     a.res_mode = res_mode; a.res_to_primary = 0;
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
-    a.CK = avc_conv_ck(KS);
     a.ngroups = 1;
+    a.g[0].CK = avc_conv_ck(KS);
     a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = out; a.g[0].out2 = out2; a.g[0].res = res; a.g[0].mask = nullptr;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.CK);
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
     return avc_launch_conv(a, (hipStream_t)stream, tile);
 }
 
@@ -80,10 +80,10 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     a.act = 0;
     a.res_mode = res_mode; a.res_to_primary = 1;
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
-    a.CK = avc_conv_ck(KS);
     a.ngroups = 1;
+    a.g[0].CK = avc_conv_ck(KS);
     a.g[0].wp = wpd; a.g[0].bias = nullptr; a.g[0].out = dx; a.g[0].out2 = dx2; a.g[0].res = res; a.g[0].mask = mask;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.CK);
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
     return avc_launch_conv(a, (hipStream_t)stream, tile);
 }
 

@@ -1,0 +1,116 @@
+"""Thin Python handle on the C-ABI launch plan (include/avc_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is
+launched by libavc_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DecoderCfg, EncoderCfg, ModelCfg
+
+
+def _check_common(name, c):
+    if c.get("act", "relu") != "relu":
+        raise NotImplementedError(f"{name}.act={c['act']!r}: only 'relu' (config.yaml default) is implemented")
+    if float(c.get("dropout_rate", 0)) != 0.0:
+        raise NotImplementedError(f"{name}.dropout_rate={c['dropout_rate']}: only 0 (config.yaml default) is implemented")
+
+
+def cfg_from_dict(config) -> ModelCfg:
+    """config.yaml:1-36 -> avc_model_cfg.  Unsupported options fail loudly."""
+    m = ModelCfg()
+    for key, dst, dense in (("SpeakerEncoder", m.spk, True), ("ContentEncoder", m.enc, False)):
+        c = config[key]
+        _check_common(key, c)
+        for f in ("c_in", "c_h", "c_out", "kernel_size", "bank_size", "bank_scale", "c_bank", "n_conv_blocks"):
+            setattr(dst, f, int(c[f]))
+        dst.n_dense_blocks = int(c["n_dense_blocks"]) if dense else 0
+        if dst.n_conv_blocks > _lib.MAX_BLOCKS:
+            raise NotImplementedError("more than 8 conv blocks")
+        for i, s in enumerate(list(c["subsample"])[: dst.n_conv_blocks]):
+            dst.subsample[i] = int(s)
+    d = config["Decoder"]
+    _check_common("Decoder", d)
+    if d.get("sn", False):
+        raise NotImplementedError("Decoder.sn=True (spectral norm) is not implemented; config.yaml default is False")
+    for f in ("c_in", "c_cond", "c_h", "c_out", "kernel_size", "n_conv_blocks"):
+        setattr(m.dec, f, int(d[f]))
+    for i, s in enumerate(list(d["upsample"])[: m.dec.n_conv_blocks]):
+        m.dec.upsample[i] = int(s)
+    return m
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+class Plan:
+    """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
+    tests may inject the CPU lane-level simulation build instead."""
+
+    def __init__(self, config, B, T, T_cond=None, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self.cfg = cfg_from_dict(config)
+        self.B, self.T, self.T_cond = int(B), int(T), int(T_cond or T)
+        h = ctypes.c_void_p()
+        rc = self.lib.avc_plan_create(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
+        self.h = h
+        self.num_params = self.lib.avc_plan_num_params(h)
+        self.param_floats = self.lib.avc_plan_param_floats(h)
+        self.workspace_floats = self.lib.avc_plan_workspace_floats(h)
+        self.out_len = self.lib.avc_plan_out_len(h)
+        self.latent_len = self.lib.avc_plan_latent_len(h)
+        self.param_info = []
+        for i in range(self.num_params):
+            off, n, dims = ctypes.c_long(), ctypes.c_long(), (ctypes.c_int * 3)()
+            self.lib.avc_plan_param_info(h, i, ctypes.byref(off), ctypes.byref(n), ctypes.byref(dims))
+            self.param_info.append((off.value, n.value, tuple(d for d in dims if d > 0)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.avc_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def buffer(self, name):
+        off = self.lib.avc_plan_buffer(self.h, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        return off
+
+    def view(self, ws, name, shape):
+        off = self.buffer(name)
+        n = 1
+        for s in shape:
+            n *= s
+        return ws[off:off + n].view(*shape)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libavc: {self.lib.avc_last_error().decode()}")
+
+    def forward(self, params, x, x_cond, eps, ws):
+        xc = x if x_cond is None else x_cond
+        self._chk(self.lib.avc_forward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
+                                       xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(ws), _stream(ws)))
+
+    def loss(self, x, lambda_rec, ws):
+        self._chk(self.lib.avc_loss(self.h, _ptr(x), x.stride(0), x.stride(1), x.stride(2), float(lambda_rec), _ptr(ws), _stream(ws)))
+
+    def backward(self, params, x, x_cond, eps, grads, ws, d_dec=None, d_muls=None, d_emb=None, lambda_kl=0.0):
+        xc = x if x_cond is None else x_cond
+        self._chk(self.lib.avc_backward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
+                                        xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(d_dec), _ptr(d_muls),
+                                        _ptr(d_emb), float(lambda_kl), _ptr(grads), _ptr(ws), _stream(ws)))

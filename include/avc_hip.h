@@ -1,0 +1,132 @@
+/* libavc_hip.so — C ABI of the MI355X-native AdaIN-VC forward/backward engine.
+ *
+ * The reference (jjery2243542/adaptive_voice_conversion) has no FFI of its own:
+ * its hot path sits behind the torch.nn.Module `AE` (model.py:373-395) and
+ * `Solver.ae_step` (solver.py:81-97).  This header is the boundary a binding
+ * for that path attaches to: plain pointers, sizes and a hipStream_t; no torch
+ * types.  The Python mirror of `AE`/`Solver` in adaptive_voice_conversion_amd/
+ * binds it with ctypes (see INTEGRATION.md for the stub a reference maintainer
+ * would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; tensors are fp32.
+ *  - activations are [B, C, T] with explicit element strides where a view may
+ *    be handed in (the collate view of data_utils.py:14-16 has strides (T*M, 1, M)).
+ *  - the library never allocates, frees or synchronises; scratch memory is a
+ *    caller-owned workspace whose size the plan reports (graph-capture safe).
+ *  - return value: 0 = ok, < 0 = bad argument / unsupported shape,
+ *    > 0 = hipError_t.  avc_last_error() describes the last failure.
+ *  - re-entrant; the stream is always an argument (backward runs on PyTorch's
+ *    autograd thread).
+ */
+#ifndef AVC_HIP_H
+#define AVC_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVC_MAX_BLOCKS 8
+
+/* config.yaml:1-24 (SpeakerEncoder / ContentEncoder blocks; n_dense_blocks = 0 for the content encoder) */
+typedef struct avc_encoder_cfg {
+    int c_in, c_h, c_out, kernel_size, bank_size, bank_scale, c_bank, n_conv_blocks, n_dense_blocks;
+    int subsample[AVC_MAX_BLOCKS];
+} avc_encoder_cfg;
+
+/* config.yaml:25-36 (Decoder) */
+typedef struct avc_decoder_cfg {
+    int c_in, c_cond, c_h, c_out, kernel_size, n_conv_blocks;
+    int upsample[AVC_MAX_BLOCKS];
+} avc_decoder_cfg;
+
+typedef struct avc_model_cfg {
+    avc_encoder_cfg spk; /* model.py:209-277 */
+    avc_encoder_cfg enc; /* model.py:279-323 */
+    avc_decoder_cfg dec; /* model.py:325-371 */
+} avc_model_cfg;
+
+typedef struct avc_plan avc_plan; /* host-side launch plan for one (B, T, T_cond) shape */
+
+int avc_version(void);
+const char* avc_last_error(void);
+
+/* ---- plan (host only) -------------------------------------------------- */
+/* T = frames of the content/source segment, T_cond = frames of the speaker
+ * (target) segment; training uses T_cond == T (model.py:380-385), inference may
+ * differ (model.py:387-391).  Fails (like the reference, a1 in SURVEY §8a) when a
+ * reflect pad is not smaller than the length it pads. */
+int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out);
+void avc_plan_destroy(avc_plan* p);
+/* flat parameter buffer: the 166 state_dict tensors in reference
+ * registration order, each at a 16-byte aligned offset */
+int avc_plan_num_params(const avc_plan* p);
+long avc_plan_param_floats(const avc_plan* p);                                   /* total floats incl. padding */
+int avc_plan_param_info(const avc_plan* p, int i, long* offset, long* numel, int dims[3]);
+long avc_plan_workspace_floats(const avc_plan* p);
+/* named workspace regions (float offsets): "muls" [B,2*c_out,Tb] (mu | log_sigma),
+ * "emb" [B,c_cond], "dec" [B,M,T'], "z", "losses" [2], "grad_norm" [1], "d_dec", ... ; -1 if unknown */
+long avc_plan_buffer(const avc_plan* p, const char* name);
+int avc_plan_out_len(const avc_plan* p);    /* T' of dec: 8*ceil(T/8) for the stock config */
+int avc_plan_latent_len(const avc_plan* p); /* Tb */
+
+/* ---- whole-model entry points (replace AE.forward / AE.inference, model.py:380-391) */
+/* x: source mel [B,M,T]; x_cond: speaker mel [B,M,T_cond] (may alias x); eps: [B,c_out,Tb]
+ * reparameterisation noise (model.py:383) or NULL for z = mu (AE.inference).
+ * Results are left in the workspace regions "muls", "emb", "dec". */
+int avc_forward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, void* stream);
+
+/* L1 + KL losses of solver.py:84-86 -> ws["losses"] = {loss_rec, loss_kl}; writes
+ * d(lambda_rec*loss_rec)/d(dec) into ws["d_dec"] for avc_backward. */
+int avc_loss(const avc_plan* p, const float* x, long sxb, long sxc, int sxt, float lambda_rec, float* ws, void* stream);
+
+/* backward of avc_forward (autograd of model.py:380-385).  d_dec [B,M,T'] (NULL = use
+ * ws["d_dec"] from avc_loss), d_muls_up [B,2*c_out,Tb] and d_emb_up [B,c_cond] are
+ * upstream gradients (may be NULL); lambda_kl adds the KL term of solver.py:86-88
+ * analytically (0 = none).  Writes every parameter gradient into the flat `grads`
+ * buffer (same layout as params). */
+int avc_backward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                 const float* x_cond, long scb, long scc, int sct, const float* eps, const float* d_dec,
+                 const float* d_muls_up, const float* d_emb_up, float lambda_kl, float* grads, float* ws, void* stream);
+
+/* clip_grad_norm_(max_norm) + torch.optim.Adam(amsgrad, coupled L2) of solver.py:75-77,
+ * :91-93 on flat buffers.  step is 1-based.  grad_prescale = 1/world_size when g holds an
+ * all-reduced SUM.  ws: avc_clip_adam_ws_floats(n) floats.  gnorm_out: device float or NULL. */
+long avc_clip_adam_ws_floats(long n);
+int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long n, int step, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int amsgrad, float max_norm, float grad_prescale,
+                       int write_clipped, float* ws, float* gnorm_out, void* stream);
+
+/* ---- op-level entry points (one per kernel family and direction) -------- */
+long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad);
+/* W[Cout][Cin][KS] (nn.Conv1d / nn.Linear state_dict layout; nsrc tensors stacked on Cout) -> LDS-image order */
+int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Cout, int Cin, int KS, int dgrad,
+                    float* dst, void* stream);
+/* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b); ops = pixel_shuffle_1d factor of the store
+ * (model.py:52-59); res/res_mode: y2 = y + resmap(res) (1 identity, 2 avg_pool1d(2, ceil_mode) model.py:248) */
+int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp,
+                   const float* bias, int Cout, int KS, int stride, int act, float* out, long ob, long oc, int ot,
+                   int ops, const float* res, int res_mode, long rb, long rc, int rt, int Tres, float* out2, int tile,
+                   void* stream);
+/* input gradient incl. the adjoint of the reflect padding; res_mode 1 identity, 3 adjoint of avg-pool,
+ * 4 adjoint of nearest-x2 upsample; dx2 = dx * (mask > 0) */
+int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int B, int Cout, int Tdy, const float* wpd,
+                     int Cin, int KS, int stride, int Tin, float* dx, long ob, long oc, int ot, const float* res,
+                     int res_mode, long rb, long rc, int rt, int Tres, float* dx2, const float* mask, int tile,
+                     void* stream);
+long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS);
+int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* dy, long syb, long syc, int syt, int yps,
+                     int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride, float* dW, float* db, float* ws,
+                     void* stream);
+/* nn.InstanceNorm1d(affine=False) (model.py:296,341) [+ append_cond model.py:77-83] [+ ReLU] [+ residual:
+ * 1 identity, 2 avg-pool(ceil), 5 nearest x2]; cond row b: beta = cond[b*cond_sb + cond_off + c], gamma = [.. + C + c] */
+int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu,
+                     const float* res, int res_mode, int Tres, float* out, float* mean, float* rstd, void* stream);
+int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const float* rstd, int B, int C, int T,
+                     const float* cond, long cond_sb, int cond_off, int relu, float* dy, float* dcond, long dcond_sb,
+                     int dcond_off, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVC_HIP_H */
