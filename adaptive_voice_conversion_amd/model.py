@@ -1,0 +1,223 @@
+"""Drop-in ``AE`` module (reference surface: model.py:373-395) backed by libavc_hip.so.
+
+What is kept identical to the reference: constructor signature ``AE(config)``,
+sub-module / parameter names (the 166-key ``state_dict`` of SURVEY.md §8b),
+registration order (so ``parameters()`` feeds torch optimizers in the same
+order), default initialisation (same nn.Conv1d / nn.Linear constructors in the
+same order => same tensors under the same ``torch.manual_seed``), and the
+methods ``forward / inference / get_speaker_embeddings``.
+
+What is different: no torch op computes anything.  All parameters alias ONE flat
+fp32 buffer (and all gradients another) laid out as the C plan dictates, and
+forward/backward are single calls into the gfx950 engine.
+"""
+import torch
+import torch.nn as nn
+
+from .engine import Plan, cfg_from_dict
+
+
+def _bank_kernels(c):
+    return list(range(c["bank_scale"], c["bank_size"] + 1, c["bank_scale"]))
+
+
+class _ParamHolder(nn.Module):
+    """A network of the reference reduced to its parameter containers."""
+
+    def extra_repr(self):
+        return "parameters only; compute runs in libavc_hip.so"
+
+
+class SpeakerEncoder(_ParamHolder):
+    """Parameter layout of model.py:209-235."""
+
+    def __init__(self, c_in, c_h, c_out, kernel_size, bank_size, bank_scale, c_bank, n_conv_blocks, n_dense_blocks,
+                 subsample, act, dropout_rate):
+        super().__init__()
+        ks = range(bank_scale, bank_size + 1, bank_scale)
+        self.conv_bank = nn.ModuleList(nn.Conv1d(c_in, c_bank, kernel_size=k) for k in ks)
+        self.in_conv_layer = nn.Conv1d(c_bank * (bank_size // bank_scale) + c_in, c_h, kernel_size=1)
+        self.first_conv_layers = nn.ModuleList(nn.Conv1d(c_h, c_h, kernel_size=kernel_size) for _ in range(n_conv_blocks))
+        self.second_conv_layers = nn.ModuleList(
+            nn.Conv1d(c_h, c_h, kernel_size=kernel_size, stride=s) for s, _ in zip(subsample, range(n_conv_blocks)))
+        self.first_dense_layers = nn.ModuleList(nn.Linear(c_h, c_h) for _ in range(n_dense_blocks))
+        self.second_dense_layers = nn.ModuleList(nn.Linear(c_h, c_h) for _ in range(n_dense_blocks))
+        self.output_layer = nn.Linear(c_h, c_out)
+
+
+class ContentEncoder(_ParamHolder):
+    """Parameter layout of model.py:279-299."""
+
+    def __init__(self, c_in, c_h, c_out, kernel_size, bank_size, bank_scale, c_bank, n_conv_blocks, subsample, act,
+                 dropout_rate):
+        super().__init__()
+        ks = range(bank_scale, bank_size + 1, bank_scale)
+        self.conv_bank = nn.ModuleList(nn.Conv1d(c_in, c_bank, kernel_size=k) for k in ks)
+        self.in_conv_layer = nn.Conv1d(c_bank * (bank_size // bank_scale) + c_in, c_h, kernel_size=1)
+        self.first_conv_layers = nn.ModuleList(nn.Conv1d(c_h, c_h, kernel_size=kernel_size) for _ in range(n_conv_blocks))
+        self.second_conv_layers = nn.ModuleList(
+            nn.Conv1d(c_h, c_h, kernel_size=kernel_size, stride=s) for s, _ in zip(subsample, range(n_conv_blocks)))
+        self.mean_layer = nn.Conv1d(c_h, c_out, kernel_size=1)
+        self.std_layer = nn.Conv1d(c_h, c_out, kernel_size=1)
+
+
+class Decoder(_ParamHolder):
+    """Parameter layout of model.py:325-345 (sn=False only)."""
+
+    def __init__(self, c_in, c_cond, c_h, c_out, kernel_size, n_conv_blocks, upsample, act, sn, dropout_rate):
+        super().__init__()
+        self.in_conv_layer = nn.Conv1d(c_in, c_h, kernel_size=1)
+        self.first_conv_layers = nn.ModuleList(nn.Conv1d(c_h, c_h, kernel_size=kernel_size) for _ in range(n_conv_blocks))
+        self.second_conv_layers = nn.ModuleList(
+            nn.Conv1d(c_h, c_h * up, kernel_size=kernel_size) for _, up in zip(range(n_conv_blocks), upsample))
+        self.conv_affine_layers = nn.ModuleList(nn.Linear(c_cond, c_h * 2) for _ in range(n_conv_blocks * 2))
+        self.out_conv_layer = nn.Conv1d(c_h, c_out, kernel_size=1)
+
+
+class _AEFunction(torch.autograd.Function):
+    """Autograd seam for drop-in use with arbitrary torch losses/optimizers."""
+
+    @staticmethod
+    def forward(ctx, ae, x, eps, *params):
+        plan, ws = ae._plan(x.shape[0], x.shape[2], x.shape[2], x.device)
+        plan.forward(ae._flat, x, None, eps, ws)
+        ctx.ae, ctx.plan, ctx.ws = ae, plan, ws
+        ctx.save_for_backward(x, eps)
+        muls, emb, dec = ae._outputs(plan, ws)
+        C = muls.shape[1] // 2
+        return muls[:, :C].clone(), muls[:, C:].clone(), emb.clone(), dec.clone()
+
+    @staticmethod
+    def backward(ctx, d_mu, d_ls, d_emb, d_dec):
+        ae, plan, ws = ctx.ae, ctx.plan, ctx.ws
+        x, eps = ctx.saved_tensors
+        B = x.shape[0]
+        C, Tb = ae._c_lat, plan.latent_len
+        d_muls = torch.zeros(B, 2 * C, Tb, device=x.device, dtype=torch.float32)
+        if d_mu is not None:
+            d_muls[:, :C] = d_mu
+        if d_ls is not None:
+            d_muls[:, C:] = d_ls
+        d_dec = (torch.zeros(B, ae._n_mels, plan.out_len, device=x.device) if d_dec is None else d_dec).contiguous().float()
+        d_emb = None if d_emb is None else d_emb.contiguous().float()
+        g = torch.empty_like(ae._flat)
+        plan.backward(ae._flat, x, None, eps, g, ws, d_dec=d_dec, d_muls=d_muls, d_emb=d_emb, lambda_kl=0.0)
+        grads = tuple(g[off:off + n].view(shape) for off, n, shape in ae._layout)
+        return (None, None, None) + grads
+
+
+class AE(nn.Module):
+    """model.py:373-395."""
+
+    def __init__(self, config, lib=None):
+        super().__init__()
+        self.config = config
+        self._lib = lib
+        cfg_from_dict(config)  # validates (raises on sn / lrelu / dropout)
+        self.speaker_encoder = SpeakerEncoder(**config["SpeakerEncoder"])
+        self.content_encoder = ContentEncoder(**config["ContentEncoder"])
+        self.decoder = Decoder(**config["Decoder"])
+        self._n_mels = int(config["ContentEncoder"]["c_in"])
+        self._c_lat = int(config["ContentEncoder"]["c_out"])
+        self._c_emb = int(config["SpeakerEncoder"]["c_out"])
+        # flat layout: state_dict order, every tensor 16-byte aligned (must equal the C plan's, checked in _plan)
+        self._layout, off = [], 0
+        for p in self.parameters():
+            self._layout.append((off, p.numel(), tuple(p.shape)))
+            off += (p.numel() + 3) // 4 * 4
+        self._flat = torch.zeros(off, dtype=torch.float32)
+        with torch.no_grad():
+            for (o, n, _), p in zip(self._layout, self.parameters()):
+                self._flat[o:o + n] = p.detach().reshape(-1)
+        self._gflat = None
+        self._alias()
+        self._plans = {}
+
+    # ---- flat storage ------------------------------------------------------
+    def _alias(self):
+        for (o, n, shape), p in zip(self._layout, self.parameters()):
+            p.data = self._flat[o:o + n].view(shape)
+            if self._gflat is not None:
+                p.grad = self._gflat[o:o + n].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._flat)
+        if new.dtype != torch.float32:
+            raise NotImplementedError("the engine stores fp32 master parameters")
+        self._flat = new.contiguous()
+        if self._gflat is not None:
+            self._gflat = fn(self._gflat).contiguous()
+        self._alias()
+        self._plans = {}
+        return self
+
+    def flat_parameters(self):
+        return self._flat
+
+    def flat_grads(self):
+        if self._gflat is None or self._gflat.device != self._flat.device:
+            self._gflat = torch.zeros_like(self._flat)
+            self._alias()
+        return self._gflat
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)  # copies into the aliased views
+        return out
+
+    # ---- plans ---------------------------------------------------------------
+    def _plan(self, B, T, Tc, device):
+        key = (int(B), int(T), int(Tc), str(device))
+        hit = self._plans.get(key)
+        if hit is None:
+            plan = Plan(self.config, B, T, Tc, lib=self._lib)
+            if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
+                raise RuntimeError("flat parameter layout of the C plan differs from the module's")
+            ws = torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device)
+            hit = self._plans[key] = (plan, ws)
+        return hit
+
+    def _outputs(self, plan, ws):
+        B = plan.B
+        muls = plan.view(ws, "muls", (B, 2 * self._c_lat, plan.latent_len))
+        emb = plan.view(ws, "emb", (B, self._c_emb))
+        dec = plan.view(ws, "dec", (B, self._n_mels, plan.out_len))
+        return muls, emb, dec
+
+    @staticmethod
+    def _prep(x):
+        if x.dtype != torch.float32:
+            x = x.float()
+        return x
+
+    # ---- reference surface ---------------------------------------------------
+    def forward(self, x, eps=None):
+        """model.py:380-385; ``eps`` may be injected for parity tests."""
+        x = self._prep(x)
+        if x.device != self._flat.device:
+            raise RuntimeError(f"input on {x.device} but parameters on {self._flat.device}")
+        T = x.shape[2]
+        if eps is None:
+            Tb = self._plan(x.shape[0], T, T, x.device)[0].latent_len
+            eps = torch.randn(x.shape[0], self._c_lat, Tb, device=x.device, dtype=torch.float32)
+        eps = eps.contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _AEFunction.apply(self, x, eps, *self.parameters())
+        plan, ws = self._plan(x.shape[0], T, T, x.device)
+        plan.forward(self._flat, x, None, eps, ws)
+        muls, emb, dec = self._outputs(plan, ws)
+        C = self._c_lat
+        return muls[:, :C].clone(), muls[:, C:].clone(), emb.clone(), dec.clone()
+
+    def inference(self, x, x_cond):
+        """model.py:387-391: decoder(mu(x), speaker(x_cond)); lengths may differ."""
+        x, x_cond = self._prep(x), self._prep(x_cond)
+        plan, ws = self._plan(x.shape[0], x.shape[2], x_cond.shape[2], x.device)
+        plan.forward(self._flat, x, x_cond, None, ws)
+        return self._outputs(plan, ws)[2].clone()
+
+    def get_speaker_embeddings(self, x):
+        """model.py:393-395."""
+        x = self._prep(x)
+        plan, ws = self._plan(x.shape[0], x.shape[2], x.shape[2], x.device)
+        plan.forward(self._flat, x, None, None, ws)
+        return self._outputs(plan, ws)[1].clone()

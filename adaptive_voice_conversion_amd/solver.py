@@ -1,0 +1,126 @@
+"""Training driver with the reference's surface (solver.py:16-118): ``Solver(config,
+args)``, ``ae_step(data, lambda_kl)``, ``train(n)``, ``save_model`` /
+``load_model`` with the same ``<path>.ckpt`` / ``<path>.opt`` files.
+
+``ae_step`` is ONE engine pass: forward, L1+KL loss, backward, (RCCL all-reduce
+of the flat gradient buffer when torch.distributed is initialised), fused
+clip+Adam — no torch op on the hot path and no host sync unless the caller asks
+for Python floats.
+"""
+import os
+
+import torch
+import yaml
+
+from .data_utils import PickleDataset, get_data_loader
+from .model import AE
+from .optim import FusedClipAdam
+from .utils import Logger, cc, infinite_iter, local_device
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class Solver(object):
+    def __init__(self, config, args, lib=None):
+        self.config = config
+        self.args = args
+        self._lib = lib
+        self.logger = Logger(getattr(args, "logdir", "./log"))
+        if getattr(args, "data_dir", None):
+            self.get_data_loaders()
+        self.build_model()
+        if getattr(args, "store_model_path", None):
+            self.save_config()
+        if getattr(args, "load_model", False):
+            self.load_model()
+
+    # ---- checkpoints (solver.py:39-55) ---------------------------------------
+    def save_model(self, iteration=None):
+        torch.save(self.model.state_dict(), f"{self.args.store_model_path}.ckpt")
+        torch.save(self.opt.state_dict(), f"{self.args.store_model_path}.opt")
+
+    def save_config(self):
+        with open(f"{self.args.store_model_path}.config.yaml", "w") as f:
+            yaml.dump(self.config, f)
+        with open(f"{self.args.store_model_path}.args.yaml", "w") as f:
+            yaml.dump(vars(self.args), f)
+
+    def load_model(self):
+        dev = self.model.flat_parameters().device
+        self.model.load_state_dict(torch.load(f"{self.args.load_model_path}.ckpt", map_location=dev))
+        opt_path = f"{self.args.load_model_path}.opt"
+        if os.path.exists(opt_path):
+            self.opt.load_state_dict(torch.load(opt_path, map_location=dev))
+
+    # ---- data (solver.py:57-68) ----------------------------------------------
+    def get_data_loaders(self):
+        d = self.args.data_dir
+        self.train_dataset = PickleDataset(os.path.join(d, f"{self.args.train_set}.pkl"),
+                                           os.path.join(d, self.args.train_index_file),
+                                           segment_size=self.config["data_loader"]["segment_size"])
+        self.train_loader = get_data_loader(self.train_dataset, frame_size=self.config["data_loader"]["frame_size"],
+                                            batch_size=self.config["data_loader"]["batch_size"],
+                                            shuffle=self.config["data_loader"]["shuffle"], num_workers=4, drop_last=False)
+        self.train_iter = infinite_iter(self.train_loader)
+
+    # ---- model + optimizer (solver.py:70-79) -----------------------------------
+    def build_model(self):
+        if self.config["data_loader"].get("frame_size", 1) != 1:
+            raise NotImplementedError("data_loader.frame_size != 1")
+        self.model = cc(AE(self.config, lib=self._lib)) if self._lib is None else AE(self.config, lib=self._lib)
+        o = self.config["optimizer"]
+        self.opt = FusedClipAdam(self.model, lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"],
+                                 weight_decay=o["weight_decay"], lib=self._lib)
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:  # identical replicas: rank 0's init wins
+            d.broadcast(self.model.flat_parameters(), src=0)
+
+    # ---- one training step (solver.py:81-97) -------------------------------------
+    def ae_step(self, data, lambda_kl, eps=None, sync=True):
+        model = self.model
+        flat = model.flat_parameters()
+        x = data if data.device == flat.device else data.to(flat.device, non_blocking=True)
+        if x.dtype != torch.float32:
+            x = x.float()
+        B, _, T = x.shape
+        plan, ws = model._plan(B, T, T, x.device)
+        if eps is None:
+            eps = torch.randn(B, model._c_lat, plan.latent_len, device=x.device, dtype=torch.float32)  # model.py:383
+        grads = model.flat_grads()
+        plan.forward(flat, x, None, eps, ws)
+        plan.loss(x, self.config["lambda"]["lambda_rec"], ws)
+        plan.backward(flat, x, None, eps, grads, ws, lambda_kl=float(lambda_kl))
+        prescale = 1.0
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:
+            d.all_reduce(grads)  # ONE flat bucket (sum) over RCCL/xGMI; the 1/W mean is folded into the optimizer kernel
+            prescale = 1.0 / d.get_world_size()
+        gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)
+        losses = plan.view(ws, "losses", (2,))
+        if not sync:
+            return {"loss_rec": losses[0], "loss_kl": losses[1], "grad_norm": gnorm[0]}
+        vals = torch.cat([losses, gnorm]).tolist()  # one D2H sync (the reference does .item() x2, solver.py:94-95)
+        return {"loss_rec": vals[0], "loss_kl": vals[1], "grad_norm": vals[2]}
+
+    def kl_weight(self, iteration):
+        """solver.py:101-104 linear annealing."""
+        lam = self.config["lambda"]["lambda_kl"]
+        if iteration >= self.config["annealing_iters"]:
+            return lam
+        return lam * (iteration + 1) / self.config["annealing_iters"]
+
+    def train(self, n_iterations):
+        for iteration in range(n_iterations):
+            lambda_kl = self.kl_weight(iteration)
+            data = next(self.train_iter)
+            meta = self.ae_step(data, lambda_kl)
+            if iteration % self.args.summary_steps == 0:
+                self.logger.scalars_summary(f"{self.args.tag}/ae_train", meta, iteration)
+            print(f"AE:[{iteration + 1}/{n_iterations}], loss_rec={meta['loss_rec']:.2f}, "
+                  f"loss_kl={meta['loss_kl']:.2f}, lambda={lambda_kl:.1e}     ", end="\r")
+            if (iteration + 1) % self.args.save_steps == 0 or iteration + 1 == n_iterations:
+                self.save_model(iteration=iteration)
+                print()
