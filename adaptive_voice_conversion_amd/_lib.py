@@ -56,6 +56,27 @@ def declare(lib):
     lib.avc_clip_adam_ws_floats.restype = c_long
     lib.avc_clip_adam_step.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_float] * 5 + [c_int, c_float, c_float, c_int,
                                                                                         c_void_p, c_void_p, c_void_p]
+    # op-level entry points
+    lib.avc_packed_weight_floats.argtypes = [c_int] * 4
+    lib.avc_packed_weight_floats.restype = c_long
+    lib.avc_pack_weight.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.avc_conv1d_fwd.argtypes = [c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_int, c_long, c_long,
+                                   c_int, c_int, c_void_p, c_int, c_void_p]
+    lib.avc_conv1d_dgrad.argtypes = [c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_int, c_long, c_long, c_int,
+                                     c_int, c_void_p, c_void_p, c_int, c_void_p]
+    lib.avc_conv1d_wgrad_ws_floats.argtypes = [c_int] * 5
+    lib.avc_conv1d_wgrad_ws_floats.restype = c_long
+    lib.avc_conv1d_wgrad.argtypes = [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_instnorm_fwd.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_instnorm_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int,
+                                     c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]
+    lib.avc_prof_end.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_prof_class_name.argtypes = [c_int]
+    lib.avc_prof_class_name.restype = ctypes.c_char_p
     return lib
 
 

@@ -41,3 +41,14 @@ struct avc_plan;
 int avc_backward_impl(const avc_plan*, const float*, const float*, long, long, int, const float*, long, long, int,
                       const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t, bool,
                       long*);
+
+// ---- optional per-class event timing (prof.hip)
+enum { AVC_K_CONV_FWD = 0, AVC_K_CONV_DGRAD, AVC_K_CONV_WGRAD, AVC_K_REDUCE, AVC_K_IN_FWD, AVC_K_IN_BWD, AVC_K_PACK,
+       AVC_K_ADAM, AVC_K_MISC, AVC_K_NCLASS };
+bool avc_prof_on();
+struct ProfScope {
+    ProfScope(int cls, double flops, double bytes, hipStream_t s);
+    ~ProfScope();
+    bool active_;
+    hipStream_t s_;
+};

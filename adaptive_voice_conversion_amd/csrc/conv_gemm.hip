@@ -378,6 +378,10 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     size_t lds = conv_lds_bytes(a, BM, BN);
     if (lds > 160 * 1024) return -5;
     dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups), block(AVC_THREADS);
+    double flops = 0;
+    for (int gi = 0; gi < a.ngroups; ++gi)
+        flops += 2.0 * a.M * a.Cred * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
+    ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     if (tile == 22)
         hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, block, lds, stream, a);
     else if (tile == 21)
@@ -392,6 +396,7 @@ int avc_launch_pack(const PackArgs& p, hipStream_t stream) {
     int blocks = (int)((total + AVC_THREADS * 4 - 1) / (AVC_THREADS * 4));
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps(AVC_K_PACK, 0.0, 8.0 * total, stream);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(AVC_THREADS), 0, stream, p);
     return (int)hipGetLastError();
 }

@@ -192,6 +192,7 @@ int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
     if (64 * XROW > AVC_THREADS * WG_MAXX) return -3;
     size_t lds = (size_t)(64 * WG_DYROW + 64 * XROW) * 4 + 16;
     dim3 grid(avc_cdiv(a.Cout, 64) * avc_cdiv(a.Cin, 64), nsplit);
+    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
     switch (a.KS) {
         case 1: launch_wgrad_ks<1>(a, grid, lds, stream); break;
         case 2: launch_wgrad_ks<2>(a, grid, lds, stream); break;
@@ -216,6 +217,9 @@ int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {
     }
     int blocks = avc_cdiv(maxn, AVC_THREADS);
     if (blocks > 256) blocks = 256;
+    double rb = 0;
+    for (int i = 0; i < n; ++i) rb += 4.0 * segs[i].n * (segs[i].nsplit + 1);
+    ProfScope ps(AVC_K_REDUCE, 0.0, rb, stream);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, n), dim3(AVC_THREADS), 0, stream, r);
     return (int)hipGetLastError();
 }

@@ -484,6 +484,7 @@ static void launch_in_bwd(const INBwdArgs& a, hipStream_t s) {
 }
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
+    ProfScope ps(AVC_K_IN_FWD, 0.0, 2.0 * 4.0 * (double)a.R * a.T, s);  // 1 read + 1 write
     int n4 = a.T >> 2;
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.out) % 16 == 0);
     if (!fast) {
@@ -500,6 +501,7 @@ int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
 }
 
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s) {
+    ProfScope ps(AVC_K_IN_BWD, 0.0, 3.0 * 4.0 * (double)a.R * a.T, s);  // 2 reads + 1 write
     int n4 = a.T >> 2;
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.g | (uintptr_t)a.dy) % 16 == 0);
     if (!fast) {
@@ -524,25 +526,30 @@ static int ew_blocks(long n) {
 
 int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int M, int T, float* dst, long db, long dc,
                          hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_blocks((long)B * M * T)), dim3(AVC_THREADS), 0, s, x, sxb, sxc, sxt, B,
                        M, T, dst, db, dc);
     return (int)hipGetLastError();
 }
 int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(timepool_fwd_kernel, dim3(avc_cdiv(B * C, AVC_THREADS)), dim3(AVC_THREADS), 0, s, in, B, C, T, out);
     return (int)hipGetLastError();
 }
 int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(timepool_bwd_kernel, dim3(ew_blocks((long)B * C * T)), dim3(AVC_THREADS), 0, s, dP, amask, B, C, T,
                        G, dy);
     return (int)hipGetLastError();
 }
 int avc_launch_reparam_fwd(const float* muls, const float* eps, int B, int C, int Tb, float* z, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ew_blocks((long)B * C * Tb)), dim3(AVC_THREADS), 0, s, muls, eps, B, C, Tb, z);
     return (int)hipGetLastError();
 }
 int avc_launch_latent_bwd(const float* muls, const float* eps, const float* dz, const float* dmuls_up, int B, int C,
                           int Tb, float lambda_kl_over_n, float* dmuls, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(ew_blocks((long)B * C * Tb)), dim3(AVC_THREADS), 0, s, muls, eps, dz,
                        dmuls_up, B, C, Tb, lambda_kl_over_n, dmuls);
     return (int)hipGetLastError();
@@ -553,6 +560,7 @@ int avc_loss_blocks(long n) {
 }
 int avc_launch_loss(const float* dec, const float* x, long sxb, long sxc, int sxt, int B, int M, int T, const float* muls,
                     int C, int Tb, float lambda_rec, float* ddec, float* partial, float* losses, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     long n = (long)B * M * T, nk = (long)B * C * Tb;
     int blocks = avc_loss_blocks(n);
     hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(AVC_THREADS), 0, s, dec, x, sxb, sxc, sxt, B, M, T, muls, C,
@@ -566,10 +574,12 @@ int avc_adam_blocks(long n) {
     return b > 1024 ? 1024 : b;
 }
 int avc_launch_sumsq(const float* g, long n, float* partial, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(avc_adam_blocks(n)), dim3(AVC_THREADS), 0, s, g, n, partial);
     return (int)hipGetLastError();
 }
 int avc_launch_clip_adam(const AdamArgs& a, hipStream_t s) {
+    ProfScope ps(AVC_K_ADAM, 0.0, 9.0 * 4.0 * (double)a.n, s);
     hipLaunchKernelGGL(clip_adam_kernel, dim3(avc_adam_blocks(a.n)), dim3(AVC_THREADS), 0, s, a);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Benchmark of the AdaIN-VC train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one full ``Solver.ae_step`` (forward, L1+KL loss, backward, RCCL
+all-reduce of the flat gradient buffer when N > 1, fused clip + Adam/amsgrad)
+over one batch of synthetic N(0,1) 80-mel x 128-frame segments already resident
+in HBM.  Workload = BASELINE.json configs[1]: batch 256 per GPU, fp32 (weak
+scaling: per-GPU batch fixed, global batch = 256*N).  Rank 0 prints ONE JSON
+line.  After the timed region (never inside it) two extra legs run on rank 0 at
+N = 1: a per-kernel-class HIP-event profile (-> "roofline") and the CPU oracle
+timed on the host cores (-> "cpu_baseline").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+
+
+def stock_config(n_mels):
+    from adaptive_voice_conversion_amd.config import default_config
+    return default_config(n_mels)
+
+
+def profile_classes(solver, x, eps, steps):
+    """Per-kernel-class totals from HIP events recorded on the launch stream."""
+    from adaptive_voice_conversion_amd import _lib
+    lib = _lib.load()
+    n = lib.avc_prof_nclass()
+    ms, launches = (ctypes.c_double * n)(), (ctypes.c_long * n)()
+    flops, nbytes = (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    torch.cuda.synchronize()
+    lib.avc_prof_begin()
+    for _ in range(steps):
+        solver.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize()
+    lib.avc_prof_end(ms, launches, flops, nbytes)
+    out = {}
+    for i in range(n):
+        if launches[i]:
+            out[lib.avc_prof_class_name(i).decode()] = dict(
+                ms_per_step=ms[i] / steps, launches_per_step=launches[i] / steps, avg_us=1e3 * ms[i] / launches[i],
+                tflops=(flops[i] / (ms[i] * 1e-3) / 1e12) if flops[i] else None,
+                gbs=(nbytes[i] / (ms[i] * 1e-3) / 1e9) if nbytes[i] else None,
+                flops_per_launch=flops[i] / launches[i], bytes_per_launch=nbytes[i] / launches[i])
+    return out
+
+
+def cpu_baseline(n_mels, T, budget_s=12.0):
+    """The oracle's train step (same ATen CPU ops as the reference) on the host cores, bounded sample."""
+    from oracle import avc_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.stock_config(n_mels)
+    Bc = 128  # best CPU batch in BASELINE.md
+    sd = O.make_state_dict(cfg, 0)
+    x, eps = O.make_inputs(cfg, Bc, T, 0)
+    opt = O.make_opt(sd, cfg)
+    O.ae_step(x, eps, sd, opt, cfg, 1.0)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.ae_step(x, eps, sd, opt, cfg, 1.0)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    return dict(value=Bc * n / el, unit="mel-segments/sec", cores=cores, kind="port",
+                sample=f"{n} oracle train steps (+1 warm-up) at batch {Bc}, 80x{T} segments, torch CPU fp32, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
+    ap.add_argument("--mels", type=int, default=80)
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from adaptive_voice_conversion_amd.solver import Solver
+    cfg = stock_config(a.mels)
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log")
+    solver = Solver(cfg, args)
+    B, T = a.batch, a.frames
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # each rank: its own shard of the global batch
+    x = torch.randn(B, a.mels, T, generator=g).to(dev)
+    plan, _ = solver.model._plan(B, T, T, dev)
+    eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], plan.latent_len, generator=g).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        solver.ae_step(x, 1.0, eps=eps, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        solver.ae_step(x, 1.0, eps=eps, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    meta = solver.ae_step(x, 1.0, eps=eps, sync=True)
+    if not all(v == v and abs(v) < 1e6 for v in meta.values()):
+        raise SystemExit(f"non-finite training state: {meta}")
+
+    if rank == 0:
+        value = world * B * a.steps / elapsed
+        out = {
+            "metric": "mel-segments/sec (80x128) train step", "value": value, "unit": "mel-segments/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: recon+KL train step (fwd, loss, bwd, clip, Adam-amsgrad), "
+                                   f"{a.mels}-mel x {T}-frame segments, batch {B}/GPU, fp32",
+                       "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
+                       "final_losses": meta},
+        }
+        if world == 1 and not a.no_profile:
+            prof = profile_classes(solver, x, eps, steps=3)
+            dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
+            d = prof[dom]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
+                               "ms_per_step": d["ms_per_step"]}
+            ib = [prof[k] for k in ("instnorm_fwd", "instnorm_bwd") if k in prof]
+            if ib:
+                tot_b = sum(p["bytes_per_launch"] * p["launches_per_step"] for p in ib)
+                tot_ms = sum(p["ms_per_step"] for p in ib)
+                gbs = tot_b / (tot_ms * 1e-3) / 1e9
+                out["roofline_instnorm"] = {"kernel": "instnorm_fwd+bwd (IN/AdaIN/ReLU/residual)", "bound": "hbm",
+                                            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                            "traffic": None, "ms_per_step": tot_ms,
+                                            "algorithmic_bytes_per_step": tot_b}
+            out["kernel_classes"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                         if kk in ("ms_per_step", "launches_per_step", "avg_us", "tflops", "gbs")}
+                                     for k, v in prof.items()}
+            if a.profile_json:
+                with open(a.profile_json, "w") as f:
+                    json.dump(prof, f, indent=1)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.mels, T)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

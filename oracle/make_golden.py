@@ -132,3 +132,16 @@ def main():
 
 if __name__ == "__main__":
     main()
+    make_init_golden()
+
+
+def make_init_golden():
+    """Default-initialisation pin: AE(config) of the reference under torch.manual_seed(0)
+    (solver.py:72 builds the model with PyTorch's default Conv/Linear init)."""
+    model_mod = import_reference()
+    out = {}
+    for name, cfg in (("m80", O.stock_config(80)), ("tiny", O.tiny_config())):
+        torch.manual_seed(0)
+        ref = model_mod.AE(cfg)
+        out[name] = np.stack([tensor_stats(v) for v in ref.state_dict().values()])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "init_seed0.npz"), **out)

@@ -147,3 +147,11 @@ static inline void __threadfence() {}
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_smem();
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
+
+// events (used only by the optional profiler): no-ops in the simulator
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* t, hipEvent_t, hipEvent_t) { *t = 0.f; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }

@@ -39,3 +39,20 @@ def P(t):
 
 L = ctypes.c_long
 I = ctypes.c_int
+
+
+KINDS = ["emu"]
+try:
+    import pytest as _pytest
+    KINDS = ["emu", _pytest.param("gpu", marks=_pytest.mark.gpu)]
+except Exception:  # pragma: no cover
+    pass
+
+
+def backend(kind):
+    """(declared ctypes lib, torch device): 'emu' = CPU lane-level simulation, 'gpu' = the real gfx950 library."""
+    import torch
+    from adaptive_voice_conversion_amd import _lib as product
+    if kind == "gpu":
+        return product.load(), torch.device("cuda", 0)
+    return product.declare(emu_lib()), torch.device("cpu")

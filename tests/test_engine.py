@@ -1,0 +1,202 @@
+"""Whole-model parity: engine forward / loss / backward / train step vs the oracle
+and vs the committed reference goldens.
+
+kind='emu': CPU lane-level simulation of the same kernels on a tiny instance of
+the architecture.  kind='gpu': the gfx950 library through the C ABI on the stock
+80-mel / 512-mel configs.  Tolerances (fp32): forward atol 2e-5 /
+rtol 1e-4; per-tensor gradient rel-L2 <= 1e-4 (abs <= 1e-6 on the 23
+analytically-zero bias gradients)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from adaptive_voice_conversion_amd.engine import Plan
+from oracle import avc_oracle as O
+from tests.emu_util import KINDS, backend
+
+GPU = pytest.mark.gpu
+
+
+def flat_params(plan, sd, dev):
+    flat = torch.zeros(plan.param_floats)
+    for (off, n, shape), (k, v) in zip(plan.param_info, sd.items()):
+        assert n == v.numel() and tuple(shape) == tuple(v.shape), k
+        flat[off:off + n] = v.reshape(-1)
+    return flat.to(dev)
+
+
+def check_grads(plan, grads, grads_ref, tol=1e-4):
+    worst = 0.0
+    g = grads.cpu()
+    for (off, n, shape), (k, gref) in zip(plan.param_info, grads_ref.items()):
+        gi = g[off:off + n].view(shape)
+        assert torch.isfinite(gi).all(), k
+        denom, err = gref.norm().item(), (gi - gref).norm().item()
+        if denom > 1e-6:
+            assert err / denom < tol, (k, err / denom)
+            worst = max(worst, err / denom)
+        else:  # analytically-zero bias gradients
+            assert err < 1e-6, (k, err)
+    return worst
+
+
+CASES = [
+    ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
+    pytest.param("gpu", "tiny", 3, 24, True, marks=GPU),
+    pytest.param("gpu", "m80", 4, 128, True, marks=GPU),
+    pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
+    pytest.param("gpu", "m80", 3, 24, False, marks=GPU),   # T_l = 3 at the bottleneck
+    pytest.param("gpu", "m512", 2, 128, False, marks=GPU),
+]
+
+
+def get_cfg(name):
+    return {"tiny": O.tiny_config, "m80": lambda: O.stock_config(80), "m512": lambda: O.stock_config(512)}[name]()
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
+def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 4)
+    x, eps = O.make_inputs(cfg, B, T, 4)
+    xd = x.to(dev)
+    if transposed:
+        xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
+    plan = Plan(cfg, B, T, lib=lib)
+    assert plan.num_params == len(sd)
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    plan.forward(params, xd, None, eps.to(dev), ws)
+    Tb, Cz = plan.latent_len, cfg["ContentEncoder"]["c_out"]
+    muls = plan.view(ws, "muls", (B, 2 * Cz, Tb)).cpu()
+    emb = plan.view(ws, "emb", (B, cfg["SpeakerEncoder"]["c_out"])).cpu()
+    dec = plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu()
+    outs, grads_ref = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    torch.testing.assert_close(emb, outs["emb"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(muls[:, :Cz], outs["mu"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(muls[:, Cz:], outs["log_sigma"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dec, outs["dec"], rtol=1e-4, atol=2e-5)
+    plan.loss(xd, cfg["lambda"]["lambda_rec"], ws)
+    losses = plan.view(ws, "losses", (2,)).cpu()
+    assert losses[0].item() == pytest.approx(outs["loss_rec"].item(), rel=1e-5)
+    assert losses[1].item() == pytest.approx(outs["loss_kl"].item(), rel=1e-5)
+    grads = torch.full((plan.param_floats,), float("nan"), device=dev)
+    plan.backward(params, xd, None, eps.to(dev), grads, ws, lambda_kl=1.0)
+    worst = check_grads(plan, grads, grads_ref)
+    print(f"[{kind}/{cfgname} B={B} T={T}] worst per-tensor grad rel-L2 = {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind,cfgname,Ts,Tc", [("emu", "tiny", 37, 19), pytest.param("gpu", "m80", 100, 77, marks=GPU),
+                                                pytest.param("gpu", "m80", 333, 129, marks=GPU)])
+def test_inference_odd_unequal_lengths(kind, cfgname, Ts, Tc):
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 7)
+    x, _ = O.make_inputs(cfg, 1, Ts, 7)
+    xc, _ = O.make_inputs(cfg, 1, Tc, 14)
+    plan = Plan(cfg, 1, Ts, Tc, lib=lib)
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    plan.forward(params, x.to(dev), xc.to(dev), None, ws)
+    dec = plan.view(ws, "dec", (1, cfg["Decoder"]["c_out"], plan.out_len)).cpu()
+    ref = O.ae_inference(x, xc, sd, cfg)
+    assert dec.shape == ref.shape  # T' = 8*ceil(T/8)
+    torch.testing.assert_close(dec, ref, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_short_input_rejected_like_reference(kind):
+    lib, _ = backend(kind)
+    with pytest.raises(RuntimeError, match="Padding size should be less"):
+        Plan(O.stock_config(80), 1, 16, lib=lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfgname", [("train_m80_t128_b2", "m80"), ("train_m80_t128_b4_s1", "m80"),
+                                          ("train_m80_t256_b1", "m80"), ("train_m512_t128_b1", "m512"),
+                                          ("train_tiny_t32_b2", "tiny"), ("train_tiny_t24_b3", "tiny")])
+def test_gpu_matches_reference_goldens(name, cfgname, golden_dir):
+    """HIP path vs fixtures produced by the REAL reference (oracle/make_golden.py)."""
+    from oracle.make_golden import tensor_stats
+    lib, dev = backend("gpu")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = get_cfg(cfgname)
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    sd = O.make_state_dict(cfg, seed)
+    x, eps = O.make_inputs(cfg, B, T, seed)
+    plan = Plan(cfg, B, T, lib=lib)
+    params = flat_params(plan, sd, dev)
+    ws = torch.zeros(plan.workspace_floats, device=dev)
+    xd, ed = x.to(dev), eps.to(dev)
+    plan.forward(params, xd, None, ed, ws)
+    Tb, Cz = plan.latent_len, cfg["ContentEncoder"]["c_out"]
+    muls = plan.view(ws, "muls", (B, 2 * Cz, Tb)).cpu()
+    emb = plan.view(ws, "emb", (B, cfg["SpeakerEncoder"]["c_out"])).cpu()
+    dec = plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu()
+    mine = np.stack([tensor_stats(t) for t in (muls[:, :Cz], muls[:, Cz:], emb, dec)])
+    np.testing.assert_allclose(mine, g["out_stats"], rtol=1e-4, atol=2e-5)
+    if "dec" in g:
+        np.testing.assert_allclose(dec.numpy(), g["dec"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(muls[:, :Cz].numpy(), g["mu"], rtol=1e-4, atol=2e-5)
+    plan.loss(xd, cfg["lambda"]["lambda_rec"], ws)
+    losses = plan.view(ws, "losses", (2,)).cpu()
+    assert losses[0].item() == pytest.approx(float(g["loss_rec_0"]), rel=2e-5)
+    assert losses[1].item() == pytest.approx(float(g["loss_kl_0"]), rel=2e-5)
+    grads = torch.zeros(plan.param_floats, device=dev)
+    plan.backward(params, xd, None, ed, grads, ws, lambda_kl=1.0)
+    gc = grads.cpu()
+    gs = np.stack([tensor_stats(gc[o:o + n].view(shape)) for o, n, shape in plan.param_info])
+    ref = g["grad_stats"]
+    np.testing.assert_allclose(gs[:, 0], ref[:, 0], rtol=1e-4, atol=1e-6)      # per-tensor L2 norms
+    np.testing.assert_allclose(gs[:, 3:], ref[:, 3:], rtol=5e-3, atol=5e-6)    # sampled entries
+    total = float(np.sqrt((gs[:, 0] ** 2).sum()))
+    assert total == pytest.approx(float(g["grad_norm_0"]), rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_properties():
+    """BASELINE config 2 size (B=256, 80x128): properties that need no oracle run.
+    (1) data-parallel exactness: every sample's outputs equal those of the same
+    sample in a smaller batch (InstanceNorm has no batch coupling);
+    (2) run-to-run determinism (split-K slabs are reduced in a fixed order);
+    (3) gradient of a batch = sum of gradients of its two halves (linearity of the
+    wgrad reduction), with mean-loss scaling."""
+    lib, dev = backend("gpu")
+    cfg = O.stock_config(80)
+    sd = O.make_state_dict(cfg, 0)
+    B, T = 256, 128
+    x, eps = O.make_inputs(cfg, B, T, 0)
+    xd, ed = x.to(dev), eps.to(dev)
+    big = Plan(cfg, B, T, lib=lib)
+    params = flat_params(big, sd, dev)
+    ws = torch.zeros(big.workspace_floats, device=dev)
+    big.forward(params, xd, None, ed, ws)
+    dec = big.view(ws, "dec", (B, 80, T)).clone()
+    emb = big.view(ws, "emb", (B, 128)).clone()
+    big.loss(xd, 10.0, ws)
+    g1 = torch.zeros(big.param_floats, device=dev)
+    big.backward(params, xd, None, ed, g1, ws, lambda_kl=1.0)
+    g2 = torch.zeros_like(g1)
+    big.forward(params, xd, None, ed, ws)
+    big.loss(xd, 10.0, ws)
+    big.backward(params, xd, None, ed, g2, ws, lambda_kl=1.0)
+    assert torch.equal(g1, g2), "backward is not deterministic"
+    assert torch.equal(dec, big.view(ws, "dec", (B, 80, T)))
+    half = Plan(cfg, B // 2, T, lib=lib)
+    wsh = torch.zeros(half.workspace_floats, device=dev)
+    gsum = torch.zeros_like(g1)
+    for i in range(2):
+        sl = slice(i * B // 2, (i + 1) * B // 2)
+        xs, es = xd[sl].contiguous(), ed[sl].contiguous()
+        half.forward(params, xs, None, es, wsh)
+        torch.testing.assert_close(half.view(wsh, "dec", (B // 2, 80, T)), dec[sl], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(half.view(wsh, "emb", (B // 2, 128)), emb[sl], rtol=1e-5, atol=1e-5)
+        half.loss(xs, 10.0, wsh)
+        gh = torch.zeros_like(g1)
+        half.backward(params, xs, None, es, gh, wsh, lambda_kl=1.0)
+        gsum += 0.5 * gh
+    rel = ((gsum - g1).norm() / g1.norm()).item()
+    assert rel < 1e-5, rel

@@ -1,0 +1,219 @@
+"""Implicit-GEMM conv kernels (forward / dgrad / wgrad) vs torch restatements of
+model.py:21-32 (pad_layer) and its autograd.
+
+kind='emu' runs the same .hip sources on the CPU lane-level simulator (kernel
+logic, runs anywhere); kind='gpu' calls the gfx950 library through the C ABI.
+Tolerance: fp32, rtol 1e-5/1e-4 (MFMA == fmaf chain, only the summation order
+differs from MKL-DNN)."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import avc_oracle as O
+from tests.emu_util import KINDS, P, backend
+
+GPU = pytest.mark.gpu
+
+
+def pack(lib, dev, ws, dgrad):
+    Cout, Cin, KS = ws[0].shape[0] * len(ws), ws[0].shape[1], (ws[0].shape[2] if ws[0].dim() == 3 else 1)
+    n = lib.avc_packed_weight_floats(Cout, Cin, KS, dgrad)
+    dst = torch.full((n,), float("nan"), device=dev)
+    arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    assert lib.avc_pack_weight(arr, len(ws), ws[0].shape[0], Cout, Cin, KS, dgrad, P(dst), None) == 0
+    assert torch.isfinite(dst).all()
+    return dst
+
+
+def conv_fwd(lib, dev, x, w, b, stride=1, act=0, tile=0, res=None, res_mode=0, ops=1):
+    B, Cin, Tin = x.shape
+    Cout, _, KS = w.shape
+    wp = pack(lib, dev, [w], 0)
+    padL, padR = KS // 2, (KS // 2 - 1 if KS % 2 == 0 else KS // 2)
+    Tout = (Tin + padL + padR - KS) // stride + 1
+    out = torch.full((B, Cout // ops, Tout * ops), float("nan"), device=dev)
+    out2 = torch.full_like(out, float("nan")) if res is not None else None
+    rb = rc = rt = Tres = 0
+    if res is not None:
+        rb, rc, rt, Tres = res.stride(0), res.stride(1), res.stride(2), res.shape[2]
+    rcode = lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), x.stride(2), B, Cin, Tin, P(wp), P(b), Cout, KS, stride,
+                               act, P(out), out.stride(0), out.stride(1), out.stride(2), ops, P(res), res_mode, rb, rc,
+                               rt, Tres, P(out2), tile, None)
+    assert rcode == 0, rcode
+    return out, out2
+
+
+FWD = [
+    # B, Cin, Cout, T, KS, stride, tile
+    (2, 16, 32, 32, 5, 1, 11),
+    (3, 24, 40, 20, 5, 2, 11),
+    (1, 16, 32, 70, 5, 1, 11),    # Tout > BN, partial last tile
+    (2, 8, 32, 19, 8, 1, 11),     # even kernel (bank), odd T
+    (2, 8, 32, 17, 2, 1, 11),
+    (1, 40, 32, 33, 1, 1, 11),    # 1x1
+    (2, 16, 130, 64, 3, 1, 21),   # 128x64 tile, 2 M tiles
+    (1, 16, 128, 130, 5, 1, 22),  # 128x128 tile
+    (5, 16, 32, 3, 5, 1, 11),     # bottleneck-sized rows
+    (2, 16, 32, 21, 5, 2, 11),    # stride 2, odd T
+    pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
+    pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
+    pytest.param(8, 128, 256, 64, 5, 1, 0, marks=GPU),
+    pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
+    pytest.param(4, 1104, 128, 128, 1, 1, 0, marks=GPU),
+    pytest.param(4, 80, 128, 128, 8, 1, 22, marks=GPU),
+    pytest.param(2, 128, 128, 1024, 5, 1, 22, marks=GPU),
+    pytest.param(2, 512, 128, 128, 7, 1, 21, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride,tile", FWD)
+def test_conv_fwd_matches_pad_conv(kind, B, Cin, Cout, T, KS, stride, tile):
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = torch.relu(O.pad_conv(x, w, b, stride))
+    out, _ = conv_fwd(lib, dev, x.to(dev), w.to(dev), b.to(dev), stride, act=1, tile=tile)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_conv_fwd_transposed_input_view_and_residual_pool(kind):
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(7)
+    B, Cin, Cout, T = 2, 16, 32, 22
+    xt = torch.randn(B, T, Cin, generator=g)
+    x = xt.transpose(1, 2)  # the [B,M,T] view of data_utils.py:14-16 (strides (T*M, 1, M))
+    w = torch.randn(Cout, Cin, 5, generator=g) / 9
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    y = torch.relu(O.pad_conv(x, w, b, 2))
+    out, out2 = conv_fwd(lib, dev, xt.to(dev).transpose(1, 2), w.to(dev), b.to(dev), 2, act=1, tile=11, res=res.to(dev), res_mode=2)
+    torch.testing.assert_close(out.cpu(), y, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out2.cpu(), y + O.avg_pool_ceil(res, 2), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_conv_fwd_pixel_shuffle_store(kind):
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 16, 12, generator=g)
+    w = torch.randn(64, 16, 5, generator=g) / 9
+    b = torch.randn(64, generator=g)
+    ref = O.pixel_shuffle_1d(O.pad_conv(x, w, b), 2)
+    out, _ = conv_fwd(lib, dev, x.to(dev), w.to(dev), b.to(dev), 1, act=0, tile=11, ops=2)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+DG = [
+    (2, 16, 32, 32, 5, 1, 11),
+    (3, 24, 40, 20, 5, 2, 11),
+    (2, 16, 32, 21, 5, 2, 11),
+    (1, 16, 32, 70, 5, 1, 11),
+    (1, 16, 32, 130, 5, 1, 11),   # right mirror spans the last two tiles
+    (1, 40, 32, 33, 1, 1, 11),
+    (5, 16, 32, 3, 5, 1, 11),
+    (1, 16, 128, 130, 5, 1, 22),
+    (2, 16, 32, 66, 5, 1, 21),
+    pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
+    pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
+    pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
+    pytest.param(2, 128, 128, 1024, 5, 1, 0, marks=GPU),
+    pytest.param(4, 128, 80, 128, 1, 1, 0, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride,tile", DG)
+def test_conv_dgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride, tile):
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 77 + T)
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    y = O.pad_conv(x, w, None, stride)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    wpd = pack(lib, dev, [w.to(dev)], 1)
+    dx = torch.full((B, Cin, T), float("nan"), device=dev)
+    dyd = dy.to(dev)
+    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), dyd.stride(2), 1, B, Cout, dy.shape[2], P(wpd), Cin,
+                              KS, stride, T, P(dx), dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None,
+                              None, tile, None)
+    assert rc == 0
+    torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_conv_dgrad_join_and_mask(kind):
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(11)
+    B, C, T = 2, 32, 21
+    w = torch.randn(C, C, 5, generator=g) / 12
+    dy = torch.randn(B, C, T, generator=g)
+    gnext = torch.randn(B, C, (T + 1) // 2, generator=g)
+    a_prev = torch.randn(B, C, T, generator=g)
+    x = torch.randn(B, C, T, generator=g, requires_grad=True)
+    y = O.pad_conv(x, w, None, 1)
+    pooled = O.avg_pool_ceil(x, 2)
+    (ref,) = torch.autograd.grad([y, pooled], x, [dy, gnext])
+    wpd = pack(lib, dev, [w.to(dev)], 1)
+    dx = torch.full((B, C, T), float("nan"), device=dev)
+    dx2 = torch.full((B, C, T), float("nan"), device=dev)
+    dyd, gd, ad = dy.to(dev), gnext.to(dev), a_prev.to(dev)
+    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, C, T, P(wpd), C, 5, 1, T, P(dx), dx.stride(0),
+                              dx.stride(1), 1, P(gd), 3, gd.stride(0), gd.stride(1), 1, gd.shape[2], P(dx2), P(ad), 11, None)
+    assert rc == 0
+    torch.testing.assert_close(dx.cpu(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx2.cpu(), ref * (a_prev > 0), rtol=1e-5, atol=1e-5)
+
+
+WG = [
+    # B, Cin, Cout, T, KS, stride
+    (2, 16, 32, 32, 5, 1),
+    (3, 24, 40, 20, 5, 2),
+    (2, 70, 33, 21, 5, 2),
+    (1, 16, 32, 70, 5, 1),
+    (2, 8, 32, 19, 8, 1),
+    (2, 8, 32, 17, 2, 1),
+    (1, 40, 32, 33, 1, 1),
+    (9, 16, 32, 3, 5, 1),
+    (1, 16, 130, 200, 3, 1),
+    pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
+    pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
+    pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
+    pytest.param(8, 1104, 128, 128, 1, 1, marks=GPU),
+    pytest.param(8, 80, 128, 128, 8, 1, marks=GPU),
+    pytest.param(2, 128, 128, 1024, 5, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", WG)
+def test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride):
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 31 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = O.pad_conv(x, w, b, stride)
+    dy = torch.randn(y.shape, generator=g)
+    dw_ref, db_ref = torch.autograd.grad(y, [w, b], dy)
+    ws = torch.full((lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, y.shape[2], KS),), float("nan"), device=dev)
+    dW = torch.full((Cout, Cin, KS), float("nan"), device=dev)
+    db = torch.full((Cout,), float("nan"), device=dev)
+    xd, dyd = x.to(dev), dy.to(dev)
+    rc = lib.avc_conv1d_wgrad(P(xd), xd.stride(0), xd.stride(1), 1, P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cin, Cout,
+                              T, y.shape[2], KS, stride, P(dW), P(db), P(ws), None)
+    assert rc == 0
+    scale = dw_ref.abs().max().item()
+    torch.testing.assert_close(dW.cpu(), dw_ref, rtol=1e-4, atol=1e-5 * max(1.0, scale))
+    torch.testing.assert_close(db.cpu(), db_ref, rtol=1e-4, atol=1e-4)

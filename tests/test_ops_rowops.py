@@ -1,0 +1,111 @@
+"""InstanceNorm/AdaIN/ReLU/residual row kernels and the fused clip+Adam step vs
+torch restatements (model.py:77-83, :296-369; solver.py:75-77,:91-93).
+kind='emu' = CPU lane-level simulator, kind='gpu' = gfx950 library."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import avc_oracle as O
+from tests.emu_util import KINDS, P, backend
+
+GPU = pytest.mark.gpu
+
+
+def ref_block(y, cond, relu, res, res_mode):
+    v = O.instance_norm(y)
+    if cond is not None:
+        v = O.append_cond(v, cond)
+    if relu:
+        v = torch.relu(v)
+    if res is not None:
+        if res_mode == 1:
+            v = v + res
+        elif res_mode == 2:
+            v = v + O.avg_pool_ceil(res, 2)
+        elif res_mode == 5:
+            v = v + O.upsample_nearest(res, 2)
+    return v
+
+
+IN_CASES = [
+    (3, 8, 16, True, 0), (2, 8, 32, False, 1), (2, 8, 64, True, 5), (2, 8, 128, True, 2), (1, 8, 24, True, 2),
+    (1, 4, 1024, True, 1), (2, 8, 19, True, 2), (2, 8, 7, False, 0), (1, 4, 2048, False, 0), (3, 5, 12, True, 5),
+    pytest.param(32, 128, 128, True, 5, marks=GPU), pytest.param(32, 128, 16, True, 0, marks=GPU),
+    pytest.param(32, 128, 64, False, 2, marks=GPU), pytest.param(8, 128, 1024, True, 1, marks=GPU),
+    pytest.param(3, 128, 100, True, 1, marks=GPU), pytest.param(3, 128, 13, True, 2, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,C,T,affine,res_mode", IN_CASES)
+def test_instnorm_fwd_bwd(kind, B, C, T, affine, res_mode):
+    if kind == "emu" and B * C * T > 20000:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(T * 10 + B)
+    y = (torch.randn(B, C, T, generator=g) * 2 + 0.5).requires_grad_(True)
+    cond_all = torch.randn(B, 3 * 2 * C, generator=g)
+    off = 2 * C
+    cond = cond_all[:, off:off + 2 * C].clone().requires_grad_(True) if affine else None
+    res = None
+    if res_mode == 1:
+        res = torch.randn(B, C, T, generator=g)
+    elif res_mode == 2:
+        res = torch.randn(B, C, 2 * T - (1 if T % 2 == 1 else 0), generator=g)
+    elif res_mode == 5:
+        res = torch.randn(B, C, T // 2, generator=g)
+    Tres = res.shape[2] if res is not None else 0
+    ref = ref_block(y, cond, True, res, res_mode)
+    yd, cd = y.detach().to(dev), cond_all.to(dev)
+    rd = res.to(dev) if res is not None else None
+    out = torch.full((B, C, T), float("nan"), device=dev)
+    mean = torch.full((B * C,), float("nan"), device=dev)
+    rstd = torch.full((B * C,), float("nan"), device=dev)
+    rc = lib.avc_instnorm_fwd(P(yd), B, C, T, P(cd if affine else None), cd.stride(0), off, 1, P(rd), res_mode, Tres, P(out),
+                              P(mean), P(rstd), None)
+    assert rc == 0
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=2e-5)
+    # size-independent property: the normalised rows have zero mean / unit (biased) variance
+    torch.testing.assert_close(mean.cpu().view(B, C), y.detach().mean(-1), rtol=1e-5, atol=1e-5)
+    gout = torch.randn(B, C, T, generator=g)
+    grads = torch.autograd.grad(ref, [y] + ([cond] if affine else []), gout)
+    dy = torch.full((B, C, T), float("nan"), device=dev)
+    dcond = torch.zeros(B, 3 * 2 * C, device=dev)
+    gd = gout.to(dev)
+    rc = lib.avc_instnorm_bwd(P(gd), P(yd), P(mean), P(rstd), B, C, T, P(cd if affine else None), cd.stride(0), off, 1, P(dy),
+                              P(dcond if affine else None), dcond.stride(0), off, None)
+    assert rc == 0
+    torch.testing.assert_close(dy.cpu(), grads[0], rtol=2e-4, atol=2e-5)
+    if affine:
+        torch.testing.assert_close(dcond.cpu()[:, off:off + 2 * C], grads[1], rtol=1e-4, atol=1e-4)
+        assert dcond.cpu()[:, :off].abs().max() == 0
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("amsgrad,wd,prescale,n", [(True, 1e-4, 1.0, 5000), (False, 0.0, 0.5, 5000),
+                                                    pytest.param(True, 1e-4, 1.0, 4892880, marks=GPU)])
+def test_clip_adam_matches_torch(kind, amsgrad, wd, prescale, n):
+    if kind == "emu" and n > 100000:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4, betas=(0.9, 0.999), amsgrad=amsgrad, weight_decay=wd)
+    p = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev); vmax = torch.zeros(n, device=dev)
+    ws = torch.zeros(lib.avc_clip_adam_ws_floats(n), device=dev)
+    gn = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * ((0.3 if step == 2 else 0.01) / (n / 5000) ** 0.5)  # step 2 clips
+        p_ref.grad = (grad * prescale).clone()
+        gn_ref = torch.nn.utils.clip_grad_norm_([p_ref], 5.0)
+        opt.step()
+        gbuf = grad.clone().to(dev)
+        rc = lib.avc_clip_adam_step(P(p), P(gbuf), P(m), P(v), P(vmax), n, step, 5e-4, 0.9, 0.999, 1e-8, wd, int(amsgrad), 5.0,
+                                    prescale, 1, P(ws), P(gn), None)
+        assert rc == 0
+        assert gn.item() == pytest.approx(gn_ref.item(), rel=1e-5)
+        torch.testing.assert_close(gbuf.cpu(), p_ref.grad, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
