@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     float* xT = smem + 64 * WG_DYROW;   // [64][XROW]
     const int nX = 64 * XROW;
     const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
+    const bool bigx = nX > AVC_THREADS * WG_MAXX;  // many short samples per chunk: stage X without registers
 
     f32x16 acc[KS];
 #pragma unroll
@@ -43,8 +44,18 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     float dbsum = 0.f;
 
     float dreg[8], xreg[WG_MAXX];
-    auto load_regs = [&](int chunk) {
-        int cb, t0;
+    auto x_value = [&](int cb, int t0, int e) -> float {
+        int row = e / XROW, pp = e - row * XROW;
+        int sl = pp / XSEG, p = pp - sl * XSEG;
+        int b = cb + sl, ci = ci0 + row;
+        float v = 0.f;
+        if (sl < spc && b < a.B && ci < a.Cin) {
+            int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
+            if (r >= 0 && r < a.Tin) v = a.x.ptr[(long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st];
+        }
+        return v;
+    };
+    auto chunk_origin = [&](int chunk, int& cb, int& t0) {
         if (spc == 1) {
             cb = chunk / a.chunks_per_sample;
             t0 = (chunk % a.chunks_per_sample) * 32;
@@ -52,6 +63,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             cb = chunk * spc;
             t0 = 0;
         }
+    };
+    auto load_regs = [&](int chunk) {
+        int cb, t0;
+        chunk_origin(chunk, cb, t0);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             int e = tid + it * AVC_THREADS;
@@ -63,32 +78,30 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
                 v = a.dy.ptr[(long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st];
             dreg[it] = v;
         }
+        if (!bigx) {
 #pragma unroll
-        for (int it = 0; it < WG_MAXX; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nX) {
-                int row = e / XROW, pp = e - row * XROW;
-                int sl = pp / XSEG, p = pp - sl * XSEG;
-                int b = cb + sl, ci = ci0 + row;
-                float v = 0.f;
-                if (sl < spc && b < a.B && ci < a.Cin) {
-                    int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
-                    if (r >= 0 && r < a.Tin) v = a.x.ptr[(long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st];
-                }
-                xreg[it] = v;
+            for (int it = 0; it < WG_MAXX; ++it) {
+                int e = tid + it * AVC_THREADS;
+                if (e < nX) xreg[it] = x_value(cb, t0, e);
             }
         }
     };
-    auto store_lds = [&]() {
+    auto store_lds = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             int e = tid + it * AVC_THREADS;
             dyT[(e >> 5) * WG_DYROW + (e & 31)] = dreg[it];
         }
+        if (!bigx) {
 #pragma unroll
-        for (int it = 0; it < WG_MAXX; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nX) xT[e] = xreg[it];
+            for (int it = 0; it < WG_MAXX; ++it) {
+                int e = tid + it * AVC_THREADS;
+                if (e < nX) xT[e] = xreg[it];
+            }
+        } else {
+            int cb, t0;
+            chunk_origin(chunk, cb, t0);
+            for (int e = tid; e < nX; e += AVC_THREADS) xT[e] = x_value(cb, t0, e);
         }
     };
 
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
 
     if (c_begin < c_end) load_regs(c_begin);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        store_lds();
+        store_lds(chunk);
         __syncthreads();
         if (chunk + 1 < c_end) load_regs(chunk + 1);
         const float* arow = dyT + (wave_m * 32 + li) * WG_DYROW;
@@ -189,7 +202,7 @@ int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
     if (a.padL >= a.Tin) return -6;
     int XSEG = (a.Tc - 1) * a.stride + a.KS;
     int XROW = (a.spc * XSEG) | 1;
-    if (64 * XROW > AVC_THREADS * WG_MAXX) return -3;
+    if ((size_t)(64 * WG_DYROW + 64 * XROW) * 4 > 150 * 1024) return -3;
     size_t lds = (size_t)(64 * WG_DYROW + 64 * XROW) * 4 + 16;
     dim3 grid(avc_cdiv(a.Cout, 64) * avc_cdiv(a.Cin, 64), nsplit);
     ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);

@@ -17,6 +17,12 @@
 
 #define AVC_IN_EPS 1e-5f
 
+// x_hat and the ReLU pre-activation are computed by the SAME explicitly rounded sequence in the
+// forward and in the backward kernels, so the recomputed ReLU mask is bit-identical to the
+// forward decision (no reliance on the compiler's fma contraction choices).
+static __device__ __forceinline__ float in_xhat(float y, float mean, float rstd) { return __fmul_rn(__fsub_rn(y, mean), rstd); }
+static __device__ __forceinline__ float in_preact(float xh, float gamma, float beta) { return __fmaf_rn(xh, gamma, beta); }
+
 template <int LPR>
 static __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -111,8 +117,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdAr
             float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float xh = (o[e] - mean) * rstd;
-                float w = xh * gamma + beta;
+                float w = in_preact(in_xhat(o[e], mean, rstd), gamma, beta);
                 o[e] = a.relu ? fmaxf(w, 0.f) : w;
             }
             if (rrow) {
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_generic_kernel(const
     float* orow = a.out + (long)row * a.T;
     const float* rrow = a.res ? a.res + (long)row * a.Tres : nullptr;
     for (int t = l; t < a.T; t += 64) {
-        float w = (yrow[t] - mean) * rstd * gamma + beta;
+        float w = in_preact(in_xhat(yrow[t], mean, rstd), gamma, beta);
         w = a.relu ? fmaxf(w, 0.f) : w;
         if (rrow) {
             if (a.res_mode == AVC_RES_IDENTITY)
@@ -206,8 +211,8 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_kernel(const INBwdAr
             float xx[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float h = (xx[e] - mean) * rstd;
-                float w = h * gamma + beta;
+                float h = in_xhat(xx[e], mean, rstd);
+                float w = in_preact(h, gamma, beta);
                 float gme = (!a.relu || w > 0.f) ? gg[e] : 0.f;
                 xx[e] = h;
                 gg[e] = gme;
@@ -263,8 +268,8 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_generic_kernel(const
     }
     float s1 = 0.f, s2 = 0.f;
     for (int t = l; t < a.T; t += 64) {
-        float h = (yrow[t] - mean) * rstd;
-        float w = h * gamma + beta;
+        float h = in_xhat(yrow[t], mean, rstd);
+        float w = in_preact(h, gamma, beta);
         float gme = (!a.relu || w > 0.f) ? grow[t] : 0.f;
         s1 += gme;
         s2 += gme * h;
@@ -281,8 +286,8 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_generic_kernel(const
     const float m1 = gamma * s1 * invT, m2 = gamma * s2 * invT;
     float* drow = a.dy + (long)row * a.T;
     for (int t = l; t < a.T; t += 64) {
-        float h = (yrow[t] - mean) * rstd;
-        float w = h * gamma + beta;
+        float h = in_xhat(yrow[t], mean, rstd);
+        float w = in_preact(h, gamma, beta);
         float gme = (!a.relu || w > 0.f) ? grow[t] : 0.f;
         drow[t] = rstd * (gme * gamma - m1 - h * m2);
     }

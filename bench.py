@@ -61,14 +61,20 @@ def profile_classes(solver, x, eps, steps):
 def cpu_baseline(n_mels, T, budget_s=12.0):
     """The oracle's train step (same ATen CPU ops as the reference) on the host cores, bounded sample."""
     from oracle import avc_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     cfg = O.stock_config(n_mels)
     Bc = 128  # best CPU batch in BASELINE.md
     sd = O.make_state_dict(cfg, 0)
     x, eps = O.make_inputs(cfg, Bc, T, 0)
     opt = O.make_opt(sd, cfg)
+    tw = time.perf_counter()
     O.ae_step(x, eps, sd, opt, cfg, 1.0)  # warm-up
+    print(f"[bench] cpu_baseline warm-up step: {time.perf_counter() - tw:.2f}s on {cores} threads", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -142,6 +148,7 @@ def main():
         raise SystemExit(f"non-finite training state: {meta}")
 
     if rank == 0:
+        print(f"[bench] timed region: {a.steps} steps in {elapsed:.3f}s", file=sys.stderr, flush=True)
         value = world * B * a.steps / elapsed
         out = {
             "metric": "mel-segments/sec (80x128) train step", "value": value, "unit": "mel-segments/sec",
@@ -176,8 +183,11 @@ def main():
                 with open(a.profile_json, "w") as f:
                     json.dump(prof, f, indent=1)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.mels, T)
-        print(json.dumps(out))
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.mels, T)
+            except Exception as e:  # never lose the GPU measurement to the baseline leg
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

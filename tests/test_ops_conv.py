@@ -217,3 +217,11 @@ def test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride):
     scale = dw_ref.abs().max().item()
     torch.testing.assert_close(dW.cpu(), dw_ref, rtol=1e-4, atol=1e-5 * max(1.0, scale))
     torch.testing.assert_close(db.cpu(), db_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", [(20, 16, 32, 5, 5, 2), (40, 8, 32, 5, 8, 1), (24, 16, 32, 7, 7, 2), (33, 16, 32, 1, 1, 1)])
+def test_conv_wgrad_many_short_samples_per_chunk(kind, B, Cin, Cout, T, KS, stride):
+    """T_l of a few frames (e.g. T=24 inputs reach T_l=3): many samples share a 32-column
+    K-chunk and the X tile is staged without registers."""
+    test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride)

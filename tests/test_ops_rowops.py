@@ -106,6 +106,10 @@ def test_clip_adam_matches_torch(kind, amsgrad, wd, prescale, n):
         rc = lib.avc_clip_adam_step(P(p), P(gbuf), P(m), P(v), P(vmax), n, step, 5e-4, 0.9, 0.999, 1e-8, wd, int(amsgrad), 5.0,
                                     prescale, 1, P(ws), P(gn), None)
         assert rc == 0
-        assert gn.item() == pytest.approx(gn_ref.item(), rel=1e-5)
-        torch.testing.assert_close(gbuf.cpu(), p_ref.grad, rtol=1e-5, atol=1e-7)
+        # the exact norm (fp64); torch's own fp32 CPU vector norm is off by 1e-4 at n = 4.9e6
+        # (measured 0.7072375 vs fp64 0.7073087, which the kernel reproduces)
+        assert gn.item() == pytest.approx((grad * prescale).double().norm().item(), rel=2e-6)
+        assert gn.item() == pytest.approx(gn_ref.item(), rel=1e-5 if n < 100000 else 3e-4)
+        big = n >= 100000
+        torch.testing.assert_close(gbuf.cpu(), p_ref.grad, rtol=3e-4 if big else 1e-5, atol=1e-7)
         torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
