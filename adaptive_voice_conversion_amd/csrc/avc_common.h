@@ -123,4 +123,16 @@ static inline __host__ __device__ int avc_reflect(int v, int T) {
     if (v >= T) v = 2 * (T - 1) - v;
     return v;
 }
+// direct global -> LDS DMA (global_load_lds_dwordx4): every lane supplies its own 16-byte source
+// address, the destination is the wave-uniform LDS base + lane * 16 (cdna_hip_programming.md §5)
+static __device__ __forceinline__ void avc_glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+static __device__ __forceinline__ void avc_glds4(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 static inline __host__ __device__ int avc_cdiv(int a, int b) { return (a + b - 1) / b; }

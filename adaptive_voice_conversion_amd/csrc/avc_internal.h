@@ -15,6 +15,8 @@ struct PackArgs {
 extern "C" int avc_conv_ck(int KS);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
+#define AVC_PACK_BATCH 16
+int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
 void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit);

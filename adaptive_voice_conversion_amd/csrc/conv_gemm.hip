@@ -27,7 +27,6 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 
-#define AVC_CONV_MAXA 8
 #define AVC_CONV_MAXX 17
 
 struct ConvGeom {
@@ -85,7 +84,45 @@ static inline __device__ float conv_load_res(const ConvArgs& a, const float* res
     }
 }
 
-template <int WM, int WN>
+// one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
+// of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR)
+template <int WM, int WN, bool MIRROR>
+static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
+                                                      int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
+                                                      const int (&cbr)[WN], bool use_mirror) {
+    constexpr int BM = 64 * WM;
+    const int groups = CK >> 3;  // CK is a multiple of 8: 4 k-steps (8 reduction channels) per unrolled group
+    for (int tap = 0; tap < KS; ++tap) {
+        const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
+        const float* Xrow = Xb + h * ROW + tap;
+        for (int g4 = 0; g4 < groups; ++g4) {
+            float av[4][WM], bv[4][WN];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) av[u][wm] = Arow[(2 * u) * BM + wm * 32];
+                const float* xr = Xrow + (2 * u) * ROW;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) {
+                    float v = xr[cb[wn]];
+                    if (MIRROR && use_mirror) v = v + xr[cbl[wn]] + xr[cbr[wn]];  // wave-uniform
+                    bv[u][wn] = v;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn)
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][wm], bv[u][wn], acc[wm][wn], 0, 0, 0);
+            Arow += 8 * BM;
+            Xrow += 8 * ROW;
+        }
+    }
+}
+
+template <int WM, int WN, bool MIRROR>
 __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -157,7 +194,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
                 base = bl * q.SEG + (t - q.t0) * a.stride;
             } else {
                 base = bl * q.SEG + (t - q.t0) + padL;
-                if (a.mirror) {
+                if (MIRROR) {
                     if (t >= 1 && t <= padL) bL = bl * q.SEG + (padL - t - q.seg_p0);
                     if (t >= Tout - 1 - padR && t <= Tout - 2) bR = bl * q.SEG + (2 * (Tout - 1) - t + padL - q.seg_p0);
                 }
@@ -176,23 +213,32 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-    float4 areg[AVC_CONV_MAXA];
     float xreg[AVC_CONV_MAXX];
-    const int nA4 = KS * CK * (BM / 4);
     const int nX = CK * ROW;
+    const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
+
+    // reflect-adjoint windows are needed only by waves that own a column within pad of a sample edge
+    bool use_mirror = false;
+    if (MIRROR) {
+        bool mine = false;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) mine |= (cbl[wn] != q.ROWDATA) || (cbr[wn] != q.ROWDATA);
+        use_mirror = __any(mine);
+    }
 
     __syncthreads();  // srcpos visible
 
-    auto load_regs = [&](int chunk) {
+    // weights: packed image == LDS image -> direct global->LDS DMA, 16 B per lane, no staging registers
+    auto load_a = [&](int chunk, int buf) {
         const float* wsrc = g.wp + (long)chunk * KS * CK * a.Mp + m_tile0;
-#pragma unroll
-        for (int it = 0; it < AVC_CONV_MAXA; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nA4) {
-                int row = e / (BM / 4), c4 = e - row * (BM / 4);
-                areg[it] = *(const float4*)(wsrc + (long)row * a.Mp + c4 * 4);
-            }
+        float* Ad = As + buf * AS;
+        for (int piece = wave; piece < npieces; piece += 4) {
+            int f = piece * 256 + lane * 4;
+            int row = f / BM, col = f - row * BM;
+            avc_glds16(wsrc + (long)row * a.Mp + col, Ad + piece * 256);
         }
+    };
+    auto load_x = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < AVC_CONV_MAXX; ++it) {
             int e = tid + it * AVC_THREADS;
@@ -209,14 +255,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
             }
         }
     };
-    auto store_lds = [&](int buf) {
-        float* Ad = As + buf * AS;
+    auto store_x = [&](int buf) {
         float* Xd = Xs + buf * XS;
-#pragma unroll
-        for (int it = 0; it < AVC_CONV_MAXA; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nA4) *(float4*)(Ad + e * 4) = areg[it];
-        }
 #pragma unroll
         for (int it = 0; it < AVC_CONV_MAXX; ++it) {
             int e = tid + it * AVC_THREADS;
@@ -224,40 +264,22 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         }
     };
 
-    load_regs(0);
-    store_lds(0);
+    load_a(0, 0);
+    load_x(0);
+    store_x(0);
     __syncthreads();
 
     const int a_lane = wave_m * (32 * WM) + li;
-    const int half = CK >> 1;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = (chunk + 1 < nchunk);
-        if (more) load_regs(chunk + 1);
+        if (more) {
+            load_a(chunk + 1, (chunk + 1) & 1);  // lands while this chunk is multiplied; drained at the barrier
+            load_x(chunk + 1);
+        }
         const float* Ab = As + (chunk & 1) * AS;
         const float* Xb = Xs + (chunk & 1) * XS;
-        for (int tap = 0; tap < KS; ++tap) {
-            const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
-            const float* Xrow = Xb + h * ROW + tap;
-#pragma unroll 4
-            for (int c2 = 0; c2 < half; ++c2) {
-                float av[WM], bv[WN];
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm) av[wm] = Arow[(2 * c2) * BM + wm * 32];
-                const float* xr = Xrow + (2 * c2) * ROW;
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn) {
-                    float v = xr[cb[wn]];
-                    if (a.mirror) v = v + xr[cbl[wn]] + xr[cbr[wn]];
-                    bv[wn] = v;
-                }
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-                    for (int wn = 0; wn < WN; ++wn)
-                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm], bv[wn], acc[wm][wn], 0, 0, 0);
-            }
-        }
-        if (more) store_lds((chunk + 1) & 1);
+        conv_chunk_mma<WM, WN, MIRROR>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr, use_mirror);
+        if (more) store_x((chunk + 1) & 1);
         __syncthreads();
     }
 
@@ -302,9 +324,24 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
 // output-channel axis (the 12 AdaIN affine Linears, the mu/log_sigma heads).
 // --------------------------------------------------------------------------
 
+struct PackBatch {
+    PackArgs a[AVC_PACK_BATCH];
+};
+
+static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride);
+
+// several layers per launch: blockIdx.y selects the layer descriptor
+__global__ void __launch_bounds__(AVC_THREADS) pack_weight_batch_kernel(const PackBatch b) {
+    pack_one(b.a[blockIdx.y], (long)blockIdx.x * AVC_THREADS + threadIdx.x, (long)gridDim.x * AVC_THREADS);
+}
+
 __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs p) {
+    pack_one(p, (long)blockIdx.x * AVC_THREADS + threadIdx.x, (long)gridDim.x * AVC_THREADS);
+}
+
+static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride) {
     long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
-    for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < total; e += (long)gridDim.x * AVC_THREADS) {
+    for (long e = first; e < total; e += stride) {
         int m = (int)(e % p.Mp);
         long rest = e / p.Mp;
         int r = (int)(rest % p.CK);
@@ -371,9 +408,8 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     int BN = (tile == 22) ? 128 : 64;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
-        if (a.g[gi].CK % 2 != 0) return -2;
+        if (a.g[gi].CK % 8 != 0) return -2;
         if ((long)a.g[gi].CK * q.ROW > (long)AVC_THREADS * AVC_CONV_MAXX) return -3;
-        if ((long)a.g[gi].KS * a.g[gi].CK * (BM / 4) > (long)AVC_THREADS * AVC_CONV_MAXA) return -4;
     }
     size_t lds = conv_lds_bytes(a, BM, BN);
     if (lds > 160 * 1024) return -5;
@@ -382,12 +418,36 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     for (int gi = 0; gi < a.ngroups; ++gi)
         flops += 2.0 * a.M * a.Cred * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
-    if (tile == 22)
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, block, lds, stream, a);
-    else if (tile == 21)
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), grid, block, lds, stream, a);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, block, lds, stream, a);
+    const bool mir = a.mode == 1 && a.mirror;
+    if (tile == 22) {
+        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<2, 2, false>), grid, block, lds, stream, a);
+    } else if (tile == 21) {
+        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<2, 1, false>), grid, block, lds, stream, a);
+    } else {
+        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false>), grid, block, lds, stream, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {
+    for (int i = 0; i < n; i += AVC_PACK_BATCH) {
+        PackBatch b;
+        int m = n - i < AVC_PACK_BATCH ? n - i : AVC_PACK_BATCH;
+        long maxtotal = 1, bytes = 0;
+        for (int k = 0; k < m; ++k) {
+            b.a[k] = ps[i + k];
+            long t = (long)ps[i + k].nchunk * ps[i + k].KS * ps[i + k].CK * ps[i + k].Mp;
+            maxtotal = t > maxtotal ? t : maxtotal;
+            bytes += 8 * t;
+        }
+        int blocks = (int)((maxtotal + AVC_THREADS * 4 - 1) / (AVC_THREADS * 4));
+        if (blocks > 256) blocks = 256;
+        ProfScope ps_(AVC_K_PACK, 0.0, (double)bytes, stream);
+        hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(blocks, m), dim3(AVC_THREADS), 0, stream, b);
+    }
     return (int)hipGetLastError();
 }
 

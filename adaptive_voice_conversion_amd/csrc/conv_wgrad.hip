@@ -13,7 +13,6 @@
 #include "avc_internal.h"
 
 #define WG_DYROW 33
-#define WG_MAXX 20
 
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
@@ -30,11 +29,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     const int Tc = a.Tc, spc = a.spc;
     const int XSEG = (Tc - 1) * a.stride + KS;
     const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
-    float* dyT = smem;                  // [64][WG_DYROW]
-    float* xT = smem + 64 * WG_DYROW;   // [64][XROW]
-    const int nX = 64 * XROW;
+    const int DYS = 64 * WG_DYROW, XS = 64 * XROW;
+    float* dyT = smem;            // [2][64][WG_DYROW]
+    float* xT = smem + 2 * DYS;   // [2][64][XROW]
     const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
-    const bool bigx = nX > AVC_THREADS * WG_MAXX;  // many short samples per chunk: stage X without registers
 
     f32x16 acc[KS];
 #pragma unroll
@@ -43,65 +41,44 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float dbsum = 0.f;
 
-    float dreg[8], xreg[WG_MAXX];
-    auto x_value = [&](int cb, int t0, int e) -> float {
-        int row = e / XROW, pp = e - row * XROW;
-        int sl = pp / XSEG, p = pp - sl * XSEG;
-        int b = cb + sl, ci = ci0 + row;
-        float v = 0.f;
-        if (sl < spc && b < a.B && ci < a.Cin) {
-            int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
-            if (r >= 0 && r < a.Tin) v = a.x.ptr[(long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st];
-        }
-        return v;
-    };
-    auto chunk_origin = [&](int chunk, int& cb, int& t0) {
+    // Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
+    // reflect padding and the padded LDS rows cost no staging registers); out-of-range elements are
+    // written as zeros with ordinary LDS stores.  Two stages: chunk c+1 lands while chunk c multiplies.
+    auto issue = [&](int chunk, int buf) {
+        int cb, t0;
         if (spc == 1) {
             cb = chunk / a.chunks_per_sample;
-            t0 = (chunk % a.chunks_per_sample) * 32;
+            t0 = (chunk - cb * a.chunks_per_sample) * 32;
         } else {
             cb = chunk * spc;
             t0 = 0;
         }
-    };
-    auto load_regs = [&](int chunk) {
-        int cb, t0;
-        chunk_origin(chunk, cb, t0);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            int e = tid + it * AVC_THREADS;
-            int row = e >> 5, qcol = e & 31;
-            int sl = qcol / Tc, tl = qcol - sl * Tc;
-            int b = cb + sl, t = t0 + tl, co = co0 + row;
-            float v = 0.f;
-            if (b < a.B && t < a.Tout && co < a.Cout)
-                v = a.dy.ptr[(long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st];
-            dreg[it] = v;
-        }
-        if (!bigx) {
-#pragma unroll
-            for (int it = 0; it < WG_MAXX; ++it) {
-                int e = tid + it * AVC_THREADS;
-                if (e < nX) xreg[it] = x_value(cb, t0, e);
+        float* dd = dyT + buf * DYS;
+        for (int piece = wave; piece * 64 < DYS; piece += 4) {
+            int f = piece * 64 + lane;
+            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+            if (f < DYS && qcol < 32) {
+                int sl = qcol / Tc, tl = qcol - sl * Tc;
+                int b = cb + sl, t = t0 + tl, co = co0 + row;
+                if (b < a.B && t < a.Tout && co < a.Cout)
+                    avc_glds4(a.dy.ptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
+                else
+                    dd[f] = 0.f;
             }
         }
-    };
-    auto store_lds = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            int e = tid + it * AVC_THREADS;
-            dyT[(e >> 5) * WG_DYROW + (e & 31)] = dreg[it];
-        }
-        if (!bigx) {
-#pragma unroll
-            for (int it = 0; it < WG_MAXX; ++it) {
-                int e = tid + it * AVC_THREADS;
-                if (e < nX) xT[e] = xreg[it];
+        float* xd = xT + buf * XS;
+        for (int piece = wave; piece * 64 < XS; piece += 4) {
+            int f = piece * 64 + lane;
+            if (f < XS) {
+                int row = f / XROW, pp = f - row * XROW;
+                int sl = pp / XSEG, p = pp - sl * XSEG;
+                int b = cb + sl, ci = ci0 + row;
+                int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
+                if (sl < spc && b < a.B && ci < a.Cin && r >= 0 && r < a.Tin)
+                    avc_glds4(a.x.ptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
+                else
+                    xd[f] = 0.f;
             }
-        } else {
-            int cb, t0;
-            chunk_origin(chunk, cb, t0);
-            for (int e = tid; e < nX; e += AVC_THREADS) xT[e] = x_value(cb, t0, e);
         }
     };
 
@@ -109,14 +86,14 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     int c_end = c_begin + a.chunks_per_wg;
     if (c_end > a.total_chunks) c_end = a.total_chunks;
 
-    if (c_begin < c_end) load_regs(c_begin);
+    if (c_begin < c_end) issue(c_begin, 0);
+    __syncthreads();
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        store_lds(chunk);
-        __syncthreads();
-        if (chunk + 1 < c_end) load_regs(chunk + 1);
-        const float* arow = dyT + (wave_m * 32 + li) * WG_DYROW;
-        const float* brow = xT + (wave_n * 32 + li) * XROW;
-#pragma unroll 4
+        const int buf = (chunk - c_begin) & 1;
+        if (chunk + 1 < c_end) issue(chunk + 1, buf ^ 1);
+        const float* arow = dyT + buf * DYS + (wave_m * 32 + li) * WG_DYROW;
+        const float* brow = xT + buf * XS + (wave_n * 32 + li) * XROW;
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
             int qcol = 2 * s + h;
             int sl = qcol / Tc, tl = qcol - sl * Tc;
@@ -126,11 +103,11 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             for (int j = 0; j < KS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j], acc[j], 0, 0, 0);
         }
         if (do_db) {
-            const float* dr = dyT + (tid >> 2) * WG_DYROW + (tid & 3) * 8;
+            const float* dr = dyT + buf * DYS + (tid >> 2) * WG_DYROW + (tid & 3) * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k) dbsum += dr[k];
         }
-        __syncthreads();
+        __syncthreads();  // next stage landed (the DMA is drained before the barrier), this one is free
     }
 
     // ---- epilogue: partial tile -> slab[z][co][ci][j]
@@ -202,8 +179,8 @@ int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
     if (a.padL >= a.Tin) return -6;
     int XSEG = (a.Tc - 1) * a.stride + a.KS;
     int XROW = (a.spc * XSEG) | 1;
-    if ((size_t)(64 * WG_DYROW + 64 * XROW) * 4 > 150 * 1024) return -3;
-    size_t lds = (size_t)(64 * WG_DYROW + 64 * XROW) * 4 + 16;
+    size_t lds = (size_t)2 * (64 * WG_DYROW + 64 * XROW) * 4 + 16;
+    if (lds > 158 * 1024) return -3;
     dim3 grid(avc_cdiv(a.Cout, 64) * avc_cdiv(a.Cin, 64), nsplit);
     ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
     switch (a.KS) {

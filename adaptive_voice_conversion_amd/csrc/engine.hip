@@ -538,7 +538,7 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     return 0;
 }
 
-static int pack_layer(const avc_plan* p, const LayerP& L, const float* params, float* ws, hipStream_t s) {
+static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, float* ws, std::vector<PackArgs>& out) {
     PackArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < L.nsrc; ++i) a.src[i] = p->par(params, L.w[i]);
@@ -546,11 +546,11 @@ static int pack_layer(const avc_plan* p, const LayerP& L, const float* params, f
     a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
     a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
     a.dst = ws + L.wpf;
-    RUN(avc_launch_pack(a, s));
+    out.push_back(a);
     if (L.need_dgrad) {
         a.dgrad = 1; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
         a.dst = ws + L.wpd;
-        RUN(avc_launch_pack(a, s));
+        out.push_back(a);
     }
     if (L.nsrc > 1) {  // stacked bias = "weight" with Cin = 1, KS = 1: first Mp floats of the image
         PackArgs b;
@@ -560,9 +560,8 @@ static int pack_layer(const avc_plan* p, const LayerP& L, const float* params, f
         b.Cout = L.Cout; b.Cin = 1; b.KS = 1;
         b.dgrad = 0; b.CK = 32; b.nchunk = 1; b.M = L.Cout; b.Mp = L.Mp_f;
         b.dst = ws + L.bpk;
-        RUN(avc_launch_pack(b, s));
+        out.push_back(b);
     }
-    return 0;
 }
 
 static int in_fwd(const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
@@ -616,7 +615,11 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
                         const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
     const int B = p->B;
     // 0. weights -> LDS-image order (they change every optimizer step)
-    for (const LayerP& L : p->layers) RUN(pack_layer(p, L, params, ws, s));
+    {
+        std::vector<PackArgs> packs;
+        for (const LayerP& L : p->layers) pack_layer(p, L, params, ws, packs);
+        RUN(avc_launch_pack_batch(packs.data(), (int)packs.size(), s));
+    }
 
     // ---------------- speaker encoder (model.py:265-277)
     {

@@ -147,6 +147,15 @@ static inline float __fsqrt_rn(float a) { return sqrtf(a); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __threadfence() {}
 
+// LDS DMA: lane l copies `size` bytes from its own global address to lds_base + l*size
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    memcpy((char*)(uintptr_t)(l) + emu::lane() * (size), (const void*)(uintptr_t)(g), (size))
+template <class T> static inline bool __any(T pred) {
+    int v = pred ? 1 : 0;
+    for (int o = 1; o < 64; o <<= 1) v |= __shfl_xor(v, o);
+    return v != 0;
+}
+
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_smem();
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
