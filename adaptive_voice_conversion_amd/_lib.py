@@ -27,6 +27,11 @@ class ModelCfg(ctypes.Structure):
     _fields_ = [("spk", EncoderCfg), ("enc", EncoderCfg), ("dec", DecoderCfg)]
 
 
+class ReluSite(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("kind", "B", "C", "T")] + \
+               [(n, ctypes.c_long) for n in ("act_off", "sb", "sc", "st", "y_off", "stat_off", "cond_off", "cond_sb")]
+
+
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 
@@ -45,6 +50,8 @@ def declare(lib):
     lib.avc_plan_workspace_floats.restype = c_long
     lib.avc_plan_buffer.argtypes = [c_void_p, ctypes.c_char_p]
     lib.avc_plan_buffer.restype = c_long
+    lib.avc_plan_num_relu_sites.argtypes = [c_void_p]
+    lib.avc_plan_relu_site.argtypes = [c_void_p, c_int, ctypes.POINTER(ReluSite)]
     lib.avc_plan_out_len.argtypes = [c_void_p]
     lib.avc_plan_latent_len.argtypes = [c_void_p]
     lib.avc_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,

@@ -95,6 +95,7 @@ struct avc_plan {
     long losses = -1, loss_partial = -1;
     long slab = -1, slab_floats = 0;
     long dhA = -1, dhB = -1, dzA = -1, dzB = -1;
+    std::vector<avc_relu_site> sites;
 
     long alloc(long n) {
         long o = ws_top;
@@ -380,6 +381,50 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     p->named["d_emb"] = p->demb;
     p->named["d_cond"] = d.dcond;
 
+    // ---- ReLU site table in the reference's forward call order (avc_plan_relu_site)
+    {
+        auto conv_site = [&](long off, int Bn, int C, int T, long sb, long sc, long st) {
+            avc_relu_site r;
+            memset(&r, 0, sizeof(r));
+            r.kind = 0; r.B = Bn; r.C = C; r.T = T; r.act_off = off; r.sb = sb; r.sc = sc; r.st = st;
+            r.y_off = r.stat_off = r.cond_off = -1;
+            p->sites.push_back(r);
+        };
+        auto in_site = [&](long y, long st, int C, int T, long cond, long csb) {
+            avc_relu_site r;
+            memset(&r, 0, sizeof(r));
+            r.kind = 1; r.B = B; r.C = C; r.T = T; r.act_off = -1;
+            r.y_off = y; r.stat_off = st; r.cond_off = cond; r.cond_sb = csb;
+            p->sites.push_back(r);
+        };
+        const EncNet& sp = p->spk;
+        const int Cs_ = sp.c.c_h;
+        for (int g = 0; g < sp.nb; ++g) conv_site(sp.cat + (long)g * sp.c.c_bank * sp.T[0], B, sp.c.c_bank, sp.T[0], (long)sp.CC * sp.T[0], sp.T[0], 1);
+        conv_site(sp.h0, B, Cs_, sp.T[0], (long)Cs_ * sp.T[0], sp.T[0], 1);
+        for (int l = 0; l < sp.n; ++l) {
+            conv_site(sp.a1[l], B, Cs_, sp.T[l], (long)Cs_ * sp.T[l], sp.T[l], 1);
+            conv_site(sp.a2[l], B, Cs_, sp.T[l + 1], (long)Cs_ * sp.T[l + 1], sp.T[l + 1], 1);
+        }
+        for (int l = 0; l < sp.nd; ++l) {  // dense activations are stored channel-major [C][B]; the reference sees [B, C]
+            conv_site(sp.d1[l], B, Cs_, 1, 1, B, 0);
+            conv_site(sp.d2[l], B, Cs_, 1, 1, B, 0);
+        }
+        const EncNet& en = p->enc;
+        const int Ce_ = en.c.c_h;
+        for (int g = 0; g < en.nb; ++g) conv_site(en.cat + (long)g * en.c.c_bank * en.T[0], B, en.c.c_bank, en.T[0], (long)en.CC * en.T[0], en.T[0], 1);
+        in_site(en.h0, en.st0, Ce_, en.T[0], -1, 0);
+        for (int l = 0; l < en.n; ++l) {
+            in_site(en.y1[l], en.st1[l], Ce_, en.T[l], -1, 0);
+            in_site(en.y2[l], en.st2[l], Ce_, en.T[l + 1], -1, 0);
+        }
+        const long csb_ = (long)2 * d.n * 2 * Cd;
+        in_site(d.y0, d.st0, (int)Cd, d.T[0], -1, 0);
+        for (int l = 0; l < d.n; ++l) {
+            in_site(d.y1[l], d.st1[l], (int)Cd, d.T[l], d.cond + (long)(2 * l) * 2 * Cd, csb_);
+            in_site(d.y2[l], d.st2[l], (int)Cd, d.T[l + 1], d.cond + (long)(2 * l + 1) * 2 * Cd, csb_);
+        }
+    }
+
     // ---- split-K slabs: size them with a dry run of the backward pass
     p->slab = p->ws_top;
     long need = 0;
@@ -405,6 +450,12 @@ extern "C" long avc_plan_workspace_floats(const avc_plan* p) { return p->ws_top;
 extern "C" long avc_plan_buffer(const avc_plan* p, const char* name) {
     auto it = p->named.find(name);
     return it == p->named.end() ? -1 : it->second;
+}
+extern "C" int avc_plan_num_relu_sites(const avc_plan* p) { return (int)p->sites.size(); }
+extern "C" int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out) {
+    if (i < 0 || i >= (int)p->sites.size()) return -1;
+    *out = p->sites[i];
+    return 0;
 }
 extern "C" int avc_plan_out_len(const avc_plan* p) { return p->Tout; }
 extern "C" int avc_plan_latent_len(const avc_plan* p) { return p->Tb; }

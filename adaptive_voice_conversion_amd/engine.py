@@ -97,6 +97,35 @@ class Plan:
             n *= s
         return ws[off:off + n].view(*shape)
 
+    def relu_masks(self, ws):
+        """0/1 masks of every ReLU of the last forward, in the reference's call order, computed
+        from the engine's own saved tensors (diagnostics / branch-matched gradient checks)."""
+        import ctypes as C
+        from ._lib import ReluSite
+        out = []
+        for i in range(self.lib.avc_plan_num_relu_sites(self.h)):
+            s = ReluSite()
+            self.lib.avc_plan_relu_site(self.h, i, C.byref(s))
+            B, Cc, T = s.B, s.C, s.T
+            if s.kind == 0:
+                act = torch.as_strided(ws, (B, Cc, T), (s.sb, s.sc, s.st), s.act_off)
+                m = act > 0
+                if T == 1 and s.st == 0:
+                    m = m.reshape(B, Cc)
+            else:
+                y = ws[s.y_off:s.y_off + B * Cc * T].view(B, Cc, T)
+                mean = ws[s.stat_off:s.stat_off + B * Cc].view(B, Cc, 1)
+                rstd = ws[s.stat_off + B * Cc:s.stat_off + 2 * B * Cc].view(B, Cc, 1)
+                xh = ((y - mean) * rstd).double()      # the same two fp32 roundings as the kernel
+                if s.cond_off >= 0:
+                    cond = torch.as_strided(ws, (B, 2 * Cc), (s.cond_sb, 1), s.cond_off).double()
+                    w = xh * cond[:, Cc:, None] + cond[:, :Cc, None]   # exact in fp64 -> same sign as the fp32 fma
+                else:
+                    w = xh
+                m = w > 0
+            out.append(m)
+        return out
+
     def _chk(self, rc):
         if rc != 0:
             raise RuntimeError(f"libavc: {self.lib.avc_last_error().decode()}")

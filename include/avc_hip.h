@@ -69,6 +69,20 @@ long avc_plan_buffer(const avc_plan* p, const char* name);
 int avc_plan_out_len(const avc_plan* p);    /* T' of dec: 8*ceil(T/8) for the stock config */
 int avc_plan_latent_len(const avc_plan* p); /* Tb */
 
+/* ReLU sites of the forward pass in the reference's call order (test/diagnostic aid: lets a checker
+ * evaluate its own gradient on the SAME piecewise-linear branch the engine took).  kind 0: the
+ * mask is (stored activation > 0) at ws[act_off] (strides sb, sc, st over [B, C, T]); kind 1
+ * (InstanceNorm sites): the pre-activation is ((y - mean) * rstd) * gamma + beta with y at
+ * ws[y_off] ([B,C,T] contiguous), mean/rstd at ws[stat_off] / ws[stat_off + B*C], and, when
+ * cond_off >= 0, beta = ws[cond_off + b*cond_sb + c], gamma = ws[cond_off + b*cond_sb + C + c]. */
+typedef struct avc_relu_site {
+    int kind, B, C, T;
+    long act_off, sb, sc, st;
+    long y_off, stat_off, cond_off, cond_sb;
+} avc_relu_site;
+int avc_plan_num_relu_sites(const avc_plan* p);
+int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
+
 /* ---- whole-model entry points (replace AE.forward / AE.inference, model.py:380-391) */
 /* x: source mel [B,M,T]; x_cond: speaker mel [B,M,T_cond] (may alias x); eps: [B,c_out,Tb]
  * reparameterisation noise (model.py:383) or NULL for z = mu (AE.inference).

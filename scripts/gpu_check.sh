@@ -17,7 +17,7 @@ for what in "$@"; do
     benchq)
       timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-json $OUT/prof_classes.json > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log ;;
     prof)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/rocprof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/rocprof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1)
       find $OUT/rocprof -name "*kernel_stats*" | head -3; find $OUT/rocprof -name "*.csv" -size +2M -delete ;;
   esac
 done
