@@ -89,7 +89,7 @@ static inline __device__ float conv_load_res(const ConvArgs& a, const float* res
 template <int WM, int WN, bool MIRROR>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
                                                       int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
-                                                      const int (&cbr)[WN], bool use_mirror) {
+                                                      const int (&cbr)[WN]) {
     constexpr int BM = 64 * WM;
     const int groups = CK >> 3;  // CK is a multiple of 8: 4 k-steps (8 reduction channels) per unrolled group
     for (int tap = 0; tap < KS; ++tap) {
@@ -105,7 +105,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 #pragma unroll
                 for (int wn = 0; wn < WN; ++wn) {
                     float v = xr[cb[wn]];
-                    if (MIRROR && use_mirror) v = v + xr[cbl[wn]] + xr[cbr[wn]];  // wave-uniform
+                    if (MIRROR) v = v + xr[cbl[wn]] + xr[cbr[wn]];
                     bv[u][wn] = v;
                 }
             }
@@ -278,7 +278,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         }
         const float* Ab = As + (chunk & 1) * AS;
         const float* Xb = Xs + (chunk & 1) * XS;
-        conv_chunk_mma<WM, WN, MIRROR>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr, use_mirror);
+        if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
+            conv_chunk_mma<WM, WN, true>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+        else
+            conv_chunk_mma<WM, WN, false>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         if (more) store_x((chunk + 1) & 1);
         __syncthreads();
     }
@@ -399,7 +402,7 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
         long t21 = (long)(a.Mp / 128) * conv_ntiles_n(a, 64) * a.ngroups;
         if (t22 >= 512)
             tile = 22;
-        else if (t21 >= 384)
+        else if (t21 >= 256)
             tile = 21;
         else
             tile = 11;

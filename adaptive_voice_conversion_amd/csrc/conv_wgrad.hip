@@ -161,10 +161,13 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* 
         *chunks_per_sample = 1;
         *total_chunks = avc_cdiv(B, *spc);
     }
+    // split-K factor: enough workgroups to cover the 256 CUs, but at least 4 chunks (128 columns)
+    // per workgroup so that the slab write + fixed-order reduce stay a small fraction of the work
     int tiles = avc_cdiv(Cout, 64) * avc_cdiv(Cin, 64);
-    int want = 512 / tiles;
+    int want = 256 / tiles;
     if (want < 1) want = 1;
-    if (want > *total_chunks) want = *total_chunks;
+    int maxsplit = avc_cdiv(*total_chunks, 4);
+    if (want > maxsplit) want = maxsplit;
     *chunks_per_wg = avc_cdiv(*total_chunks, want);
     *nsplit = avc_cdiv(*total_chunks, *chunks_per_wg);
 }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <map>
@@ -96,6 +97,12 @@ struct avc_plan {
     long slab = -1, slab_floats = 0;
     long dhA = -1, dhB = -1, dzA = -1, dzB = -1;
     std::vector<avc_relu_site> sites;
+    // second gradient-temporary set + side stream: the speaker and content encoders are independent
+    // branches (model.py:381-382) and run concurrently so that their small-T layers fill the chip
+    long gA2 = -1, gB2 = -1, gC2 = -1, dyA2 = -1, dyB2 = -1;
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    mutable int side_state = 0;  // 0 = not created, 1 = ready, -1 = disabled
 
     long alloc(long n) {
         long o = ws_top;
@@ -354,6 +361,11 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     p->gC = p->alloc(Bl * maxCT);
     p->dyA = p->alloc(Bl * maxCT);
     p->dyB = p->alloc(Bl * maxCT);
+    p->gA2 = p->alloc(Bl * maxCT);
+    p->gB2 = p->alloc(Bl * maxCT);
+    p->gC2 = p->alloc(Bl * maxCT);
+    p->dyA2 = p->alloc(Bl * maxCT);
+    p->dyB2 = p->alloc(Bl * maxCT);
     long Cs = p->spk.c.c_h;
     p->dhA = p->alloc(Cs * Bl);
     p->dhB = p->alloc(Cs * Bl);
@@ -436,7 +448,42 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     return 0;
 }
 
-extern "C" void avc_plan_destroy(avc_plan* p) { delete p; }
+extern "C" void avc_plan_destroy(avc_plan* p) {
+    if (p && p->side_state == 1) {
+        hipStreamDestroy(p->side);
+        hipEventDestroy(p->ev_fork);
+        hipEventDestroy(p->ev_join);
+    }
+    delete p;
+}
+
+// fork/join helpers: `side` runs one independent branch while the caller's stream runs the other
+static bool side_ready(const avc_plan* p) {
+    if (p->side_state == 0) {
+        const char* e = getenv("AVC_SINGLE_STREAM");
+        if (e && e[0] == '1') {
+            p->side_state = -1;
+        } else if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess) {
+            p->side_state = 1;
+        } else {
+            p->side_state = -1;
+        }
+    }
+    return p->side_state == 1;
+}
+static hipStream_t fork_side(const avc_plan* p, hipStream_t mainS) {
+    if (!side_ready(p)) return mainS;
+    hipEventRecord(p->ev_fork, mainS);
+    hipStreamWaitEvent(p->side, p->ev_fork, 0);
+    return p->side;
+}
+static void join_side(const avc_plan* p, hipStream_t mainS, hipStream_t sideS) {
+    if (sideS == mainS) return;
+    hipEventRecord(p->ev_join, sideS);
+    hipStreamWaitEvent(mainS, p->ev_join, 0);
+}
 extern "C" int avc_plan_num_params(const avc_plan* p) { return (int)p->params.size(); }
 extern "C" long avc_plan_param_floats(const avc_plan* p) { return p->param_floats; }
 extern "C" int avc_plan_param_info(const avc_plan* p, int i, long* offset, long* numel, int dims[3]) {
@@ -672,8 +719,11 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         RUN(avc_launch_pack_batch(packs.data(), (int)packs.size(), s));
     }
 
-    // ---------------- speaker encoder (model.py:265-277)
+    // ---------------- speaker encoder (model.py:265-277), concurrent with the content encoder
+    const hipStream_t mainS = s;
+    const hipStream_t sideS = fork_side(p, mainS);
     {
+        const hipStream_t s = sideS;
         const EncNet& e = p->spk;
         const int C = e.c.c_h;
         RUN(enc_front(p, e, params, ws, xc, scb, scc, sct, s));
@@ -732,6 +782,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         RUN(avc_launch_conv(h, s, 0));
     }
 
+    join_side(p, mainS, sideS);
     // ---------------- reparameterisation (model.py:383-384) + decoder (model.py:347-371)
     {
         const DecNet& d = p->dec;
@@ -876,41 +927,18 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
     }
 
-    // ---------------- content encoder
+    // ---------------- speaker encoder (side stream, own temporaries: concurrent with the content encoder)
+    const hipStream_t mainS = s;
+    const hipStream_t sideS = dry ? mainS : fork_side(p, mainS);
     {
-        const EncNet& e = p->enc;
-        const int C = e.c.c_h, Tb = p->Tb, Co2 = 2 * e.c.c_out;
-        const LayerP& Lh = p->layers[e.heads];
-        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0));
-        }
-        for (int l = e.n - 1; l >= 0; --l) {
-            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
-            const LayerP& L1 = p->layers[e.c1[l]];
-            const LayerP& L2 = p->layers[e.c2[l]];
-            if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0));
-            }
-            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
-            if (!dry) RUN(in_bwd(gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
-                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0));
-            }
-            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
-            rot();
-        }
-        if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
-        RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
-    }
-
-    // ---------------- speaker encoder
-    {
+        const hipStream_t s = sideS;
+        c.s = sideS;
+        float* gA = ws + p->gA2;
+        float* gB = ws + p->gB2;
+        float* gC = ws + p->gC2;
+        float* dyA = ws + p->dyA2;
+        float* dyB = ws + p->dyB2;
+        auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
         const EncNet& e = p->spk;
         const int C = e.c.c_h;
         float* dhA = ws + p->dhA;
@@ -976,7 +1004,42 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
+        c.s = mainS;
     }
+    // ---------------- content encoder
+    {
+        const EncNet& e = p->enc;
+        const int C = e.c.c_h, Tb = p->Tb, Co2 = 2 * e.c.c_out;
+        const LayerP& Lh = p->layers[e.heads];
+        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
+            RUN(avc_launch_conv(a, s, 0));
+        }
+        for (int l = e.n - 1; l >= 0; --l) {
+            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
+            const LayerP& L1 = p->layers[e.c1[l]];
+            const LayerP& L2 = p->layers[e.c2[l]];
+            if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            if (!dry) RUN(in_bwd(gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                RUN(avc_launch_conv(a, s, 0));
+            }
+            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
+            rot();
+        }
+        if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
+        RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
+    }
+
+    if (!dry) join_side(p, mainS, sideS);
     RUN(c.red.flush());
     if (slab_need) *slab_need = c.slab_used;
     return 0;
