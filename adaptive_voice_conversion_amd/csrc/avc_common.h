@@ -135,4 +135,14 @@ static __device__ __forceinline__ void avc_glds4(const float* gsrc, float* lds_w
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
+// f / d for 0 <= f < 2^22 with a precomputed float reciprocal (one fix-up step; integer division
+// by a run-time divisor costs ~25 instructions on gfx950, this costs ~6)
+static __device__ __forceinline__ int avc_fastdiv(int f, int d, float inv_d) {
+    int q = (int)((float)f * inv_d);
+    int r = f - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
 static inline __host__ __device__ int avc_cdiv(int a, int b) { return (a + b - 1) / b; }

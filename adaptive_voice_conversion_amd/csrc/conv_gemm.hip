@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[blockIdx.z];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int li = lane & 31, h = lane >> 5;
 
@@ -215,6 +216,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
 
     float xreg[AVC_CONV_MAXX];
     const int nX = CK * ROW;
+    const float inv_row = 1.0f / (float)ROW;
     const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
 
     // reflect-adjoint windows are needed only by waves that own a column within pad of a sample edge
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         for (int it = 0; it < AVC_CONV_MAXX; ++it) {
             int e = tid + it * AVC_THREADS;
             if (e < nX) {
-                int r = e / ROW, p = e - r * ROW;
+                int r = avc_fastdiv(e, ROW, inv_row), p = e - r * ROW;
                 int sp = srcpos[p];
                 int c = chunk * CK + r;
                 float v = 0.f;
@@ -373,6 +375,28 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
 // --------------------------------------------------------------------------
 extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? 8 : (KS >= 2 ? 16 : 32); }
 
+// tile choice shared by the launcher and the plan (which sizes CK from it)
+int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {
+    auto ntn = [&](int BN) { return Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout); };
+    long t22 = (long)(Mp / 128) * ntn(128) * ngroups;
+    long t21 = (long)(Mp / 128) * ntn(64) * ngroups;
+    if (t22 >= 512) return 22;
+    if (t21 >= 256) return 21;
+    return 11;
+}
+long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
+    int BM = (tile == 11) ? 64 : 128, BN = (tile == 22) ? 128 : 64;
+    long ntn = Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout);
+    return (long)(Mp / BM) * ntn * ngroups;
+}
+// K-chunk depth: layers that cannot put two workgroups on every CU are latency-bound per chunk
+// (global -> LDS round trip vs. ~1.3k MFMA cycles), so they take twice the channels per chunk
+int avc_conv_ck_for(int KS, long wgs) {
+    int ck = avc_conv_ck(KS);
+    if (KS >= 4 && wgs <= 256) ck = 16;
+    return ck;
+}
+
 static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     size_t worst = 0;
     for (int gi = 0; gi < a.ngroups; ++gi) {
@@ -397,16 +421,7 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
     int tile = force_tile;
-    if (tile == 0) {
-        long t22 = (long)(a.Mp / 128) * conv_ntiles_n(a, 128) * a.ngroups;
-        long t21 = (long)(a.Mp / 128) * conv_ntiles_n(a, 64) * a.ngroups;
-        if (t22 >= 512)
-            tile = 22;
-        else if (t21 >= 256)
-            tile = 21;
-        else
-            tile = 11;
-    }
+    if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups);
     int BM = (tile == 11) ? 64 : 128;
     int BN = (tile == 22) ? 128 : 64;
     for (int gi = 0; gi < a.ngroups; ++gi) {

@@ -8,6 +8,7 @@
 // gradient (row sums of dy) is produced by the ci-tile-0 workgroups from the dy
 // tile they already hold in LDS.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -21,7 +22,8 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 template <int KS>
 __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
     const int wave_m = wave >> 1, wave_n = wave & 1, li = lane & 31, h = lane >> 5;
     const int ci_tiles = avc_cdiv(a.Cin, 64);
     const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
@@ -33,6 +35,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     float* dyT = smem;            // [2][64][WG_DYROW]
     float* xT = smem + 2 * DYS;   // [2][64][XROW]
     const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
+    const float inv_xrow = 1.0f / (float)XROW;
 
     f32x16 acc[KS];
 #pragma unroll
@@ -42,9 +45,65 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     float dbsum = 0.f;
 
     // Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
-    // reflect padding and the padded LDS rows cost no staging registers); out-of-range elements are
-    // written as zeros with ordinary LDS stores.  Two stages: chunk c+1 lands while chunk c multiplies.
+    // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1
+    // lands while chunk c multiplies.  Both stages are zero-filled once; afterwards only elements
+    // that exist are ever written, dy columns past the end of a sample are re-zeroed, and x
+    // elements that no valid dy column multiplies may keep stale (finite) data.
+    for (int e = tid; e < 2 * (DYS + XS); e += AVC_THREADS) smem[e] = 0.f;
+
+    // chunk-invariant part of every lane's DMA descriptors (fast path: one sample per chunk)
+    constexpr int NPD = (64 * WG_DYROW + 255) / 256;  // dy pieces per wave
+    constexpr int NPX = 18;                           // x pieces per wave (XROW <= 71 when spc == 1)
+    const bool fastp = (spc == 1) && (XS <= NPX * 256);
+    int dyo[NPD], dyq[NPD], xo[NPX], xq[NPX];
+    if (fastp) {
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            int f = (wave + 4 * i) * 64 + lane;
+            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+            bool ok = f < DYS && qcol < 32 && (co0 + row) < a.Cout;
+            dyo[i] = ok ? (int)(src_chan_off(a.dy, co0 + row) + (long)qcol * a.dy.st) : -1;
+            dyq[i] = qcol;
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            int f = (wave + 4 * i) * 64 + lane;
+            int row = avc_fastdiv(f, XROW, inv_xrow), p = f - row * XROW;
+            bool ok = f < XS && p < XSEG && (ci0 + row) < a.Cin;
+            xo[i] = ok ? (int)src_chan_off(a.x, ci0 + row) : -1;
+            xq[i] = p;
+        }
+    }
+
     auto issue = [&](int chunk, int buf) {
+        float* dd = dyT + buf * DYS;
+        float* xd = xT + buf * XS;
+        if (fastp) {
+            const int cb = chunk / a.chunks_per_sample;
+            const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
+            const float* dyb = a.dy.ptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);
+            const float* xb = a.x.ptr + (long)cb * a.x.sb;
+            const int v0 = t0 * a.stride - a.padL;
+#pragma unroll
+            for (int i = 0; i < NPD; ++i) {
+                const int piece = wave + 4 * i;
+                if (piece * 64 < DYS && dyo[i] >= 0) {
+                    if (t0 + dyq[i] < a.Tout)
+                        avc_glds4(dyb + dyo[i], dd + piece * 64);
+                    else
+                        dd[piece * 64 + lane] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int piece = wave + 4 * i;
+                if (piece * 64 < XS && xo[i] >= 0) {
+                    int r = avc_reflect(v0 + xq[i], a.Tin);
+                    if (r >= 0 && r < a.Tin) avc_glds4(xb + ((long)xo[i] + (long)r * a.x.st), xd + piece * 64);
+                }
+            }
+            return;
+        }
         int cb, t0;
         if (spc == 1) {
             cb = chunk / a.chunks_per_sample;
@@ -53,7 +112,6 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             cb = chunk * spc;
             t0 = 0;
         }
-        float* dd = dyT + buf * DYS;
         for (int piece = wave; piece * 64 < DYS; piece += 4) {
             int f = piece * 64 + lane;
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
@@ -66,11 +124,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
                     dd[f] = 0.f;
             }
         }
-        float* xd = xT + buf * XS;
         for (int piece = wave; piece * 64 < XS; piece += 4) {
             int f = piece * 64 + lane;
             if (f < XS) {
-                int row = f / XROW, pp = f - row * XROW;
+                int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
                 int sl = pp / XSEG, p = pp - sl * XSEG;
                 int b = cb + sl, ci = ci0 + row;
                 int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
@@ -86,6 +143,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     int c_end = c_begin + a.chunks_per_wg;
     if (c_end > a.total_chunks) c_end = a.total_chunks;
 
+    __syncthreads();  // zero fill complete before the first DMA lands
     if (c_begin < c_end) issue(c_begin, 0);
     __syncthreads();
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
@@ -164,7 +222,13 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* 
     // split-K factor: enough workgroups to cover the 256 CUs, but at least 4 chunks (128 columns)
     // per workgroup so that the slab write + fixed-order reduce stay a small fraction of the work
     int tiles = avc_cdiv(Cout, 64) * avc_cdiv(Cin, 64);
-    int want = 256 / tiles;
+    static int target_wgs = 0;
+    if (target_wgs == 0) {
+        const char* e = getenv("AVC_WGRAD_WGS");  // tuning knob (workgroups per launch the split-K aims for)
+        target_wgs = e ? atoi(e) : 256;
+        if (target_wgs < 1) target_wgs = 256;
+    }
+    int want = target_wgs / tiles;
     if (want < 1) want = 1;
     int maxsplit = avc_cdiv(*total_chunks, 4);
     if (want > maxsplit) want = maxsplit;

@@ -51,7 +51,7 @@ struct LayerP {
     int nsrc = 1, rows = 0;
     int w[12], b[12];
     long wpf = -1, wpd = -1, bpk = -1;
-    int CK = 8, nchunk_f = 0, nchunk_d = 0, Mp_f = 0, Mp_d = 0, dgM = 0;
+    int CK = 8, CKd = 8, nchunk_f = 0, nchunk_d = 0, Mp_f = 0, Mp_d = 0, dgM = 0;
     bool need_dgrad = true;
 };
 
@@ -141,16 +141,20 @@ static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool co
     return (int)p->layers.size() - 1;
 }
 
-static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM) {
-    L.CK = avc_conv_ck(L.KS);
-    L.nchunk_f = avc_cdiv(L.Cin, L.CK);
-    L.nchunk_d = avc_cdiv(L.Cout, L.CK);
+// Bn/Tf: batch and output length of the forward launch; Td: output length of the dgrad launch
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1) {
     L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
     L.Mp_d = avc_cdiv(L.dgM, 128) * 128;
+    int tf = avc_conv_pick_tile(L.Mp_f, Bn, Tf, ngroups);
+    L.CK = avc_conv_ck_for(L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups));
+    int td = avc_conv_pick_tile(L.Mp_d, Bn, Td, 1);
+    L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1));
+    L.nchunk_f = avc_cdiv(L.Cin, L.CK);
+    L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
-    if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CK * L.Mp_d);
+    if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CKd * L.Mp_d);
     if (L.nsrc > 1) L.bpk = p->alloc((long)32 * L.Mp_f);
 }
 
@@ -263,31 +267,27 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     p->Tout = d.T[d.n];
 
     // ---- packed weights
-    for (int id : p->spk.bank) finish_layer(p, p->layers[id], false, 0);
-    finish_layer(p, p->layers[p->spk.in_conv], true, p->spk.CC - p->spk.c.c_in);
-    for (int l = 0; l < p->spk.n; ++l) {
-        finish_layer(p, p->layers[p->spk.c1[l]], true, 0);
-        finish_layer(p, p->layers[p->spk.c2[l]], true, 0);
+    for (EncNet* e : {&p->spk, &p->enc}) {
+        for (int id : e->bank) finish_layer(p, p->layers[id], false, 0, B, e->T[0], e->T[0], e->nb);
+        finish_layer(p, p->layers[e->in_conv], true, e->CC - e->c.c_in, B, e->T[0], e->T[0]);
+        for (int l = 0; l < e->n; ++l) {
+            finish_layer(p, p->layers[e->c1[l]], true, 0, B, e->T[l], e->T[l]);
+            finish_layer(p, p->layers[e->c2[l]], true, 0, B, e->T[l + 1], e->T[l]);
+        }
     }
     for (int l = 0; l < p->spk.nd; ++l) {
-        finish_layer(p, p->layers[p->spk.dn1[l]], true, 0);
-        finish_layer(p, p->layers[p->spk.dn2[l]], true, 0);
+        finish_layer(p, p->layers[p->spk.dn1[l]], true, 0, 1, B, B);
+        finish_layer(p, p->layers[p->spk.dn2[l]], true, 0, 1, B, B);
     }
-    finish_layer(p, p->layers[p->spk.outl], true, 0);
-    for (int id : p->enc.bank) finish_layer(p, p->layers[id], false, 0);
-    finish_layer(p, p->layers[p->enc.in_conv], true, p->enc.CC - p->enc.c.c_in);
-    for (int l = 0; l < p->enc.n; ++l) {
-        finish_layer(p, p->layers[p->enc.c1[l]], true, 0);
-        finish_layer(p, p->layers[p->enc.c2[l]], true, 0);
-    }
-    finish_layer(p, p->layers[p->enc.heads], true, 0);
-    finish_layer(p, p->layers[d.in_conv], true, 0);
+    finish_layer(p, p->layers[p->spk.outl], true, 0, 1, B, B);
+    finish_layer(p, p->layers[p->enc.heads], true, 0, B, p->Tb, p->Tb);
+    finish_layer(p, p->layers[d.in_conv], true, 0, B, p->Tb, p->Tb);
     for (int l = 0; l < d.n; ++l) {
-        finish_layer(p, p->layers[d.c1[l]], true, 0);
-        finish_layer(p, p->layers[d.c2[l]], true, 0);
+        finish_layer(p, p->layers[d.c1[l]], true, 0, B, d.T[l], d.T[l]);
+        finish_layer(p, p->layers[d.c2[l]], true, 0, B, d.T[l], d.T[l]);
     }
-    finish_layer(p, p->layers[d.affine], true, 0);
-    finish_layer(p, p->layers[d.out_conv], true, 0);
+    finish_layer(p, p->layers[d.affine], true, 0, 1, B, B);
+    finish_layer(p, p->layers[d.out_conv], true, 0, B, p->Tout, p->Tout);
 
     // ---- activations
     const long Bl = B;
@@ -458,7 +458,11 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
 }
 
 // fork/join helpers: `side` runs one independent branch while the caller's stream runs the other
+static int g_force_single = 0;
+extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
+
 static bool side_ready(const avc_plan* p) {
+    if (g_force_single) return false;
     if (p->side_state == 0) {
         const char* e = getenv("AVC_SINGLE_STREAM");
         if (e && e[0] == '1') {
@@ -554,7 +558,7 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
     a.ngroups = 1;
-    set_group(a.g[0], ws + L.wpd, nullptr, L.KS, L.CK, L.nchunk_d);
+    set_group(a.g[0], ws + L.wpd, nullptr, L.KS, L.CKd, L.nchunk_d);
     a.g[0].out = dx;
     return a;
 }
@@ -646,7 +650,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     a.dst = ws + L.wpf;
     out.push_back(a);
     if (L.need_dgrad) {
-        a.dgrad = 1; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
+        a.dgrad = 1; a.CK = L.CKd; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
         a.dst = ws + L.wpd;
         out.push_back(a);
     }

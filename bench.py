@@ -42,11 +42,13 @@ def profile_classes(solver, x, eps, steps):
     ms, launches = (ctypes.c_double * n)(), (ctypes.c_long * n)()
     flops, nbytes = (ctypes.c_double * n)(), (ctypes.c_double * n)()
     torch.cuda.synchronize()
+    lib.avc_set_single_stream(1)   # one stream: event brackets then measure each kernel class in isolation
     lib.avc_prof_begin()
     for _ in range(steps):
         solver.ae_step(x, 1.0, eps=eps, sync=False)
     torch.cuda.synchronize()
     lib.avc_prof_end(ms, launches, flops, nbytes)
+    lib.avc_set_single_stream(0)
     out = {}
     for i in range(n):
         if launches[i]:

@@ -83,6 +83,9 @@ typedef struct avc_relu_site {
 int avc_plan_num_relu_sites(const avc_plan* p);
 int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 
+/* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
+void avc_set_single_stream(int on);
+
 /* ---- whole-model entry points (replace AE.forward / AE.inference, model.py:380-391) */
 /* x: source mel [B,M,T]; x_cond: speaker mel [B,M,T_cond] (may alias x); eps: [B,c_out,Tb]
  * reparameterisation noise (model.py:383) or NULL for z = mu (AE.inference).
