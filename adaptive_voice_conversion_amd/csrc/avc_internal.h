@@ -15,7 +15,7 @@ struct PackArgs {
 extern "C" int avc_conv_ck(int KS);
 int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups);
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups);
-int avc_conv_ck_for(int KS, long wgs);
+int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
 #define AVC_PACK_BATCH 16

@@ -27,7 +27,7 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 
-#define AVC_CONV_MAXX 17
+#define AVC_CONV_NJ 6   // source-tile rows of up to 384 positions
 
 struct ConvGeom {
     int b0, t0, SPT, ncols, SEG, seg_p0, ROWDATA, ROW;
@@ -85,44 +85,81 @@ static inline __device__ float conv_load_res(const ConvArgs& a, const float* res
 }
 
 // one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
-// of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR)
+// of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR).
+// A "unit" is 4 k-steps (8 reduction channels of one tap).
 template <int WM, int WN, bool MIRROR>
+static __device__ __forceinline__ void conv_load_unit(float (&av)[4][WM], float (&bv)[4][WN], const float* Arow, const float* Xrow,
+                                                      int ROW, const int (&cb)[WN], const int (&cbl)[WN], const int (&cbr)[WN]) {
+    constexpr int BM = 64 * WM;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) av[u][wm] = Arow[(2 * u) * BM + wm * 32];
+        const float* xr = Xrow + (2 * u) * ROW;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            float v = xr[cb[wn]];
+            if (MIRROR) v = v + xr[cbl[wn]] + xr[cbr[wn]];
+            bv[u][wn] = v;
+        }
+    }
+}
+template <int WM, int WN>
+static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const float (&av)[4][WM], const float (&bv)[4][WN]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+                acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][wm], bv[u][wn], acc[wm][wn], 0, 0, 0);
+}
+
+// KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
+// block with the fragments of unit u+1 fetched from LDS before the MFMAs of unit u are issued
+// (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
+template <int WM, int WN, bool MIRROR, int KSC, int GRC>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
                                                       int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
                                                       const int (&cbr)[WN]) {
     constexpr int BM = 64 * WM;
-    const int groups = CK >> 3;  // CK is a multiple of 8: 4 k-steps (8 reduction channels) per unrolled group
-    for (int tap = 0; tap < KS; ++tap) {
-        const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
-        const float* Xrow = Xb + h * ROW + tap;
-        for (int g4 = 0; g4 < groups; ++g4) {
-            float av[4][WM], bv[4][WN];
+    if constexpr (KSC > 0) {
+        constexpr int U = KSC * GRC;
+        constexpr int CKC = 8 * GRC;
+        float av[2][4][WM], bv[2][4][WN];
+        auto unit_ptrs = [&](int u, const float*& Arow, const float*& Xrow) {
+            const int tap = u / GRC, g4 = u % GRC;
+            Arow = Ab + (tap * CKC + 8 * g4 + h) * BM + a_lane;
+            Xrow = Xb + (8 * g4 + h) * ROW + tap;
+        };
+        const float *Ar, *Xr;
+        unit_ptrs(0, Ar, Xr);
+        conv_load_unit<WM, WN, MIRROR>(av[0], bv[0], Ar, Xr, ROW, cb, cbl, cbr);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm) av[u][wm] = Arow[(2 * u) * BM + wm * 32];
-                const float* xr = Xrow + (2 * u) * ROW;
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn) {
-                    float v = xr[cb[wn]];
-                    if (MIRROR) v = v + xr[cbl[wn]] + xr[cbr[wn]];
-                    bv[u][wn] = v;
-                }
+        for (int u = 0; u < U; ++u) {
+            if (u + 1 < U) {
+                unit_ptrs(u + 1, Ar, Xr);
+                conv_load_unit<WM, WN, MIRROR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-                    for (int wn = 0; wn < WN; ++wn)
-                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][wm], bv[u][wn], acc[wm][wn], 0, 0, 0);
-            Arow += 8 * BM;
-            Xrow += 8 * ROW;
+            conv_mma_unit<WM, WN>(acc, av[u & 1], bv[u & 1]);
+        }
+    } else {
+        const int groups = CK >> 3;
+        for (int tap = 0; tap < KS; ++tap) {
+            const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
+            const float* Xrow = Xb + h * ROW + tap;
+            for (int g4 = 0; g4 < groups; ++g4) {
+                float av[4][WM], bv[4][WN];
+                conv_load_unit<WM, WN, MIRROR>(av, bv, Arow, Xrow, ROW, cb, cbl, cbr);
+                conv_mma_unit<WM, WN>(acc, av, bv);
+                Arow += 8 * BM;
+                Xrow += 8 * ROW;
+            }
         }
     }
 }
 
-template <int WM, int WN, bool MIRROR>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC>
 __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -143,10 +180,15 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
     const int XS = CK * ROW;      // floats per X stage
     float* As = smem;
     float* Xs = smem + 2 * AS;
-    int* srcpos = (int*)(smem + 2 * AS + 2 * XS);
 
-    // ---- per-position source offsets (same for every channel chunk)
-    for (int p = tid; p < ROW; p += AVC_THREADS) {
+    // ---- per-lane source descriptors of the X tile: lane l owns LDS positions p = 64*j + l of every
+    // row (one row = one reduction channel), so the descriptor depends on p only and each chunk's
+    // loads are dword LDS-DMAs (no staging registers, no index table): offset of the element inside
+    // its channel row, or -1 where the tile holds a structural zero (halo / null window / masked).
+    int xoff[AVC_CONV_NJ];
+#pragma unroll
+    for (int j = 0; j < AVC_CONV_NJ; ++j) {
+        const int p = 64 * j + lane;
         int sp = -1;
         if (p < q.ROWDATA) {
             int seg = p / q.SEG, qq = p - seg * q.SEG;
@@ -166,8 +208,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
                 }
             }
         }
-        srcpos[p] = sp;
+        xoff[j] = sp;
     }
+    // both X stages start as zeros; structural zeros are never overwritten afterwards
+    for (int e = tid; e < 2 * XS; e += AVC_THREADS) Xs[e] = 0.f;
 
     // ---- per-lane column bases into an LDS row
     int cb[WN], cbl[WN], cbr[WN], colb[WN], colt[WN];
@@ -214,10 +258,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-    float xreg[AVC_CONV_MAXX];
-    const int nX = CK * ROW;
-    const float inv_row = 1.0f / (float)ROW;
     const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
+    const int nj = (ROW + 63) >> 6;
 
     // reflect-adjoint windows are needed only by waves that own a column within pad of a sample edge
     bool use_mirror = false;
@@ -228,7 +270,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         use_mirror = __any(mine);
     }
 
-    __syncthreads();  // srcpos visible
+    __syncthreads();  // zero fill done before the first DMA lands
 
     // weights: packed image == LDS image -> direct global->LDS DMA, 16 B per lane, no staging registers
     auto load_a = [&](int chunk, int buf) {
@@ -240,51 +282,42 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
             avc_glds16(wsrc + (long)row * a.Mp + col, Ad + piece * 256);
         }
     };
-    auto load_x = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < AVC_CONV_MAXX; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nX) {
-                int r = avc_fastdiv(e, ROW, inv_row), p = e - r * ROW;
-                int sp = srcpos[p];
-                int c = chunk * CK + r;
-                float v = 0.f;
-                if (sp >= 0 && c < a.Cred) {
-                    long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
-                    v = a.x.ptr[(long)sp + coff];
-                }
-                xreg[it] = v;
-            }
-        }
-    };
-    auto store_x = [&](int buf) {
+    // source tile: wave w stages rows w, w+4, ... of the chunk, 64 positions per DMA instruction
+    auto load_x = [&](int chunk, int buf) {
         float* Xd = Xs + buf * XS;
+        for (int r = wave; r < CK; r += 4) {
+            const int c = chunk * CK + r;
+            if (c < a.Cred) {
+                const long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
+                const float* src = a.x.ptr + coff;
 #pragma unroll
-        for (int it = 0; it < AVC_CONV_MAXX; ++it) {
-            int e = tid + it * AVC_THREADS;
-            if (e < nX) Xd[e] = xreg[it];
+                for (int j = 0; j < AVC_CONV_NJ; ++j)
+                    if (j < nj && xoff[j] >= 0) avc_glds4(src + xoff[j], Xd + r * ROW + 64 * j);
+            } else {  // channel padding of the last chunk
+#pragma unroll
+                for (int j = 0; j < AVC_CONV_NJ; ++j)
+                    if (j < nj && 64 * j + lane < ROW) Xd[r * ROW + 64 * j + lane] = 0.f;
+            }
         }
     };
 
     load_a(0, 0);
-    load_x(0);
-    store_x(0);
+    load_x(0, 0);
     __syncthreads();
 
     const int a_lane = wave_m * (32 * WM) + li;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = (chunk + 1 < nchunk);
         if (more) {
-            load_a(chunk + 1, (chunk + 1) & 1);  // lands while this chunk is multiplied; drained at the barrier
-            load_x(chunk + 1);
+            load_a(chunk + 1, (chunk + 1) & 1);  // both land while this chunk is multiplied; drained at the barrier
+            load_x(chunk + 1, (chunk + 1) & 1);
         }
         const float* Ab = As + (chunk & 1) * AS;
         const float* Xb = Xs + (chunk & 1) * XS;
         if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, WN, true>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, WN, true, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else
-            conv_chunk_mma<WM, WN, false>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-        if (more) store_x((chunk + 1) & 1);
+            conv_chunk_mma<WM, WN, false, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         __syncthreads();
     }
 
@@ -391,9 +424,13 @@ long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
 }
 // K-chunk depth: layers that cannot put two workgroups on every CU are latency-bound per chunk
 // (global -> LDS round trip vs. ~1.3k MFMA cycles), so they take twice the channels per chunk
-int avc_conv_ck_for(int KS, long wgs) {
+int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) {
     int ck = avc_conv_ck(KS);
-    if (KS >= 4 && wgs <= 256) ck = 16;
+    if (KS >= 4 && wgs <= 256) {
+        int BN = (tile == 22) ? 128 : 64;
+        ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
+        if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;
+    }
     return ck;
 }
 
@@ -402,7 +439,7 @@ static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         size_t AS = (size_t)a.g[gi].KS * a.g[gi].CK * BM, XS = (size_t)a.g[gi].CK * q.ROW;
-        size_t bytes = (2 * AS + 2 * XS + q.ROW) * 4;
+        size_t bytes = (2 * AS + 2 * XS) * 4;
         worst = bytes > worst ? bytes : worst;
     }
     return worst + 16;
@@ -427,7 +464,7 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         if (a.g[gi].CK % 8 != 0) return -2;
-        if ((long)a.g[gi].CK * q.ROW > (long)AVC_THREADS * AVC_CONV_MAXX) return -3;
+        if (q.ROW > 64 * AVC_CONV_NJ) return -3;
     }
     size_t lds = conv_lds_bytes(a, BM, BN);
     if (lds > 160 * 1024) return -5;
@@ -437,16 +474,21 @@ int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
         flops += 2.0 * a.M * a.Cred * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     const bool mir = a.mode == 1 && a.mirror;
-    if (tile == 22) {
-        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<2, 2, false>), grid, block, lds, stream, a);
-    } else if (tile == 21) {
-        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<2, 1, false>), grid, block, lds, stream, a);
-    } else {
-        if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false>), grid, block, lds, stream, a);
-    }
+    // the model's kernel_size (5) with the two chunk depths the plan uses gets straight-line chunks
+    const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : 0)) : 0;
+#define AVC_LAUNCH_CONV(WM_, WN_)                                                                                      \
+    do {                                                                                                               \
+        if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 1>), grid, block, lds, stream, a);    \
+        else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 2>), grid, block, lds, stream, a); \
+        else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 0, 0>), grid, block, lds, stream, a);          \
+        else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 1>), grid, block, lds, stream, a);   \
+        else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 2>), grid, block, lds, stream, a);   \
+        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0>), grid, block, lds, stream, a);                  \
+    } while (0)
+    if (tile == 22) AVC_LAUNCH_CONV(2, 2);
+    else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
+    else AVC_LAUNCH_CONV(1, 1);
+#undef AVC_LAUNCH_CONV
     return (int)hipGetLastError();
 }
 

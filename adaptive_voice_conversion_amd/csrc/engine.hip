@@ -148,9 +148,9 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.dgM = dgM > 0 ? dgM : L.Cin;
     L.Mp_d = avc_cdiv(L.dgM, 128) * 128;
     int tf = avc_conv_pick_tile(L.Mp_f, Bn, Tf, ngroups);
-    L.CK = avc_conv_ck_for(L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups));
+    L.CK = avc_conv_ck_for(L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
     int td = avc_conv_pick_tile(L.Mp_d, Bn, Td, 1);
-    L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1));
+    L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
     L.nchunk_f = avc_cdiv(L.Cin, L.CK);
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);

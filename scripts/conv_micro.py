@@ -1,0 +1,68 @@
+"""Micro-benchmark of the conv kernels at model shapes through the op-level C ABI (GPU only)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adaptive_voice_conversion_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+P = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+def pack(w, dgrad):
+    Cout, Cin, KS = w.shape
+    n = lib.avc_packed_weight_floats(Cout, Cin, KS, dgrad)
+    dst = torch.zeros(n, device=dev)
+    arr = (ctypes.c_void_p * 1)(w.data_ptr())
+    assert lib.avc_pack_weight(arr, 1, Cout, Cout, Cin, KS, dgrad, P(dst), None) == 0
+    return dst
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
+    x = torch.randn(B, Cin, T, device=dev)
+    w = torch.randn(Cout, Cin, KS, device=dev) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, device=dev)
+    padL, padR = KS // 2, (KS // 2 - 1 if KS % 2 == 0 else KS // 2)
+    To = (T + padL + padR - KS) // stride + 1
+    out = torch.zeros(B, Cout, To, device=dev)
+    dy = torch.randn(B, Cout, To, device=dev)
+    dx = torch.zeros(B, Cin, T, device=dev)
+    wp, wpd = pack(w, 0), pack(w, 1)
+    flops = 2.0 * Cout * Cin * KS * B * To
+    res = []
+    for tile in tiles:
+        if "f" in which:
+            f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wp), P(b), Cout, KS, stride, 1, P(out),
+                                           out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, tile, None)
+            assert f() == 0
+            us = timeit(f); res.append(f"fwd t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
+        if "d" in which:
+            f = lambda: lib.avc_conv1d_dgrad(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, To, P(wpd), Cin, KS, stride, T, P(dx),
+                                             dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, tile, None)
+            assert f() == 0
+            us = timeit(f); res.append(f"dgr t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
+    if "w" in which:
+        ws = torch.zeros(lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, To, KS), device=dev)
+        dW = torch.zeros(Cout, Cin, KS, device=dev); db = torch.zeros(Cout, device=dev)
+        f = lambda: lib.avc_conv1d_wgrad(P(x), x.stride(0), x.stride(1), 1, P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cin, Cout, T, To,
+                                         KS, stride, P(dW), P(db), P(ws), None)
+        assert f() == 0
+        us = timeit(f); res.append(f"wgrad(+reduce): {us:7.1f}us {flops/us/1e6:6.1f}TF")
+    print(f"B={B} {Cin}->{Cout} T={T} k={KS} s={stride}: " + " | ".join(res), flush=True)
+
+if __name__ == "__main__":
+    B = 256
+    run(B, 128, 128, 128, 5, 1)
+    run(B, 128, 128, 64, 5, 1)
+    run(B, 128, 128, 32, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 16, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 128, 5, 2, tiles=(21, 11))
+    run(B, 1104, 128, 128, 1, 1, tiles=(22, 21))
+    run(B, 80, 128, 128, 8, 1, tiles=(22, 21), which="fw")
+    run(1, 128, 128, 256, 1, 1, tiles=(11,))
