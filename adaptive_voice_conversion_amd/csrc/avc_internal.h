@@ -21,7 +21,7 @@ int avc_launch_pack(const PackArgs& p, hipStream_t stream);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
-void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit);
 int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
 int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream);

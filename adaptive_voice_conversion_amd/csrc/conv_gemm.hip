@@ -410,12 +410,15 @@ extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? 8 : (KS >= 2 ? 16 : 32); }
 
 // tile choice shared by the launcher and the plan (which sizes CK from it)
 int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {
+    // measured on MI355X (profiles/r01_conv_micro_*.log): at equal work the 64x64 tile beats 128x64
+    // and 128x128 (more resident waves hide the per-chunk LDS/DMA latency; the fp32 MFMA needs no
+    // bigger tile for operand reuse), so take the smallest tile unless the grid gets very large
     auto ntn = [&](int BN) { return Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout); };
-    long t22 = (long)(Mp / 128) * ntn(128) * ngroups;
+    long t11 = (long)(Mp / 64) * ntn(64) * ngroups;
     long t21 = (long)(Mp / 128) * ntn(64) * ngroups;
-    if (t22 >= 512) return 22;
-    if (t21 >= 256) return 21;
-    return 11;
+    if (t11 <= 2048) return 11;
+    if (t21 <= 4096) return 21;
+    return 22;
 }
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
     int BM = (tile == 11) ? 64 : 128, BN = (tile == 22) ? 128 : 64;

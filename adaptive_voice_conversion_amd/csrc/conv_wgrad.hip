@@ -19,27 +19,36 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
 }
 
-template <int KS>
+// KS taps, NB 32-wide ci blocks per wave, WCO waves along co (4/WCO along ci):
+//   workgroup tile = (32*WCO) co  x  (32*NB*(4/WCO)) ci  x  KS taps.
+// <5,1,2> is the 64x64 tile of the k=5 layers; WCO=4 (128co x 32ci) suits Cin that is not a multiple
+// of 64 (the 80-mel bank convs); <1,4,4> (128co x 128ci) gives the 1x1 convs / Linears four
+// accumulators per wave, i.e. the arithmetic intensity per staged element that the taps give k=5.
+template <int KS, int NB, int WCO>
 __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int WCI = 4 / WCO;            // waves along ci
+    constexpr int TCO = 32 * WCO;           // co rows per workgroup
+    constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
+    constexpr int NACC = KS * NB;
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
-    const int wave_m = wave >> 1, wave_n = wave & 1, li = lane & 31, h = lane >> 5;
-    const int ci_tiles = avc_cdiv(a.Cin, 64);
-    const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
+    const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
+    const int ci_tiles = avc_cdiv(a.Cin, TCI);
+    const int co0 = (blockIdx.x / ci_tiles) * TCO, ci0 = (blockIdx.x % ci_tiles) * TCI;
     const int z = blockIdx.y;
     const int Tc = a.Tc, spc = a.spc;
     const int XSEG = (Tc - 1) * a.stride + KS;
     const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
-    const int DYS = 64 * WG_DYROW, XS = 64 * XROW;
-    float* dyT = smem;            // [2][64][WG_DYROW]
-    float* xT = smem + 2 * DYS;   // [2][64][XROW]
+    const int DYS = TCO * WG_DYROW, XS = TCI * XROW;
+    float* dyT = smem;            // [2][TCO][WG_DYROW]
+    float* xT = smem + 2 * DYS;   // [2][TCI][XROW]
     const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
     const float inv_xrow = 1.0f / (float)XROW;
 
-    f32x16 acc[KS];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int j = 0; j < KS; ++j)
+    for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float dbsum = 0.f;
@@ -52,10 +61,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     for (int e = tid; e < 2 * (DYS + XS); e += AVC_THREADS) smem[e] = 0.f;
 
     // chunk-invariant part of every lane's DMA descriptors (fast path: one sample per chunk)
-    constexpr int NPD = (64 * WG_DYROW + 255) / 256;  // dy pieces per wave
-    constexpr int NPX = 18;                           // x pieces per wave (XROW <= 71 when spc == 1)
+    constexpr int NPD = (TCO * WG_DYROW + 255) / 256;  // dy pieces per wave
+    constexpr int NPX = (TCI * (KS == 1 ? 33 : 71) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
     const bool fastp = (spc == 1) && (XS <= NPX * 256);
-    int dyo[NPD], dyq[NPD], xo[NPX], xq[NPX];
+    int dyo[NPD], xo[NPX], xq[NPX];
     if (fastp) {
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
@@ -63,7 +72,6 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
             bool ok = f < DYS && qcol < 32 && (co0 + row) < a.Cout;
             dyo[i] = ok ? (int)(src_chan_off(a.dy, co0 + row) + (long)qcol * a.dy.st) : -1;
-            dyq[i] = qcol;
         }
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
@@ -88,10 +96,12 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             for (int i = 0; i < NPD; ++i) {
                 const int piece = wave + 4 * i;
                 if (piece * 64 < DYS && dyo[i] >= 0) {
-                    if (t0 + dyq[i] < a.Tout)
+                    const int f = piece * 64 + lane;
+                    const int qcol = f - (f / WG_DYROW) * WG_DYROW;
+                    if (t0 + qcol < a.Tout)
                         avc_glds4(dyb + dyo[i], dd + piece * 64);
                     else
-                        dd[piece * 64 + lane] = 0.f;
+                        dd[f] = 0.f;
                 }
             }
 #pragma unroll
@@ -146,11 +156,13 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     __syncthreads();  // zero fill complete before the first DMA lands
     if (c_begin < c_end) issue(c_begin, 0);
     __syncthreads();
+    constexpr int TPR = AVC_THREADS / TCO;  // threads per dy row in the bias-gradient partial sum
+    constexpr int CPT = 32 / TPR;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const int buf = (chunk - c_begin) & 1;
         if (chunk + 1 < c_end) issue(chunk + 1, buf ^ 1);
         const float* arow = dyT + buf * DYS + (wave_m * 32 + li) * WG_DYROW;
-        const float* brow = xT + buf * XS + (wave_n * 32 + li) * XROW;
+        const float* brow = xT + buf * XS + (wave_n * NB * 32 + li) * XROW;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             int qcol = 2 * s + h;
@@ -158,33 +170,39 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             float av = arow[qcol];
             const float* bp = brow + sl * XSEG + tl * a.stride;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j], acc[j], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+                    acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nb * 32 * XROW + j], acc[nb * KS + j], 0, 0, 0);
         }
         if (do_db) {
-            const float* dr = dyT + buf * DYS + (tid >> 2) * WG_DYROW + (tid & 3) * 8;
+            const float* dr = dyT + buf * DYS + (tid / TPR) * WG_DYROW + (tid % TPR) * CPT;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dbsum += dr[k];
+            for (int k = 0; k < CPT; ++k) dbsum += dr[k];
         }
         __syncthreads();  // next stage landed (the DMA is drained before the barrier), this one is free
     }
 
     // ---- epilogue: partial tile -> slab[z][co][ci][j]
     float* slab = a.slab + (long)z * a.slab_stride;
-    const int ci = ci0 + wave_n * 32 + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < a.Cout && ci < a.Cin) {
-            float* dst = slab + ((long)co * a.Cin + ci) * KS;
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ci = ci0 + (wave_n * NB + nb) * 32 + li;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) dst[j] = acc[j][r];
+        for (int r = 0; r < 16; ++r) {
+            int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < a.Cout && ci < a.Cin) {
+                float* dst = slab + ((long)co * a.Cin + ci) * KS;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) dst[j] = acc[nb * KS + j][r];
+            }
         }
     }
     if (do_db) {
-        dbsum += __shfl_xor(dbsum, 1);
-        dbsum += __shfl_xor(dbsum, 2);
-        int co = co0 + (tid >> 2);
-        if ((tid & 3) == 0 && co < a.Cout) a.dbslab[(long)z * a.db_stride + co] = dbsum;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) dbsum += __shfl_xor(dbsum, o);
+        int co = co0 + tid / TPR;
+        if ((tid % TPR) == 0 && co < a.Cout) a.dbslab[(long)z * a.db_stride + co] = dbsum;
     }
 }
 
@@ -204,7 +222,18 @@ __global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceAr
 }
 
 // --------------------------------------------------------------------------
-void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+// tile shape per layer: returns (NB, WCO); tile = (32*WCO) co x (32*NB*(4/WCO)) ci
+static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
+    if (KS == 1 && Cin >= 96) {
+        *NB = 4; *WCO = 4;      // 128 x 128
+    } else if (Cin % 64 == 0 || KS == 1) {
+        *NB = 1; *WCO = 2;      // 64 x 64
+    } else {
+        *NB = 1; *WCO = 4;      // 128 x 32: Cin = 80 wastes 17 % instead of 38 %
+    }
+}
+
+void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit) {
     if (Tout >= 32) {
         *Tc = 32;
@@ -221,7 +250,9 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* 
     }
     // split-K factor: enough workgroups to cover the 256 CUs, but at least 4 chunks (128 columns)
     // per workgroup so that the slab write + fixed-order reduce stay a small fraction of the work
-    int tiles = avc_cdiv(Cout, 64) * avc_cdiv(Cin, 64);
+    int NB, WCO;
+    wgrad_shape(Cin, Cout, KS, &NB, &WCO);
+    int tiles = avc_cdiv(Cout, 32 * WCO) * avc_cdiv(Cin, 32 * NB * (4 / WCO));
     static int target_wgs = 0;
     if (target_wgs == 0) {
         const char* e = getenv("AVC_WGRAD_WGS");  // tuning knob (workgroups per launch the split-K aims for)
@@ -236,31 +267,44 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int* Tc, int* spc, int* 
     *nsplit = avc_cdiv(*total_chunks, *chunks_per_wg);
 }
 
+template <int KS, int NB, int WCO>
+static int launch_wgrad_t(const WgradArgs& a, int nsplit, hipStream_t stream) {
+    constexpr int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
+    int XSEG = (a.Tc - 1) * a.stride + KS;
+    int XROW = (a.spc * XSEG) | 1;
+    size_t lds = (size_t)2 * (TCO * WG_DYROW + TCI * XROW) * 4 + 16;
+    if (lds > 158 * 1024) return -3;
+    dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit);
+    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO>), grid, dim3(AVC_THREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
 template <int KS>
-static void launch_wgrad_ks(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS>), grid, dim3(AVC_THREADS), lds, stream, a);
+static int launch_wgrad_ks(const WgradArgs& a, int nsplit, int WCO, hipStream_t stream) {
+    return WCO == 4 ? launch_wgrad_t<KS, 1, 4>(a, nsplit, stream) : launch_wgrad_t<KS, 1, 2>(a, nsplit, stream);
 }
 
 int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
     if (a.KS < 1 || a.KS > 8) return -1;
     if (a.padL >= a.Tin) return -6;
-    int XSEG = (a.Tc - 1) * a.stride + a.KS;
-    int XROW = (a.spc * XSEG) | 1;
-    size_t lds = (size_t)2 * (64 * WG_DYROW + 64 * XROW) * 4 + 16;
-    if (lds > 158 * 1024) return -3;
-    dim3 grid(avc_cdiv(a.Cout, 64) * avc_cdiv(a.Cin, 64), nsplit);
-    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
-    switch (a.KS) {
-        case 1: launch_wgrad_ks<1>(a, grid, lds, stream); break;
-        case 2: launch_wgrad_ks<2>(a, grid, lds, stream); break;
-        case 3: launch_wgrad_ks<3>(a, grid, lds, stream); break;
-        case 4: launch_wgrad_ks<4>(a, grid, lds, stream); break;
-        case 5: launch_wgrad_ks<5>(a, grid, lds, stream); break;
-        case 6: launch_wgrad_ks<6>(a, grid, lds, stream); break;
-        case 7: launch_wgrad_ks<7>(a, grid, lds, stream); break;
-        default: launch_wgrad_ks<8>(a, grid, lds, stream); break;
+    int NB, WCO;
+    wgrad_shape(a.Cin, a.Cout, a.KS, &NB, &WCO);
+    if (a.KS == 1 && NB == 4) {
+        int rc = launch_wgrad_t<1, 4, 4>(a, nsplit, stream);
+        if (rc != -3) return rc;
+        return launch_wgrad_t<1, 1, 2>(a, nsplit, stream);  // LDS too small for the wide tile (many short samples)
     }
-    return (int)hipGetLastError();
+    switch (a.KS) {
+        case 1: return launch_wgrad_ks<1>(a, nsplit, WCO, stream);
+        case 2: return launch_wgrad_ks<2>(a, nsplit, WCO, stream);
+        case 3: return launch_wgrad_ks<3>(a, nsplit, WCO, stream);
+        case 4: return launch_wgrad_ks<4>(a, nsplit, WCO, stream);
+        case 5: return launch_wgrad_ks<5>(a, nsplit, WCO, stream);
+        case 6: return launch_wgrad_ks<6>(a, nsplit, WCO, stream);
+        case 7: return launch_wgrad_ks<7>(a, nsplit, WCO, stream);
+        default: return launch_wgrad_ks<8>(a, nsplit, WCO, stream);
+    }
 }
 
 int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {

@@ -609,7 +609,7 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.B = Bn; a.Cin = L.Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
     int nsplit;
-    avc_wgrad_plan(Bn, L.Cin, Cout, Tout, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+    avc_wgrad_plan(Bn, L.Cin, Cout, Tout, L.KS, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
     long wsz = (long)Cout * L.Cin * L.KS;
     long need = (long)nsplit * (wsz + Cout);
     long off = c.slab_used;

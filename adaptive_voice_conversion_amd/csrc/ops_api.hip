@@ -90,7 +90,7 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
 // workspace (floats) needed by avc_conv1d_wgrad for the split-K slabs
 long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
     int Tc, spc, cps, tot, cpw, nsplit;
-    avc_wgrad_plan(B, Cin, Cout, Tout, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
+    avc_wgrad_plan(B, Cin, Cout, Tout, KS, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
     return (long)nsplit * ((long)Cout * Cin * KS + Cout);
 }
 
@@ -105,7 +105,7 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = KS; a.padL = KS / 2; a.stride = stride;
     int nsplit;
-    avc_wgrad_plan(B, Cin, Cout, Tout, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+    avc_wgrad_plan(B, Cin, Cout, Tout, KS, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
     long wsz = (long)Cout * Cin * KS;
     a.slab = ws; a.slab_stride = wsz;
     a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;

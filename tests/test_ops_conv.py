@@ -185,6 +185,8 @@ WG = [
     (1, 40, 32, 33, 1, 1),
     (9, 16, 32, 3, 5, 1),
     (1, 16, 130, 200, 3, 1),
+    (2, 130, 40, 40, 1, 1),      # 1x1 with the 128x128 four-accumulator tile
+    (2, 80, 32, 33, 4, 1),       # Cin = 80: 128co x 32ci tile
     pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
     pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
     pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
