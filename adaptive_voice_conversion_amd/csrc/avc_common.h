@@ -73,7 +73,26 @@ struct ReduceSeg {
     float* dst;
     long stride;
     int n, nsplit;
+    int KS;  // > 1: slab is tap-major [KS][n/KS], dst is [n/KS][KS]
+    int pad_;
 };
+#define AVC_DENSE_MAXL 17
+struct DenseLayer {
+    const float* wp;    // packed weight image [Kp][Mp] (forward image, or the dgrad image for the backward kernel)
+    const float* bias;  // forward only
+    float* act;         // ReLU output of this layer [C][B] (written forward, read as mask backward)
+    float* out2;        // forward, second Linear of a block: h_{l+1} [C][B]
+    float* dz;          // backward: gradient wrt this layer's pre-activation [C][B]
+    int Cin, Cout, Kp, Mp;
+};
+struct DenseArgs {
+    DenseLayer layer[AVC_DENSE_MAXL];
+    int nlayers, B, C, Kmax, Wmax;
+    const float* in;    // forward: pooled [C][B]; backward: d(emb) [B][c_out]
+    float* emb;         // forward output [B][c_out]
+    float* dpooled;     // backward output [C][B]
+};
+
 struct INFwdArgs {
     const float* y;   // conv output rows [R][T]
     float* out;       // relu((y-mean)*rstd*gamma+beta) [+ resmap(res)]

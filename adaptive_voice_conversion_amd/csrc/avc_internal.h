@@ -24,7 +24,7 @@ int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit);
 int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
-int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream);
+int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream);
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);
@@ -57,3 +57,4 @@ struct ProfScope {
     bool active_;
     hipStream_t s_;
 };
+int avc_launch_dense(const DenseArgs& a, int backward, hipStream_t s);

@@ -141,6 +141,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
                 unit_ptrs(u + 1, Ar, Xr);
                 conv_load_unit<WM, WN, MIRROR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
             }
+            // (pinning this order with sched_barrier(0) was measured: no gain with 4 waves/SIMD, r1 log)
             conv_mma_unit<WM, WN>(acc, av[u & 1], bv[u & 1]);
         }
     } else {

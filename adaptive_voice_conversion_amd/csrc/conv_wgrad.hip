@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
         __syncthreads();  // next stage landed (the DMA is drained before the barrier), this one is free
     }
 
-    // ---- epilogue: partial tile -> slab[z][co][ci][j]
+    // ---- epilogue: partial tile -> slab[z][tap][co][ci]  (tap-major: the 32 lanes of a half-wave
+    // hold 32 consecutive ci of one (tap, co) row -> 128-byte coalesced stores; the reduce kernel
+    // restores the [co][ci][tap] parameter layout)
     float* slab = a.slab + (long)z * a.slab_stride;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -192,9 +194,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
         for (int r = 0; r < 16; ++r) {
             int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (co < a.Cout && ci < a.Cin) {
-                float* dst = slab + ((long)co * a.Cin + ci) * KS;
 #pragma unroll
-                for (int j = 0; j < KS; ++j) dst[j] = acc[nb * KS + j][r];
+                for (int j = 0; j < KS; ++j) slab[((long)j * a.Cout + co) * a.Cin + ci] = acc[nb * KS + j][r];
             }
         }
     }
@@ -214,10 +215,16 @@ struct ReduceArgs {
 
 __global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceArgs a) {
     const ReduceSeg s = a.seg[blockIdx.y];
+    const int plane = s.n / s.KS;  // slab is [tap][rows*Cin]; dst is [rows*Cin][tap]
     for (int e = blockIdx.x * AVC_THREADS + threadIdx.x; e < s.n; e += gridDim.x * AVC_THREADS) {
         float v = 0.f;
         for (int zz = 0; zz < s.nsplit; ++zz) v += s.slab[(long)zz * s.stride + e];
-        s.dst[e] = v;
+        if (s.KS == 1) {
+            s.dst[e] = v;
+        } else {
+            int j = e / plane, rem = e - j * plane;
+            s.dst[(long)rem * s.KS + j] = v;
+        }
     }
 }
 
@@ -325,7 +332,7 @@ int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, hipStream_t stream) {
+int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream) {
     ReduceArgs r;
     r.nseg = 1;
     r.seg[0].slab = slab;
@@ -333,6 +340,7 @@ int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* 
     r.seg[0].stride = stride;
     r.seg[0].n = n;
     r.seg[0].nsplit = nsplit;
+    r.seg[0].KS = KS;
     int blocks = avc_cdiv(n, AVC_THREADS);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1), dim3(AVC_THREADS), 0, stream, r);

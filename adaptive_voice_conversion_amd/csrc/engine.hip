@@ -41,6 +41,8 @@ static int fail(int rc, const char* what) {
 extern "C" const char* avc_last_error(void) { return g_err.c_str(); }
 extern "C" int avc_version(void) { return 100; }
 
+#define AVC_MAX_WEV 192
+
 struct ParamT {
     long off, numel;
     int d[3];
@@ -103,6 +105,12 @@ struct avc_plan {
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     mutable int side_state = 0;  // 0 = not created, 1 = ready, -1 = disabled
+    // weight-gradient kernels depend on nothing downstream: they run on their own (low priority)
+    // streams beside the dgrad / InstanceNorm-backward chain of each branch
+    mutable hipStream_t wstream[2] = {nullptr, nullptr};
+    mutable hipEvent_t wev[AVC_MAX_WEV];
+    mutable hipEvent_t wjoin[2];
+    long dyarena = -1, dyarena_floats = 0;
 
     long alloc(long n) {
         long o = ws_top;
@@ -439,11 +447,14 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
 
     // ---- split-K slabs: size them with a dry run of the backward pass
     p->slab = p->ws_top;
-    long need = 0;
+    long need[2] = {0, 0};
     avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
-                      nullptr, nullptr, true, &need);
-    p->slab_floats = need;
-    p->ws_top += (need + 63) / 64 * 64;
+                      nullptr, nullptr, true, need);
+    p->slab_floats = need[0];
+    p->ws_top += (need[0] + 63) / 64 * 64;
+    p->dyarena = p->ws_top;
+    p->dyarena_floats = need[1];
+    p->ws_top += (need[1] + 63) / 64 * 64;
     *out = p;
     return 0;
 }
@@ -453,6 +464,11 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
         hipStreamDestroy(p->side);
         hipEventDestroy(p->ev_fork);
         hipEventDestroy(p->ev_join);
+        for (int i = 0; i < 2; ++i) {
+            hipStreamDestroy(p->wstream[i]);
+            hipEventDestroy(p->wjoin[i]);
+        }
+        for (int i = 0; i < AVC_MAX_WEV; ++i) hipEventDestroy(p->wev[i]);
     }
     delete p;
 }
@@ -470,7 +486,15 @@ static bool side_ready(const avc_plan* p) {
         } else if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
                    hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess) {
-            p->side_state = 1;
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
+            bool ok = true;
+            for (int i = 0; i < 2; ++i) {
+                ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
+            }
+            for (int i = 0; i < AVC_MAX_WEV; ++i) ok = ok && hipEventCreateWithFlags(&p->wev[i], hipEventDisableTiming) == hipSuccess;
+            p->side_state = ok ? 1 : -1;
         } else {
             p->side_state = -1;
         }
@@ -595,6 +619,15 @@ struct BwdCtx {
     bool dry;
     long slab_used;
     Reducer red;
+    hipStream_t wstream;   // stream of the weight-gradient kernels of the current branch (== s when not overlapping)
+    int nev;
+    long dy_used;
+    // every gradient tensor a (possibly still running) wgrad kernel reads gets its own buffer
+    float* fresh(long n) {
+        long off = dy_used;
+        dy_used += (n + 63) / 64 * 64;
+        return dry ? nullptr : ws + p->dyarena + off;
+    }
 };
 
 // weight + bias gradient of layer L: x = forward input view, dy = output-gradient view
@@ -619,7 +652,14 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.slab_stride = wsz;
     a.dbslab = a.slab + (long)nsplit * wsz;
     a.db_stride = Cout;
-    int rc = avc_launch_wgrad(a, nsplit, c.s);
+    hipStream_t ls = c.s;
+    if (c.wstream != c.s && c.nev < AVC_MAX_WEV) {  // order after the producer of dy, then run beside the main chain
+        hipEvent_t e = c.p->wev[c.nev++];
+        hipEventRecord(e, c.s);
+        hipStreamWaitEvent(c.wstream, e, 0);
+        ls = c.wstream;
+    }
+    int rc = avc_launch_wgrad(a, nsplit, ls);
     if (rc) return rc;
     for (int s = 0; s < L.nsrc; ++s) {
         ReduceSeg w;
@@ -628,12 +668,14 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
         w.stride = a.slab_stride;
         w.n = (int)((long)L.rows * L.Cin * L.KS);
         w.nsplit = nsplit;
+        w.KS = L.KS;
         ReduceSeg b;
         b.slab = a.dbslab + (long)s * L.rows;
         b.dst = c.grads + c.p->params[L.b[s]].off;
         b.stride = a.db_stride;
         b.n = L.rows;
         b.nsplit = nsplit;
+        b.KS = 1;
         c.red.segs.push_back(w);
         c.red.segs.push_back(b);
     }
@@ -747,18 +789,30 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         }
         const int Tn = e.T[e.n];
         RUN(avc_launch_timepool_fwd(ws + e.out[e.n], B, C, Tn, ws + e.pooled, s));
-        // dense blocks on the channel-major [C][B] matrix viewed as one [1, C, T=B] sample (model.py:252-263)
-        for (int l = 0; l < e.nd; ++l) {
-            ConvArgs a = mk_fwd(p, p->layers[e.dn1[l]], params, ws, ws + e.hd[l], 0, B, 1, 1, B, ws + e.d1[l], 0, B, 1, 1);
-            RUN(avc_launch_conv(a, s, 0));
-            ConvArgs b = mk_fwd(p, p->layers[e.dn2[l]], params, ws, ws + e.d1[l], 0, B, 1, 1, B, ws + e.d2[l], 0, B, 1, 1);
-            b.g[0].out2 = ws + e.hd[l + 1];
-            set_res(b, ws + e.hd[l], AVC_RES_IDENTITY, 0, B, 1, B);
-            RUN(avc_launch_conv(b, s, 0));
+        // dense blocks + output layer: ONE fused launch (dense.hip); activations channel-major [C][B]
+        {
+            DenseArgs da;
+            memset(&da, 0, sizeof(da));
+            da.nlayers = 2 * e.nd + 1;
+            da.B = B; da.C = C;
+            da.in = ws + e.hd[0];
+            da.emb = ws + p->emb;
+            for (int l = 0; l < da.nlayers; ++l) {
+                const bool last = (l == da.nlayers - 1);
+                const LayerP& L = p->layers[last ? e.outl : ((l & 1) ? e.dn2[l / 2] : e.dn1[l / 2])];
+                DenseLayer& D = da.layer[l];
+                D.wp = ws + L.wpf;
+                D.bias = p->par(params, L.b[0]);
+                D.Cin = L.Cin; D.Cout = L.Cout; D.Kp = L.nchunk_f * L.CK; D.Mp = L.Mp_f;
+                if (!last) {
+                    D.act = ws + ((l & 1) ? e.d2[l / 2] : e.d1[l / 2]);
+                    D.out2 = (l & 1) ? ws + e.hd[l / 2 + 1] : nullptr;
+                }
+                da.Kmax = D.Kp > da.Kmax ? D.Kp : da.Kmax;
+                da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
+            }
+            RUN(avc_launch_dense(da, 0, s));
         }
-        // output layer -> emb [B][c_out] row-major
-        ConvArgs o = mk_fwd(p, p->layers[e.outl], params, ws, ws + e.hd[e.nd], 0, B, 1, 1, B, ws + p->emb, 0, 1, e.c.c_out, 0);
-        RUN(avc_launch_conv(o, s, 0));
     }
 
     // ---------------- content encoder (model.py:301-323)
@@ -868,13 +922,16 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                       long* slab_need) {
     BwdCtx c;
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
+    c.nev = 0; c.dy_used = 0;
+    const bool overlap = !dry && side_ready(p);
+    c.wstream = overlap ? p->wstream[0] : s;
     c.red.s = s; c.red.dry = dry;
     const int B = p->B;
     float* gA = ws + p->gA;
     float* gB = ws + p->gB;
     float* gC = ws + p->gC;
-    float* dyA = ws + p->dyA;
-    float* dyB = ws + p->dyB;
+    float* dyA = nullptr;
+    float* dyB = nullptr;
     auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
 
     // ---------------- decoder
@@ -893,6 +950,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
             const LayerP& L1 = p->layers[d.c1[l]];
             const LayerP& L2 = p->layers[d.c2[l]];
+            dyA = c.fresh((long)B * C * T2);
             if (!dry) RUN(in_bwd(gA, ws + d.y2[l], ws + d.st2[l], B, C, T2, ws + d.cond, csb, (2 * l + 1) * 2 * C, dyA, ws + d.dcond, s));
             // dyA is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
             if (!dry) {
@@ -900,6 +958,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 RUN(avc_launch_conv(a, s, 0));
             }
             RUN(wgrad_layer(c, L2, ws + d.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, up, up, B, Ti, Ti));
+            dyB = c.fresh((long)B * C * Ti);
             if (!dry) RUN(in_bwd(gB, ws + d.y1[l], ws + d.st1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, dyB, ws + d.dcond, s));
             if (!dry) {
                 ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
@@ -910,6 +969,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         const LayerP& Li = p->layers[d.in_conv];
+        dyA = c.fresh((long)B * C * Tb);
         if (!dry) RUN(in_bwd(gA, ws + d.y0, ws + d.st0, B, C, Tb, nullptr, 0, 0, dyA, nullptr, s));
         RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
@@ -940,56 +1000,55 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         float* gA = ws + p->gA2;
         float* gB = ws + p->gB2;
         float* gC = ws + p->gC2;
-        float* dyA = ws + p->dyA2;
-        float* dyB = ws + p->dyB2;
+        float* dyA = nullptr;
+        float* dyB = nullptr;
+        c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
         auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
         const EncNet& e = p->spk;
         const int C = e.c.c_h;
         float* dhA = ws + p->dhA;
-        float* dhB = ws + p->dhB;
-        float* dzA = ws + p->dzA;
-        float* dzB = ws + p->dzB;
         const LayerP& Lo = p->layers[e.outl];
-        // output layer: x = h[nd] ([1,C,B]), dy = d_emb ([B][c_out] row-major)
-        RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(Lo, ws, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B, dhA, 0, B, 1);
-            if (e.nd > 0) {
-                a.g[0].out2 = dzA;
-                a.g[0].mask = ws + e.d2[e.nd - 1];
-            }
-            RUN(avc_launch_conv(a, s, 0));
-        }
-        for (int l = e.nd - 1; l >= 0; --l) {
-            const LayerP& D1 = p->layers[e.dn1[l]];
-            const LayerP& D2 = p->layers[e.dn2[l]];
-            RUN(wgrad_layer(c, D2, ws + e.d1[l], 0, B, 1, dzA, 0, B, 1, 1, 1, B, B));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(D2, ws, dzA, 0, B, 1, 1, 1, B, B, nullptr, 0, B, 1);
-                a.g[0].out2 = dzB;
-                a.g[0].mask = ws + e.d1[l];
-                RUN(avc_launch_conv(a, s, 0));
-            }
-            RUN(wgrad_layer(c, D1, ws + e.hd[l], 0, B, 1, dzB, 0, B, 1, 1, 1, B, B));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(D1, ws, dzB, 0, B, 1, 1, 1, B, B, dhB, 0, B, 1);
-                set_res(a, dhA, AVC_RES_IDENTITY, 0, B, 1, B);
-                if (l > 0) {
-                    a.g[0].out2 = dzA;
-                    a.g[0].mask = ws + e.d2[l - 1];
+        // output layer + dense blocks: ONE fused dgrad launch produces every dz (and d pooled);
+        // the weight gradients are ordinary GEMMs over the batch on the wgrad stream
+        {
+            DenseArgs da;
+            memset(&da, 0, sizeof(da));
+            da.nlayers = 2 * e.nd + 1;
+            da.B = B; da.C = C;
+            da.in = ws + p->demb;
+            da.dpooled = dhA;
+            float* dzl[AVC_DENSE_MAXL];
+            for (int l = 0; l < da.nlayers; ++l) {
+                const bool last = (l == da.nlayers - 1);
+                const LayerP& L = p->layers[last ? e.outl : ((l & 1) ? e.dn2[l / 2] : e.dn1[l / 2])];
+                DenseLayer& D = da.layer[l];
+                D.wp = ws + L.wpd;
+                D.Cin = L.Cin; D.Cout = L.Cout; D.Kp = L.nchunk_d * L.CKd; D.Mp = L.Mp_d;
+                dzl[l] = last ? nullptr : c.fresh((long)C * B);
+                if (!last) {
+                    D.act = ws + ((l & 1) ? e.d2[l / 2] : e.d1[l / 2]);
+                    D.dz = dzl[l];
                 }
-                RUN(avc_launch_conv(a, s, 0));
+                da.Kmax = D.Kp > da.Kmax ? D.Kp : da.Kmax;
+                da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
             }
-            float* t = dhA; dhA = dhB; dhB = t;
+            if (!dry) RUN(avc_launch_dense(da, 1, s));
+            RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B));
+            for (int l = e.nd - 1; l >= 0; --l) {
+                RUN(wgrad_layer(c, p->layers[e.dn2[l]], ws + e.d1[l], 0, B, 1, dzl[2 * l + 1], 0, B, 1, 1, 1, B, B));
+                RUN(wgrad_layer(c, p->layers[e.dn1[l]], ws + e.hd[l], 0, B, 1, dzl[2 * l], 0, B, 1, 1, 1, B, B));
+            }
         }
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
+        dyA = c.fresh((long)B * C * Tn);
         if (!dry) RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, C, Tn, gA, dyA, s));
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
             const LayerP& L1 = p->layers[e.c1[l]];
             const LayerP& L2 = p->layers[e.c2[l]];
             // dyA = G_{l+1} * (a2 > 0)
+            dyB = c.fresh((long)B * C * Ti);
             if (!dry) {
                 ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, nullptr, (long)C * Ti, Ti, 1);
                 a.g[0].out2 = dyB;
@@ -997,6 +1056,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 RUN(avc_launch_conv(a, s, 0));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            dyA = c.fresh((long)B * C * Ti);  // (the wgrad of conv2 above still reads the previous dyA)
             if (!dry) {
                 ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
@@ -1009,6 +1069,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
         c.s = mainS;
+        c.wstream = overlap ? p->wstream[0] : mainS;
     }
     // ---------------- content encoder
     {
@@ -1024,12 +1085,14 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
             const LayerP& L1 = p->layers[e.c1[l]];
             const LayerP& L2 = p->layers[e.c2[l]];
+            dyA = c.fresh((long)B * C * T2);
             if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
             if (!dry) {
                 ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
                 RUN(avc_launch_conv(a, s, 0));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            dyB = c.fresh((long)B * C * Ti);
             if (!dry) RUN(in_bwd(gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
             if (!dry) {
                 ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
@@ -1039,13 +1102,23 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
             rot();
         }
+        dyA = c.fresh((long)B * C * e.T[0]);
         if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
     }
 
     if (!dry) join_side(p, mainS, sideS);
+    if (overlap) {
+        for (int i = 0; i < 2; ++i) {
+            hipEventRecord(p->wjoin[i], p->wstream[i]);
+            hipStreamWaitEvent(mainS, p->wjoin[i], 0);
+        }
+    }
     RUN(c.red.flush());
-    if (slab_need) *slab_need = c.slab_used;
+    if (slab_need) {
+        slab_need[0] = c.slab_used;
+        slab_need[1] = c.dy_used;
+    }
     return 0;
 }
 

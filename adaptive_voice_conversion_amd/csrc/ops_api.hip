@@ -111,9 +111,9 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;
     int rc = avc_launch_wgrad(a, nsplit, (hipStream_t)stream);
     if (rc) return rc;
-    rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, (hipStream_t)stream);
+    rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, KS, (hipStream_t)stream);
     if (rc || !db) return rc;
-    return avc_launch_reduce(a.dbslab, a.db_stride, nsplit, Cout, db, (hipStream_t)stream);
+    return avc_launch_reduce(a.dbslab, a.db_stride, nsplit, Cout, db, 1, (hipStream_t)stream);
 }
 
 // out = relu((y - mean_T)/sqrt(var_T + 1e-5) * gamma + beta) [+ resmap(res)]; saves mean/rstd

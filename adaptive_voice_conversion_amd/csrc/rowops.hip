@@ -11,6 +11,7 @@
 // = 2 reads + 1 write (SURVEY.md App. B traffic model).  Reductions are
 // xor-shuffles inside the LPR group.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -477,6 +478,15 @@ __global__ void __launch_bounds__(AVC_THREADS) clip_adam_kernel(const AdamArgs a
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
+static int in_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AVC_IN_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int LPR, int NV>
 static void launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
     int rpb = AVC_THREADS / LPR;
@@ -494,6 +504,15 @@ int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.out) % 16 == 0);
     if (!fast) {
         hipLaunchKernelGGL(instnorm_fwd_generic_kernel, dim3(avc_cdiv(a.R, 4)), dim3(AVC_THREADS), 0, s, a);
+    } else if (in_variant() == 1) {  // two float4 per lane: half the shuffle steps, twice the loads in flight
+        if (n4 <= 4) launch_in_fwd<4, 1>(a, s);
+        else if (n4 <= 8) launch_in_fwd<4, 2>(a, s);
+        else if (n4 <= 16) launch_in_fwd<8, 2>(a, s);
+        else if (n4 <= 32) launch_in_fwd<16, 2>(a, s);
+        else if (n4 <= 64) launch_in_fwd<32, 2>(a, s);
+        else if (n4 <= 128) launch_in_fwd<64, 2>(a, s);
+        else if (n4 <= 256) launch_in_fwd<64, 4>(a, s);
+        else launch_in_fwd<64, 8>(a, s);
     } else if (n4 <= 4) launch_in_fwd<4, 1>(a, s);
     else if (n4 <= 8) launch_in_fwd<8, 1>(a, s);
     else if (n4 <= 16) launch_in_fwd<16, 1>(a, s);
@@ -511,6 +530,15 @@ int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s) {
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.g | (uintptr_t)a.dy) % 16 == 0);
     if (!fast) {
         hipLaunchKernelGGL(instnorm_bwd_generic_kernel, dim3(avc_cdiv(a.R, 4)), dim3(AVC_THREADS), 0, s, a);
+    } else if (in_variant() == 1) {  // two float4 per lane: half the shuffle steps, twice the loads in flight
+        if (n4 <= 4) launch_in_bwd<4, 1>(a, s);
+        else if (n4 <= 8) launch_in_bwd<4, 2>(a, s);
+        else if (n4 <= 16) launch_in_bwd<8, 2>(a, s);
+        else if (n4 <= 32) launch_in_bwd<16, 2>(a, s);
+        else if (n4 <= 64) launch_in_bwd<32, 2>(a, s);
+        else if (n4 <= 128) launch_in_bwd<64, 2>(a, s);
+        else if (n4 <= 256) launch_in_bwd<64, 4>(a, s);
+        else launch_in_bwd<64, 8>(a, s);
     } else if (n4 <= 4) launch_in_bwd<4, 1>(a, s);
     else if (n4 <= 8) launch_in_bwd<8, 1>(a, s);
     else if (n4 <= 16) launch_in_bwd<16, 1>(a, s);

@@ -60,6 +60,59 @@ def profile_classes(solver, x, eps, steps):
     return out
 
 
+def instnorm_dominant_shape(B, C, T, launches=50):
+    """IN/AdaIN/ReLU forward + backward at the dominant shape [B, C, T] of the step: `launches`
+    back-to-back launches between two HIP events on the launch stream (no per-launch bracket)."""
+    from adaptive_voice_conversion_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nb = 8  # rotate buffers: 8 x 3 x 16.8 MB > 256 MiB Infinity Cache at the bench shape
+    ys = [torch.randn(B, C, T, device=dev) for _ in range(nb)]
+    outs = [torch.empty_like(y) for y in ys]
+    gs = [torch.randn_like(y) for y in ys]
+    cond = torch.randn(B, 2 * C, device=dev)
+    mean, rstd = torch.empty(B * C, device=dev), torch.empty(B * C, device=dev)
+    dcond = torch.zeros(B, 2 * C, device=dev)
+
+    def fwd(k):
+        lib.avc_instnorm_fwd(P(ys[k]), B, C, T, P(cond), 2 * C, 0, 1, None, 0, 0, P(outs[k]), P(mean), P(rstd), st)
+
+    def bwd(k):
+        lib.avc_instnorm_bwd(P(gs[k]), P(ys[k]), P(mean), P(rstd), B, C, T, P(cond), 2 * C, 0, 1, P(outs[k]), P(dcond), 2 * C, 0, st)
+
+    res = {}
+    for name, fn, passes in (("fwd", fwd, 2), ("bwd", bwd, 3)):
+        for k in range(nb):
+            fn(k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(launches):
+            fn(i % nb)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / launches
+        res[name] = dict(avg_launch_us=us, bytes_per_launch=passes * 4.0 * B * C * T, gbs=passes * 4.0 * B * C * T / us / 1e3)
+    return res
+
+
+def pmc_traffic(kernel_prefix, grid):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled on gfx950,
+    MI355X_MICROARCH.md §HBM; KB units) — None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")
+    try:
+        d = json.load(open(path))
+        for name, grids in d.items():
+            if name.startswith(kernel_prefix) and str(grid) in grids:
+                c = grids[str(grid)]
+                return (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(n_mels, T, budget_s=12.0):
     """The oracle's train step (same ATen CPU ops as the reference) on the host cores, bounded sample."""
     from oracle import avc_oracle as O
@@ -171,13 +224,22 @@ def main():
                                "ms_per_step": d["ms_per_step"]}
             ib = [prof[k] for k in ("instnorm_fwd", "instnorm_bwd") if k in prof]
             if ib:
+                C = cfg["ContentEncoder"]["c_h"]
+                dom_s = instnorm_dominant_shape(B, C, T)
+                bts = dom_s["fwd"]["bytes_per_launch"] + dom_s["bwd"]["bytes_per_launch"]
+                us = dom_s["fwd"]["avg_launch_us"] + dom_s["bwd"]["avg_launch_us"]
+                gbs = bts / us / 1e3
                 tot_b = sum(p["bytes_per_launch"] * p["launches_per_step"] for p in ib)
                 tot_ms = sum(p["ms_per_step"] for p in ib)
-                gbs = tot_b / (tot_ms * 1e-3) / 1e9
-                out["roofline_instnorm"] = {"kernel": "instnorm_fwd+bwd (IN/AdaIN/ReLU/residual)", "bound": "hbm",
-                                            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                            "traffic": None, "ms_per_step": tot_ms,
-                                            "algorithmic_bytes_per_step": tot_b}
+                tf = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
+                tb = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
+                out["roofline_instnorm"] = {
+                    "kernel": f"instnorm_fwd + instnorm_bwd (IN/AdaIN/ReLU) at the dominant shape [{B},{C},{T}]",
+                    "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "traffic": (tf + tb) if (tf and tb and B == 256 and T == 128) else None,
+                    "algorithmic_bytes": bts, "fwd": dom_s["fwd"], "bwd": dom_s["bwd"],
+                    "all_shapes_per_step": {"gbs": tot_b / (tot_ms * 1e-3) / 1e9, "ms": tot_ms, "algorithmic_bytes": tot_b,
+                                            "note": "26+26 launches of all T_l, each bracketed by its own event pair"}}
             out["kernel_classes"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
                                          if kk in ("ms_per_step", "launches_per_step", "avg_us", "tflops", "gbs")}
                                      for k, v in prof.items()}
