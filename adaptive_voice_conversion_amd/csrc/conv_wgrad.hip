@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     const int co0 = (blockIdx.x / ci_tiles) * TCO, ci0 = (blockIdx.x % ci_tiles) * TCI;
     const int z = blockIdx.y;
     const int Tc = a.Tc, spc = a.spc;
+    const int lgTc = 31 - __builtin_clz(Tc);
     const int XSEG = (Tc - 1) * a.stride + KS;
     const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
     const int DYS = TCO * WG_DYROW, XS = TCI * XROW;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
             int f = piece * 64 + lane;
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
             if (f < DYS && qcol < 32) {
-                int sl = qcol / Tc, tl = qcol - sl * Tc;
+                int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
                 int b = cb + sl, t = t0 + tl, co = co0 + row;
                 if (b < a.B && t < a.Tout && co < a.Cout)
                     avc_glds4(a.dy.ptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             int qcol = 2 * s + h;
-            int sl = qcol / Tc, tl = qcol - sl * Tc;
+            int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
             float av = arow[qcol];
             const float* bp = brow + sl * XSEG + tl * a.stride;
 #pragma unroll
@@ -217,8 +218,15 @@ __global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceAr
     const ReduceSeg s = a.seg[blockIdx.y];
     const int plane = s.n / s.KS;  // slab is [tap][rows*Cin]; dst is [rows*Cin][tap]
     for (int e = blockIdx.x * AVC_THREADS + threadIdx.x; e < s.n; e += gridDim.x * AVC_THREADS) {
+        // fixed summation order (deterministic); 4 independent loads in flight per thread
         float v = 0.f;
-        for (int zz = 0; zz < s.nsplit; ++zz) v += s.slab[(long)zz * s.stride + e];
+        int zz = 0;
+        for (; zz + 4 <= s.nsplit; zz += 4) {
+            const float* q = s.slab + (long)zz * s.stride + e;
+            float a0 = q[0], a1 = q[s.stride], a2 = q[2 * s.stride], a3 = q[3 * s.stride];
+            v = (((v + a0) + a1) + a2) + a3;
+        }
+        for (; zz < s.nsplit; ++zz) v += s.slab[(long)zz * s.stride + e];
         if (s.KS == 1) {
             s.dst[e] = v;
         } else {

@@ -25,14 +25,25 @@ static __device__ __forceinline__ void dense_gemm(f32x16 (&acc)[MAXMB], const fl
     for (int i = 0; i < MAXMB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    for (int s = 0; s < Kp / 2; ++s) {
-        const int k = 2 * s + h;
-        const float bv = Hin[k * DS_NS + li];
+    // Kp is a multiple of 32: 8 k-steps per unrolled group so that the 16 LDS fragment reads of a
+    // group are in flight together instead of one exposed LDS latency per MFMA
+    for (int s0 = 0; s0 < Kp / 2; s0 += 8) {
+        float bv[8], av[8][MAXMB];
 #pragma unroll
-        for (int i = 0; i < MAXMB; ++i) {
-            const int mb = wave + 4 * i;
-            if (mb < nmb) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[k * Mp + mb * 32 + li], bv, acc[i], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            const int k = 2 * (s0 + u) + h;
+            bv[u] = Hin[k * DS_NS + li];
+#pragma unroll
+            for (int i = 0; i < MAXMB; ++i) {
+                const int mb = wave + 4 * i;
+                av[u][i] = (mb < nmb) ? Wl[k * Mp + mb * 32 + li] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < MAXMB; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u], acc[i], 0, 0, 0);
     }
 }
 
