@@ -1,0 +1,91 @@
+"""One-shot conversion front (reference: inference.py:24-93 ``Inferencer``), the immediate
+caller of the hot path.
+
+Kept from the reference: ``Inferencer(config, args)``, ``load_model`` (``args.model`` =
+``<path>.ckpt`` state_dict), ``attr`` pickle with per-bin ``mean``/``std``,
+``utt_make_frames``, ``normalize`` / ``denormalize``, ``inference_one_utterance(x, x_cond)``.
+Added: ``convert_batch`` — many (source, target) pairs of arbitrary, unequal lengths in few engine
+calls (pairs are bucketed by shape; the reference only ever runs batch 1).
+
+Out of scope: wav <-> mel DSP (librosa STFT, Griffin-Lim).  If the caller
+supplies ``mel2wav`` it is applied to the denormalised mel exactly where the reference calls
+``melspectrogram2wav``; otherwise the waveform slot of the result is ``None``.
+"""
+import pickle
+from collections import defaultdict
+
+import torch
+
+from .model import AE
+from .utils import cc, local_device
+
+
+class Inferencer(object):
+    def __init__(self, config, args, mel2wav=None, lib=None):
+        self.config = config
+        self.args = args
+        self.mel2wav = mel2wav
+        self._lib = lib
+        self.build_model()
+        if getattr(args, "model", None):
+            self.load_model()
+        self.attr = None
+        if getattr(args, "attr", None):
+            with open(args.attr, "rb") as f:
+                self.attr = pickle.load(f)
+
+    def load_model(self):
+        dev = self.model.flat_parameters().device
+        self.model.load_state_dict(torch.load(f"{self.args.model}", map_location=dev))
+
+    def build_model(self):
+        self.model = AE(self.config, lib=self._lib) if self._lib is not None else cc(AE(self.config))
+        self.model.eval()
+
+    # ---- inference.py:54-60
+    def utt_make_frames(self, x):
+        frame_size = self.config["data_loader"]["frame_size"]
+        remains = x.size(0) % frame_size
+        if remains != 0:
+            x = torch.nn.functional.pad(x, (0, remains))
+        return x.view(1, x.size(0) // frame_size, frame_size * x.size(1)).transpose(1, 2)
+
+    def denormalize(self, x):
+        if self.attr is None:
+            return x
+        return x * self.attr["std"] + self.attr["mean"]
+
+    def normalize(self, x):
+        if self.attr is None:
+            return x
+        return (x - self.attr["mean"]) / self.attr["std"]
+
+    # ---- inference.py:62-70
+    def inference_one_utterance(self, x, x_cond):
+        """x: [T, M] source mel, x_cond: [T', M] target-speaker mel (normalised).  Returns (wav | None, mel [T'', M])."""
+        dev = self.model.flat_parameters().device
+        x = self.utt_make_frames(x.to(dev))
+        x_cond = self.utt_make_frames(x_cond.to(dev))
+        with torch.no_grad():
+            dec = self.model.inference(x, x_cond)
+        dec = dec.transpose(1, 2).squeeze(0).detach().cpu().numpy()
+        dec = self.denormalize(dec)
+        wav = self.mel2wav(dec) if self.mel2wav is not None else None
+        return wav, dec
+
+    def convert_batch(self, pairs):
+        """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T')
+        share one engine call.  Returns the converted mels ([T'',M] CPU tensors) in input order."""
+        dev = self.model.flat_parameters().device
+        buckets = defaultdict(list)
+        for i, (s, t) in enumerate(pairs):
+            buckets[(s.shape[0], t.shape[0])].append(i)
+        out = [None] * len(pairs)
+        with torch.no_grad():
+            for (_, _), idx in buckets.items():
+                xs = torch.stack([pairs[i][0] for i in idx]).to(dev).transpose(1, 2)   # [B, M, T] views, no copy
+                xc = torch.stack([pairs[i][1] for i in idx]).to(dev).transpose(1, 2)
+                dec = self.model.inference(xs, xc).transpose(1, 2).cpu()
+                for k, i in enumerate(idx):
+                    out[i] = dec[k]
+        return out

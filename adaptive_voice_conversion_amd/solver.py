@@ -58,6 +58,17 @@ class Solver(object):
     # ---- data (solver.py:57-68) ----------------------------------------------
     def get_data_loaders(self):
         d = self.args.data_dir
+        if getattr(self.args, "device_feed", False):
+            from .device_feed import DeviceSegmentFeed
+            rank, world = 0, 1
+            dd = _dist()
+            if dd is not None:
+                rank, world = dd.get_rank(), dd.get_world_size()
+            self.train_iter = DeviceSegmentFeed.from_files(
+                os.path.join(d, f"{self.args.train_set}.pkl"), os.path.join(d, self.args.train_index_file),
+                self.config["data_loader"]["segment_size"], self.config["data_loader"]["batch_size"], local_device(),
+                shuffle=self.config["data_loader"]["shuffle"], seed=rank)   # every rank draws its own shard order
+            return
         self.train_dataset = PickleDataset(os.path.join(d, f"{self.args.train_set}.pkl"),
                                            os.path.join(d, self.args.train_index_file),
                                            segment_size=self.config["data_loader"]["segment_size"])

@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--mode", choices=("train", "infer"), default="train",
+                    help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
@@ -185,6 +187,30 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if a.mode == "infer":
+        # BASELINE configs[3]: batched one-shot conversion AE.inference(x, x_cond) (model.py:387-391), forward only
+        xc = torch.randn(B, a.mels, T, generator=g).to(dev)
+        model = solver.model
+        plan_i, ws_i = model._plan(B, T, T, dev)
+        for _ in range(a.warmup):
+            plan_i.forward(model.flat_parameters(), x, xc, None, ws_i)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            plan_i.forward(model.flat_parameters(), x, xc, None, ws_i)
+        barrier()
+        el = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "utterances/sec one-shot conversion (AE.inference)", "value": world * B * a.steps / el,
+                              "unit": "utterances/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"BASELINE configs[3]: AE.inference, {a.mels}-mel x {T}-frame source and target, batch {B}/GPU, fp32"}}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     for _ in range(a.warmup):
         solver.ae_step(x, 1.0, eps=eps, sync=False)
