@@ -88,7 +88,8 @@ struct DenseLayer {
 struct DenseArgs {
     DenseLayer layer[AVC_DENSE_MAXL];
     int nlayers, B, C, Kmax, Wmax;
-    const float* in;    // forward: pooled [C][B]; backward: d(emb) [B][c_out]
+    const float* in;    // forward: pooled [C][B]; backward: d(emb) [c_out][B] channel-major
+    const float* in2;   // backward: optional upstream d(emb) [B][c_out] row-major, added to `in`
     float* emb;         // forward output [B][c_out]
     float* dpooled;     // backward output [C][B]
 };

@@ -58,3 +58,4 @@ struct ProfScope {
     hipStream_t s_;
 };
 int avc_launch_dense(const DenseArgs& a, int backward, hipStream_t s);
+int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);

@@ -430,7 +430,7 @@ long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
 // (global -> LDS round trip vs. ~1.3k MFMA cycles), so they take twice the channels per chunk
 int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) {
     int ck = avc_conv_ck(KS);
-    if (KS >= 4 && wgs <= 256) {
+    if (KS >= 4 && wgs <= 512) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
         int BN = (tile == 22) ? 128 : 64;
         ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
         if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;

@@ -84,35 +84,50 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
         }
     }
 
+    // fast-path pieces (statically indexed descriptors): issued one by one so that the main loop can
+    // place each LDS-DMA right behind a group of queued MFMAs
+    struct FastOrigin {
+        const float* dyb;
+        const float* xb;
+        int t0, v0;
+    };
+    auto fast_origin = [&](int chunk) {
+        FastOrigin o;
+        const int cb = chunk / a.chunks_per_sample;
+        o.t0 = (chunk - cb * a.chunks_per_sample) * 32;
+        o.dyb = a.dy.ptr + ((long)cb * a.dy.sb + (long)o.t0 * a.dy.st);
+        o.xb = a.x.ptr + (long)cb * a.x.sb;
+        o.v0 = o.t0 * a.stride - a.padL;
+        return o;
+    };
+    auto fast_dy_piece = [&](const FastOrigin& o, int i, int dyoi, float* dd) {
+        const int piece = wave + 4 * i;
+        if (piece * 64 < DYS && dyoi >= 0) {
+            const int f = piece * 64 + lane;
+            const int qcol = f - (f / WG_DYROW) * WG_DYROW;
+            if (o.t0 + qcol < a.Tout)
+                avc_glds4(o.dyb + dyoi, dd + piece * 64);
+            else
+                dd[f] = 0.f;
+        }
+    };
+    auto fast_x_piece = [&](const FastOrigin& o, int i, int xoi, int xqi, float* xd) {
+        const int piece = wave + 4 * i;
+        if (piece * 64 < XS && xoi >= 0) {
+            int r = avc_reflect(o.v0 + xqi, a.Tin);
+            if (r >= 0 && r < a.Tin) avc_glds4(o.xb + ((long)xoi + (long)r * a.x.st), xd + piece * 64);
+        }
+    };
+
     auto issue = [&](int chunk, int buf) {
         float* dd = dyT + buf * DYS;
         float* xd = xT + buf * XS;
         if (fastp) {
-            const int cb = chunk / a.chunks_per_sample;
-            const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
-            const float* dyb = a.dy.ptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);
-            const float* xb = a.x.ptr + (long)cb * a.x.sb;
-            const int v0 = t0 * a.stride - a.padL;
+            const FastOrigin o = fast_origin(chunk);
 #pragma unroll
-            for (int i = 0; i < NPD; ++i) {
-                const int piece = wave + 4 * i;
-                if (piece * 64 < DYS && dyo[i] >= 0) {
-                    const int f = piece * 64 + lane;
-                    const int qcol = f - (f / WG_DYROW) * WG_DYROW;
-                    if (t0 + qcol < a.Tout)
-                        avc_glds4(dyb + dyo[i], dd + piece * 64);
-                    else
-                        dd[f] = 0.f;
-                }
-            }
+            for (int i = 0; i < NPD; ++i) fast_dy_piece(o, i, dyo[i], dd);
 #pragma unroll
-            for (int i = 0; i < NPX; ++i) {
-                const int piece = wave + 4 * i;
-                if (piece * 64 < XS && xo[i] >= 0) {
-                    int r = avc_reflect(v0 + xq[i], a.Tin);
-                    if (r >= 0 && r < a.Tin) avc_glds4(xb + ((long)xo[i] + (long)r * a.x.st), xd + piece * 64);
-                }
-            }
+            for (int i = 0; i < NPX; ++i) fast_x_piece(o, i, xo[i], xq[i], xd);
             return;
         }
         int cb, t0;
@@ -161,7 +176,14 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     constexpr int CPT = 32 / TPR;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const int buf = (chunk - c_begin) & 1;
-        if (chunk + 1 < c_end) issue(chunk + 1, buf ^ 1);
+        const bool more = chunk + 1 < c_end;
+        // generic path: stage the next chunk up front; fast path: one slice of its DMAs behind each
+        // k-step's MFMAs (a DMA-only phase would leave the matrix pipe idle: one wave per SIMD here)
+        if (more && !fastp) issue(chunk + 1, buf ^ 1);
+        FastOrigin fo;
+        if (more && fastp) fo = fast_origin(chunk + 1);
+        float* ndd = dyT + (buf ^ 1) * DYS;
+        float* nxd = xT + (buf ^ 1) * XS;
         const float* arow = dyT + buf * DYS + (wave_m * 32 + li) * WG_DYROW;
         const float* brow = xT + buf * XS + (wave_n * NB * 32 + li) * XROW;
 #pragma unroll
@@ -175,6 +197,12 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
 #pragma unroll
                 for (int j = 0; j < KS; ++j)
                     acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nb * 32 * XROW + j], acc[nb * KS + j], 0, 0, 0);
+            if (more && fastp) {
+#pragma unroll
+                for (int i = s; i < NPD; i += 16) fast_dy_piece(fo, i, dyo[i], ndd);
+#pragma unroll
+                for (int i = s; i < NPX; i += 16) fast_x_piece(fo, i, xo[i], xq[i], nxd);
+            }
         }
         if (do_db) {
             const float* dr = dyT + buf * DYS + (tid / TPR) * WG_DYROW + (tid % TPR) * CPT;

@@ -122,11 +122,15 @@ __global__ void __launch_bounds__(AVC_THREADS) dense_stack_bwd_kernel(const Dens
     float* Hb = smem + a.Wmax;
     for (int e = tid; e < 3 * HB; e += AVC_THREADS) Hb[e] = 0.f;
     __syncthreads();
-    // input: d(emb) [B][c_out] row-major -> [c][n]
+    // input: d(emb) [c_out][B] channel-major (+ optional upstream [B][c_out]) -> [c][n]
     const int Co = a.layer[a.nlayers - 1].Cout;
     for (int e = tid; e < Co * DS_NS; e += AVC_THREADS) {
-        int n = e / Co, c = e - n * Co;
-        if (b0 + n < a.B) Hb[c * DS_NS + n] = a.in[(long)(b0 + n) * Co + c];
+        int c = e / DS_NS, n = e - c * DS_NS;
+        if (b0 + n < a.B) {
+            float v = a.in[(long)c * a.B + b0 + n];
+            if (a.in2) v += a.in2[(long)(b0 + n) * Co + c];
+            Hb[c * DS_NS + n] = v;
+        }
     }
     // buffer roles: X = gradient fed to the current layer (dz), G = dH carried along the residual path
     int xi = 0, gi = 1;

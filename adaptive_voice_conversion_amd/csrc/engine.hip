@@ -979,10 +979,30 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
         const LayerP& La = p->layers[d.affine];
         RUN(wgrad_layer(c, La, ws + p->emb, 0, 1, d.c.c_cond, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(La, ws, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B, ws + p->demb, 0, 1, d.c.c_cond);
-            if (d_emb_up) set_res(a, d_emb_up, AVC_RES_IDENTITY, 0, 1, d.c.c_cond, B);
-            RUN(avc_launch_conv(a, s, 0));
+        {
+            // d(emb)[i][b] = sum_o W[o][i] * dcond[b][o]: a 128 x B output with K = 2n*2C = 3072.  As a dgrad
+            // launch that is 8 workgroups walking 96 chunks one after the other (206 us on the critical
+            // path, measured); as a split-K GEMM through the weight-gradient kernel ("co" = i read from the
+            // packed forward image [i][o], "ci" = b read from dcond [b][o], "t" = o) it is ~50 workgroups.
+            WgradArgs w;
+            memset(&w, 0, sizeof(w));
+            w.x.ptr = ws + d.dcond; w.x.sb = 0; w.x.sc = csb; w.x.st = 1; w.x.ps = 1;
+            w.dy.ptr = ws + La.wpf; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
+            w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
+            w.KS = 1; w.padL = 0; w.stride = 1;
+            int nsplit;
+            avc_wgrad_plan(1, w.Cin, w.Cout, w.Tout, 1, &w.Tc, &w.spc, &w.chunks_per_sample, &w.total_chunks, &w.chunks_per_wg, &nsplit);
+            const long wsz = (long)w.Cout * w.Cin;
+            const long off = c.slab_used;
+            c.slab_used += ((long)nsplit * wsz + 63) / 64 * 64;
+            if (!dry) {
+                w.slab = ws + p->slab + off;
+                w.slab_stride = wsz;
+                w.dbslab = nullptr;
+                RUN(avc_launch_wgrad(w, nsplit, s));
+                RUN(avc_launch_reduce(w.slab, wsz, nsplit, (int)wsz, ws + p->demb, 1, s));  // demb: channel-major [c_cond][B]
+                if (d_emb_up) RUN(avc_launch_add_transposed(ws + p->demb, d_emb_up, B, d.c.c_cond, s));
+            }
         }
         // latent: KL term + reparameterisation (solver.py:86, model.py:384)
         if (!dry) {
@@ -1015,7 +1035,8 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             memset(&da, 0, sizeof(da));
             da.nlayers = 2 * e.nd + 1;
             da.B = B; da.C = C;
-            da.in = ws + p->demb;
+            da.in = ws + p->demb;      // [c_out][B] channel-major
+            da.in2 = nullptr;           // (upstream d_emb is already folded into demb above)
             da.dpooled = dhA;
             float* dzl[AVC_DENSE_MAXL];
             for (int l = 0; l < da.nlayers; ++l) {
@@ -1033,7 +1054,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
             }
             if (!dry) RUN(avc_launch_dense(da, 1, s));
-            RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, 1, e.c.c_out, 1, 1, B, B));
+            RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, B, 1, 1, 1, B, B));
             for (int l = e.nd - 1; l >= 0; --l) {
                 RUN(wgrad_layer(c, p->layers[e.dn2[l]], ws + e.d1[l], 0, B, 1, dzl[2 * l + 1], 0, B, 1, 1, 1, B, B));
                 RUN(wgrad_layer(c, p->layers[e.dn1[l]], ws + e.hd[l], 0, B, 1, dzl[2 * l], 0, B, 1, 1, 1, B, B));

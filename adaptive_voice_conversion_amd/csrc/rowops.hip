@@ -310,6 +310,14 @@ copy_rows_kernel(const float* x, long sxb, long sxc, int sxt, int B, int M, int 
     }
 }
 
+// dst[c][b] += src[b][c]   (upstream d(emb) of the autograd seam joins the channel-major gradient)
+__global__ void __launch_bounds__(AVC_THREADS) add_transposed_kernel(float* dst, const float* src, int B, int C) {
+    int e = blockIdx.x * AVC_THREADS + threadIdx.x;
+    if (e >= B * C) return;
+    int c = e / B, b = e - c * B;
+    dst[e] += src[(long)b * C + c];
+}
+
 // AdaptiveAvgPool1d(1) (model.py:273): in [B,C,T] -> out[c*B + b]  (channel-major for the dense stack)
 __global__ void __launch_bounds__(AVC_THREADS) timepool_fwd_kernel(const float* in, int B, int C, int T, float* out) {
     int r = blockIdx.x * AVC_THREADS + threadIdx.x;
@@ -562,6 +570,11 @@ int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int
     ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_blocks((long)B * M * T)), dim3(AVC_THREADS), 0, s, x, sxb, sxc, sxt, B,
                        M, T, dst, db, dc);
+    return (int)hipGetLastError();
+}
+int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
+    hipLaunchKernelGGL(add_transposed_kernel, dim3(avc_cdiv(B * C, AVC_THREADS)), dim3(AVC_THREADS), 0, s, dst, src, B, C);
     return (int)hipGetLastError();
 }
 int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hipStream_t s) {

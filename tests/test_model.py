@@ -153,3 +153,24 @@ def test_gpu_training_curve_tracks_oracle():
         first = first or meta["loss_rec"]
         last = meta["loss_rec"]
     assert last < first
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_autograd_seam_with_direct_embedding_and_latent_losses(kind):
+    """Upstream gradients on every output (dec, mu, log_sigma AND emb) through the autograd seam."""
+    cfg = O.tiny_config()
+    sd = O.make_state_dict(cfg, 5)
+    x, eps = O.make_inputs(cfg, 2, 32, 5)
+    ae, dev, lib = make_ae(kind, cfg)
+    ae.load_state_dict(sd)
+    mu, ls, emb, dec = ae(x.to(dev), eps=eps.to(dev))
+    loss = (dec ** 2).mean() + 3.0 * (emb ** 2).sum() + (mu * ls).mean()
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    omu, ols, oemb, odec = O.ae_forward(x, eps, leaves, cfg)
+    oloss = (odec ** 2).mean() + 3.0 * (oemb ** 2).sum() + (omu * ols).mean()
+    grads = torch.autograd.grad(oloss, list(leaves.values()), allow_unused=True)
+    for (k, p), g in zip(ae.named_parameters(), grads):
+        g = torch.zeros_like(p.grad.cpu()) if g is None else g
+        d, e = g.norm().item(), (p.grad.cpu() - g).norm().item()
+        assert e <= 2e-4 * d + 2e-6, (k, e, d)
