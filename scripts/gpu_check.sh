@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 for what in "$@"; do
   case $what in
     tests)
-      for f in test_ops_rowops test_ops_conv test_engine test_model; do
+      for f in test_ops_rowops test_ops_conv test_engine test_model test_feed_infer; do
         timeout 900 python -m pytest tests/$f.py -m gpu -q --timeout 300 -s 2>&1 | tail -80 > $OUT/$f.log
         tail -2 $OUT/$f.log
       done
