@@ -7,6 +7,7 @@
 
 #define AVC_MAX_GROUPS 8
 #define AVC_THREADS 256
+#define AVC_WGRAD_MAXG 16
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +54,7 @@ struct ConvArgs {
     long rb, rc;
     int rt, Tres;
     int ngroups;
+    int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     ConvGroup g[AVC_MAX_GROUPS];
 };
 
@@ -66,6 +68,13 @@ struct WgradArgs {
     float* dbslab; // [nsplit][Cout] partial bias sums (may be null)
     long slab_stride, db_stride;
     int wrow0;     // row offset (bank/grouped layers write a sub-block)
+    int dbg;       // ablation switches of the micro-benchmarks (0 in the product path)
+    // grouped launch (ngroups > 1): blockIdx.z selects the operand pair of one of several layers of
+    // identical geometry (the speaker encoder's Linear stack); slab/dbslab advance by the group strides
+    int ngroups;
+    long gslab_stride, gdb_stride;
+    const float* gx[AVC_WGRAD_MAXG];
+    const float* gdy[AVC_WGRAD_MAXG];
 };
 
 struct ReduceSeg {
@@ -152,6 +161,14 @@ static __device__ __forceinline__ void avc_glds16(const float* gsrc, float* lds_
 
 static __device__ __forceinline__ void avc_glds4(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// same, dword, with a wave-uniform base and a per-lane unsigned BYTE offset: selects the SADDR form
+// (global_load_lds_dword voff, s[base:base+1]) -- no 64-bit address arithmetic per lane
+static __device__ __forceinline__ void avc_glds4_s(const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
+    const char* p = (const char*)sbase + voff_bytes;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 

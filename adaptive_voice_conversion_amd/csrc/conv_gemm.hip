@@ -23,6 +23,7 @@
 // residual join (identity / ceil-mode avg-pool / their adjoints) and the ReLU
 // mask of the backward pass.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -309,17 +310,18 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
     const int a_lane = wave_m * (32 * WM) + li;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = (chunk + 1 < nchunk);
-        if (more) {
+        if (more && !((a.dbg & 1) && chunk >= 1)) {
             load_a(chunk + 1, (chunk + 1) & 1);  // both land while this chunk is multiplied; drained at the barrier
             load_x(chunk + 1, (chunk + 1) & 1);
         }
         const float* Ab = As + (chunk & 1) * AS;
         const float* Xb = Xs + (chunk & 1) * XS;
-        if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
+        if (a.dbg & 2) {
+        } else if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
             conv_chunk_mma<WM, WN, true, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else
             conv_chunk_mma<WM, WN, false, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-        __syncthreads();
+        if (!(a.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue
@@ -456,7 +458,12 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
 }
 
 // returns 0 on success, negative on unsupported geometry
-int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile) {
+int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
+    ConvArgs a = a_in;
+    {
+        const char* e = getenv("AVC_CONV_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
     if (a.Mp % 128 != 0) return -2;
     for (int gi = 0; gi < a.ngroups; ++gi)

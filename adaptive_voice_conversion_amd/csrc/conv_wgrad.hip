@@ -14,6 +14,7 @@
 #include "avc_internal.h"
 
 #define WG_DYROW 33
+#define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue)
 
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
@@ -24,112 +25,125 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // <5,1,2> is the 64x64 tile of the k=5 layers; WCO=4 (128co x 32ci) suits Cin that is not a multiple
 // of 64 (the 80-mel bank convs); <1,4,4> (128co x 128ci) gives the 1x1 convs / Linears four
 // accumulators per wave, i.e. the arithmetic intensity per staged element that the taps give k=5.
+//
+// Warp-specialised: with ~80 accumulator registers per wave the kernel runs one MFMA wave per SIMD,
+// and a wave issues in order -- every DMA address computation or exposed LDS round trip inside the
+// k-loop is matrix-pipe idle time (measured: 62 % MFMA duty even with DMA and barriers removed).
+// So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
+// issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
 template <int KS, int NB, int WCO>
-__global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int WCI = 4 / WCO;            // waves along ci
     constexpr int TCO = 32 * WCO;           // co rows per workgroup
     constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
     constexpr int NACC = KS * NB;
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;   // consumer: tile position; producer: which pieces of a chunk it stages
+    const int ptid = tid & 255;   // thread index inside its role group
     const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
     const int ci_tiles = avc_cdiv(a.Cin, TCI);
     const int co0 = (blockIdx.x / ci_tiles) * TCO, ci0 = (blockIdx.x % ci_tiles) * TCI;
     const int z = blockIdx.y;
+    const float* xptr = a.x.ptr;
+    const float* dyptr = a.dy.ptr;
+    float* slabp = a.slab;
+    float* dbp = a.dbslab;
+    if (a.ngroups > 1) {
+        const int g = blockIdx.z;
+        xptr = a.gx[g];
+        dyptr = a.gdy[g];
+        slabp += (long)g * a.gslab_stride;
+        if (dbp) dbp += (long)g * a.gdb_stride;
+    }
     const int Tc = a.Tc, spc = a.spc;
     const int lgTc = 31 - __builtin_clz(Tc);
     const int XSEG = (Tc - 1) * a.stride + KS;
     const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
     const int DYS = TCO * WG_DYROW, XS = TCI * XROW;
-    float* dyT = smem;            // [2][TCO][WG_DYROW]
-    float* xT = smem + 2 * DYS;   // [2][TCI][XROW]
-    const bool do_db = (a.dbslab != nullptr) && (ci0 == 0);
+    const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
+    float* dyT = smem;             // [2][TCO][WG_DYROW]
+    float* xT = smem + 2 * DYSP;   // [2][TCI][XROW]
+    const bool do_db = (dbp != nullptr) && (ci0 == 0);
     const float inv_xrow = 1.0f / (float)XROW;
 
-    f32x16 acc[NACC];
-#pragma unroll
-    for (int j = 0; j < NACC; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float dbsum = 0.f;
 
     // Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
     // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1
-    // lands while chunk c multiplies.  Both stages are zero-filled once; afterwards only elements
-    // that exist are ever written, dy columns past the end of a sample are re-zeroed, and x
-    // elements that no valid dy column multiplies may keep stale (finite) data.
-    for (int e = tid; e < 2 * (DYS + XS); e += AVC_THREADS) smem[e] = 0.f;
+    // lands while chunk c multiplies.  Both stages are zero-filled once.
+    for (int e = tid; e < 2 * (DYSP + XSP); e += WG_THREADS) smem[e] = 0.f;
 
-    // chunk-invariant part of every lane's DMA descriptors (fast path: one sample per chunk)
+    // Fast path (one sample per chunk, whole chunks): every lane of every DMA piece always loads --
+    // LDS positions that hold no tile element (row padding, rows past Cout / Cin) get a clamped,
+    // valid address instead of an exec-masked branch; they are never read, or feed accumulator rows
+    // that are never stored.  The chunk-invariant byte offsets live in producer registers, the
+    // chunk origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
     constexpr int NPD = (TCO * WG_DYROW + 255) / 256;  // dy pieces per wave
     constexpr int NPX = (TCI * (KS == 1 ? 33 : 71) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
-    const bool fastp = (spc == 1) && (XS <= NPX * 256);
-    int dyo[NPD], xo[NPX], xq[NPX];
-    if (fastp) {
+    const bool fastp = (spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256);
+    unsigned dyo[NPD], xo[NPX];
+    int xq[NPX];
+    if (fastp && producer) {
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
-            int f = (wave + 4 * i) * 64 + lane;
+            const int f = (wave + 4 * i) * 64 + lane;
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            bool ok = f < DYS && qcol < 32 && (co0 + row) < a.Cout;
-            dyo[i] = ok ? (int)(src_chan_off(a.dy, co0 + row) + (long)qcol * a.dy.st) : -1;
+            row = row < TCO ? row : TCO - 1;
+            qcol = qcol < 32 ? qcol : 31;
+            int co = co0 + row;
+            co = co < a.Cout ? co : a.Cout - 1;
+            dyo[i] = 4u * (unsigned)(src_chan_off(a.dy, co) + (long)qcol * a.dy.st);
         }
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            int f = (wave + 4 * i) * 64 + lane;
+            const int f = (wave + 4 * i) * 64 + lane;
             int row = avc_fastdiv(f, XROW, inv_xrow), p = f - row * XROW;
-            bool ok = f < XS && p < XSEG && (ci0 + row) < a.Cin;
-            xo[i] = ok ? (int)src_chan_off(a.x, ci0 + row) : -1;
+            row = row < TCI ? row : TCI - 1;
+            p = p < XSEG ? p : XSEG - 1;
+            int ci = ci0 + row;
+            ci = ci < a.Cin ? ci : a.Cin - 1;
+            xo[i] = 4u * (unsigned)src_chan_off(a.x, ci);
             xq[i] = p;
         }
     }
-
-    // fast-path pieces (statically indexed descriptors): issued one by one so that the main loop can
-    // place each LDS-DMA right behind a group of queued MFMAs
-    struct FastOrigin {
-        const float* dyb;
-        const float* xb;
-        int t0, v0;
-    };
-    auto fast_origin = [&](int chunk) {
-        FastOrigin o;
+    auto issue_fast = [&](int chunk, int buf) {
+        float* dd = dyT + buf * DYSP;
+        float* xd = xT + buf * XSP;
         const int cb = chunk / a.chunks_per_sample;
-        o.t0 = (chunk - cb * a.chunks_per_sample) * 32;
-        o.dyb = a.dy.ptr + ((long)cb * a.dy.sb + (long)o.t0 * a.dy.st);
-        o.xb = a.x.ptr + (long)cb * a.x.sb;
-        o.v0 = o.t0 * a.stride - a.padL;
-        return o;
-    };
-    auto fast_dy_piece = [&](const FastOrigin& o, int i, int dyoi, float* dd) {
-        const int piece = wave + 4 * i;
-        if (piece * 64 < DYS && dyoi >= 0) {
-            const int f = piece * 64 + lane;
-            const int qcol = f - (f / WG_DYROW) * WG_DYROW;
-            if (o.t0 + qcol < a.Tout)
-                avc_glds4(o.dyb + dyoi, dd + piece * 64);
-            else
-                dd[f] = 0.f;
-        }
-    };
-    auto fast_x_piece = [&](const FastOrigin& o, int i, int xoi, int xqi, float* xd) {
-        const int piece = wave + 4 * i;
-        if (piece * 64 < XS && xoi >= 0) {
-            int r = avc_reflect(o.v0 + xqi, a.Tin);
-            if (r >= 0 && r < a.Tin) avc_glds4(o.xb + ((long)xoi + (long)r * a.x.st), xd + piece * 64);
+        const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
+        const float* dyb = dyptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);
+        const float* xb = xptr + (long)cb * a.x.sb;
+        const int v0 = t0 * a.stride - a.padL;
+        const unsigned st4 = 4u * (unsigned)a.x.st;
+#pragma unroll
+        for (int i = 0; i < NPD; ++i)
+            if ((wave + 4 * i) * 64 < DYSP) avc_glds4_s(dyb, dyo[i], dd + (wave + 4 * i) * 64);
+        if (v0 >= 0 && v0 + XSEG <= a.Tin) {  // interior chunk: no reflection anywhere in the tile
+            const float* xbv = xb + (long)v0 * a.x.st;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i)
+                if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xbv, xo[i] + (unsigned)xq[i] * st4, xd + (wave + 4 * i) * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPX; ++i)
+                if ((wave + 4 * i) * 64 < XSP) {
+                    int r = avc_reflect(v0 + xq[i], a.Tin);
+                    r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);  // (only positions no valid dy column multiplies)
+                    avc_glds4_s(xb, xo[i] + (unsigned)r * st4, xd + (wave + 4 * i) * 64);
+                }
         }
     };
 
     auto issue = [&](int chunk, int buf) {
-        float* dd = dyT + buf * DYS;
-        float* xd = xT + buf * XS;
         if (fastp) {
-            const FastOrigin o = fast_origin(chunk);
-#pragma unroll
-            for (int i = 0; i < NPD; ++i) fast_dy_piece(o, i, dyo[i], dd);
-#pragma unroll
-            for (int i = 0; i < NPX; ++i) fast_x_piece(o, i, xo[i], xq[i], xd);
+            issue_fast(chunk, buf);
             return;
         }
+        float* dd = dyT + buf * DYSP;
+        float* xd = xT + buf * XSP;
         int cb, t0;
         if (spc == 1) {
             cb = chunk / a.chunks_per_sample;
@@ -145,7 +159,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
                 int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
                 int b = cb + sl, t = t0 + tl, co = co0 + row;
                 if (b < a.B && t < a.Tout && co < a.Cout)
-                    avc_glds4(a.dy.ptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
+                    avc_glds4(dyptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
                 else
                     dd[f] = 0.f;
             }
@@ -158,7 +172,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
                 int b = cb + sl, ci = ci0 + row;
                 int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
                 if (sl < spc && b < a.B && ci < a.Cin && r >= 0 && r < a.Tin)
-                    avc_glds4(a.x.ptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
+                    avc_glds4(xptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
                 else
                     xd[f] = 0.f;
             }
@@ -170,52 +184,76 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
     if (c_end > a.total_chunks) c_end = a.total_chunks;
 
     __syncthreads();  // zero fill complete before the first DMA lands
-    if (c_begin < c_end) issue(c_begin, 0);
+    if (producer && c_begin < c_end) issue(c_begin, 0);
     __syncthreads();
-    constexpr int TPR = AVC_THREADS / TCO;  // threads per dy row in the bias-gradient partial sum
+    constexpr int TPR = 256 / TCO;  // producer threads per dy row in the bias-gradient partial sum
     constexpr int CPT = 32 / TPR;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const int buf = (chunk - c_begin) & 1;
-        const bool more = chunk + 1 < c_end;
-        // generic path: stage the next chunk up front; fast path: one slice of its DMAs behind each
-        // k-step's MFMAs (a DMA-only phase would leave the matrix pipe idle: one wave per SIMD here)
-        if (more && !fastp) issue(chunk + 1, buf ^ 1);
-        FastOrigin fo;
-        if (more && fastp) fo = fast_origin(chunk + 1);
-        float* ndd = dyT + (buf ^ 1) * DYS;
-        float* nxd = xT + (buf ^ 1) * XS;
-        const float* arow = dyT + buf * DYS + (wave_m * 32 + li) * WG_DYROW;
-        const float* brow = xT + buf * XS + (wave_n * NB * 32 + li) * XROW;
+    // The two roles run separate loops that meet at one s_barrier per chunk (the barrier counts wave
+    // arrivals, not call sites).  Producer side of the barrier: the next stage has landed (the DMA is
+    // drained by the s_waitcnt in front of it); consumer side: the current stage is free again.
+    if (producer) {
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const int buf = (chunk - c_begin) & 1;
+            const bool more = (chunk + 1 < c_end) && !((a.dbg & 1) && chunk > c_begin);
+            if (more) issue(chunk + 1, buf ^ 1);
+            if (do_db) {
+                const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            int qcol = 2 * s + h;
-            int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
-            float av = arow[qcol];
-            const float* bp = brow + sl * XSEG + tl * a.stride;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int j = 0; j < KS; ++j)
-                    acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nb * 32 * XROW + j], acc[nb * KS + j], 0, 0, 0);
-            if (more && fastp) {
-#pragma unroll
-                for (int i = s; i < NPD; i += 16) fast_dy_piece(fo, i, dyo[i], ndd);
-#pragma unroll
-                for (int i = s; i < NPX; i += 16) fast_x_piece(fo, i, xo[i], xq[i], nxd);
+                for (int k = 0; k < CPT; ++k) dbsum += dr[k];
             }
+            if (!(a.dbg & 4)) __syncthreads();
         }
         if (do_db) {
-            const float* dr = dyT + buf * DYS + (tid / TPR) * WG_DYROW + (tid % TPR) * CPT;
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) dbsum += dr[k];
+            for (int o = 1; o < TPR; o <<= 1) dbsum += __shfl_xor(dbsum, o);
+            int co = co0 + ptid / TPR;
+            if ((ptid % TPR) == 0 && co < a.Cout) dbp[(long)z * a.db_stride + co] = dbsum;
         }
-        __syncthreads();  // next stage landed (the DMA is drained before the barrier), this one is free
+        return;
+    }
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const int buf = (chunk - c_begin) & 1;
+        if (!(a.dbg & 2)) {
+            const float* arow = dyT + buf * DYSP + (wave_m * 32 + li) * WG_DYROW;
+            const float* brow = xT + buf * XSP + (wave_n * NB * 32 + li) * XROW;
+            auto ldfrag = [&](int s, float& av, float (&bv)[NACC]) {
+                const int qcol = 2 * s + h;
+                const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
+                av = arow[qcol];
+                const float* bp = brow + sl * XSEG + tl * a.stride;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
+            };
+            // fragments of k-step s+1 are requested before the MFMAs of step s are queued
+            float av[2], bv[2][NACC];
+            ldfrag(0, av[0], bv[0]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int cur = s & 1;
+                if (s + 1 < 16) ldfrag(s + 1, av[cur ^ 1], bv[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);  // reads stay in front of the MFMAs they overlap with ...
+#pragma unroll
+                for (int k = 0; k < NACC; ++k)
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][k], acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
+            }
+        }
+        if (!(a.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: partial tile -> slab[z][tap][co][ci]  (tap-major: the 32 lanes of a half-wave
     // hold 32 consecutive ci of one (tap, co) row -> 128-byte coalesced stores; the reduce kernel
     // restores the [co][ci][tap] parameter layout)
-    float* slab = a.slab + (long)z * a.slab_stride;
+    float* slab = slabp + (long)z * a.slab_stride;
+    if (!(a.dbg & 8))
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int ci = ci0 + (wave_n * NB + nb) * 32 + li;
@@ -227,12 +265,6 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_wgrad_kernel(const WgradArgs
                 for (int j = 0; j < KS; ++j) slab[((long)j * a.Cout + co) * a.Cin + ci] = acc[nb * KS + j][r];
             }
         }
-    }
-    if (do_db) {
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) dbsum += __shfl_xor(dbsum, o);
-        int co = co0 + tid / TPR;
-        if ((tid % TPR) == 0 && co < a.Cout) a.dbslab[(long)z * a.db_stride + co] = dbsum;
     }
 }
 
@@ -315,11 +347,12 @@ static int launch_wgrad_t(const WgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
     int XSEG = (a.Tc - 1) * a.stride + KS;
     int XROW = (a.spc * XSEG) | 1;
-    size_t lds = (size_t)2 * (TCO * WG_DYROW + TCI * XROW) * 4 + 16;
+    size_t lds = (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 16;
     if (lds > 158 * 1024) return -3;
-    dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit);
-    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO>), grid, dim3(AVC_THREADS), lds, stream, a);
+    const int ng = a.ngroups > 1 ? a.ngroups : 1;
+    dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit, ng);
+    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * ng * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO>), grid, dim3(WG_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -328,8 +361,13 @@ static int launch_wgrad_ks(const WgradArgs& a, int nsplit, int WCO, hipStream_t 
     return WCO == 4 ? launch_wgrad_t<KS, 1, 4>(a, nsplit, stream) : launch_wgrad_t<KS, 1, 2>(a, nsplit, stream);
 }
 
-int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
-    if (a.KS < 1 || a.KS > 8) return -1;
+int avc_launch_wgrad(const WgradArgs& a_in, int nsplit, hipStream_t stream) {
+    WgradArgs a = a_in;
+    {
+        const char* e = getenv("AVC_WGRAD_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
+    if (a.KS < 1 || a.KS > 8 || a.ngroups > AVC_WGRAD_MAXG) return -1;
     if (a.padL >= a.Tin) return -6;
     int NB, WCO;
     wgrad_shape(a.Cin, a.Cout, a.KS, &NB, &WCO);

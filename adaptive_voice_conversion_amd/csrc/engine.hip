@@ -682,6 +682,81 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     return 0;
 }
 
+// Weight gradients of several Linear layers of identical geometry on [C][B] channel-major operands
+// (the speaker encoder's dense stack) as ONE grouped launch: alone each is a 2-workgroup kernel whose
+// ~25 us are launch + pipeline latency.
+static int wgrad_dense_group(BwdCtx& c, const LayerP* const* Ls, const float* const* xs, const float* const* dys, int n, int Bn) {
+    int i = 0;
+    while (i < n) {
+        int m = 1;
+        while (i + m < n && m < AVC_WGRAD_MAXG && Ls[i + m]->Cin == Ls[i]->Cin && Ls[i + m]->Cout == Ls[i]->Cout &&
+               Ls[i + m]->KS == 1 && Ls[i]->KS == 1 && Ls[i + m]->nsrc == 1 && Ls[i]->nsrc == 1)
+            ++m;
+        const LayerP& L = *Ls[i];
+        if (m == 1) {
+            int rc = wgrad_layer(c, L, xs[i], 0, Bn, 1, dys[i], 0, Bn, 1, 1, 1, Bn, Bn);
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x.ptr = xs[i]; a.x.sb = 0; a.x.sc = Bn; a.x.st = 1; a.x.ps = 1;
+        a.dy.ptr = dys[i]; a.dy.sb = 0; a.dy.sc = Bn; a.dy.st = 1; a.dy.ps = 1;
+        a.B = 1; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Bn; a.Tout = Bn;
+        a.KS = 1; a.padL = 0; a.stride = 1;
+        int nsplit;
+        avc_wgrad_plan(1, L.Cin, L.Cout, Bn, 1, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+        const long wsz = (long)L.Cout * L.Cin;
+        const long per = ((long)nsplit * (wsz + L.Cout) + 63) / 64 * 64;
+        const long off = c.slab_used;
+        c.slab_used += per * m;
+        if (!c.dry) {
+            a.slab = c.ws + c.p->slab + off;
+            a.slab_stride = wsz;
+            a.dbslab = a.slab + (long)nsplit * wsz;
+            a.db_stride = L.Cout;
+            a.ngroups = m;
+            a.gslab_stride = per;
+            a.gdb_stride = per;
+            for (int g = 0; g < m; ++g) {
+                a.gx[g] = xs[i + g];
+                a.gdy[g] = dys[i + g];
+            }
+            hipStream_t ls = c.s;
+            if (c.wstream != c.s && c.nev < AVC_MAX_WEV) {
+                hipEvent_t e = c.p->wev[c.nev++];
+                hipEventRecord(e, c.s);
+                hipStreamWaitEvent(c.wstream, e, 0);
+                ls = c.wstream;
+            }
+            int rc = avc_launch_wgrad(a, nsplit, ls);
+            if (rc) return rc;
+            for (int g = 0; g < m; ++g) {
+                const LayerP& Lg = *Ls[i + g];
+                ReduceSeg w;
+                w.slab = a.slab + (long)g * per;
+                w.dst = c.grads + c.p->params[Lg.w[0]].off;
+                w.stride = wsz;
+                w.n = (int)wsz;
+                w.nsplit = nsplit;
+                w.KS = 1;
+                ReduceSeg b;
+                b.slab = a.dbslab + (long)g * per;
+                b.dst = c.grads + c.p->params[Lg.b[0]].off;
+                b.stride = L.Cout;
+                b.n = L.Cout;
+                b.nsplit = nsplit;
+                b.KS = 1;
+                c.red.segs.push_back(w);
+                c.red.segs.push_back(b);
+            }
+        }
+        i += m;
+    }
+    return 0;
+}
+
 static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, float* ws, std::vector<PackArgs>& out) {
     PackArgs a;
     memset(&a, 0, sizeof(a));
@@ -1054,11 +1129,16 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
             }
             if (!dry) RUN(avc_launch_dense(da, 1, s));
-            RUN(wgrad_layer(c, Lo, ws + e.hd[e.nd], 0, B, 1, ws + p->demb, 0, B, 1, 1, 1, B, B));
+            const LayerP* gl[AVC_DENSE_MAXL];
+            const float* gx[AVC_DENSE_MAXL];
+            const float* gdy[AVC_DENSE_MAXL];
+            int ng = 0;
+            gl[ng] = &Lo; gx[ng] = ws + e.hd[e.nd]; gdy[ng] = ws + p->demb; ++ng;
             for (int l = e.nd - 1; l >= 0; --l) {
-                RUN(wgrad_layer(c, p->layers[e.dn2[l]], ws + e.d1[l], 0, B, 1, dzl[2 * l + 1], 0, B, 1, 1, 1, B, B));
-                RUN(wgrad_layer(c, p->layers[e.dn1[l]], ws + e.hd[l], 0, B, 1, dzl[2 * l], 0, B, 1, 1, 1, B, B));
+                gl[ng] = &p->layers[e.dn2[l]]; gx[ng] = ws + e.d1[l]; gdy[ng] = dzl[2 * l + 1]; ++ng;
+                gl[ng] = &p->layers[e.dn1[l]]; gx[ng] = ws + e.hd[l]; gdy[ng] = dzl[2 * l]; ++ng;
             }
+            RUN(wgrad_dense_group(c, gl, gx, gdy, ng, B));
         }
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
