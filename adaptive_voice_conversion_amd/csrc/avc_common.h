@@ -172,6 +172,12 @@ static __device__ __forceinline__ void avc_glds4_s(const float* sbase, unsigned 
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
+static __device__ __forceinline__ void avc_glds16_s(const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
+    const char* p = (const char*)sbase + voff_bytes;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // f / d for 0 <= f < 2^22 with a precomputed float reciprocal (one fix-up step; integer division
 // by a run-time divisor costs ~25 instructions on gfx950, this costs ~6)
 static __device__ __forceinline__ int avc_fastdiv(int f, int d, float inv_d) {

@@ -325,6 +325,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
     }
 
     // ---- epilogue
+    if (a.dbg & 8) return;
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         if (!colv[wn]) continue;
@@ -424,7 +425,7 @@ int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {
     return 22;
 }
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
-    int BM = (tile == 11) ? 64 : 128, BN = (tile == 22) ? 128 : 64;
+    int BM = (tile / 10 == 1) ? 64 : 128, BN = (tile % 10 == 1) ? 64 : 128;
     long ntn = Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout);
     return (long)(Mp / BM) * ntn * ngroups;
 }
@@ -433,7 +434,7 @@ long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
 int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) {
     int ck = avc_conv_ck(KS);
     if (KS >= 4 && wgs <= 512) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
-        int BN = (tile == 22) ? 128 : 64;
+        int BN = (tile % 10 == 1) ? 64 : 128;
         ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
         if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;
     }
@@ -470,8 +471,8 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
     int tile = force_tile;
     if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups);
-    int BM = (tile == 11) ? 64 : 128;
-    int BN = (tile == 22) ? 128 : 64;
+    int BM = (tile / 10 == 1) ? 64 : 128;
+    int BN = (tile % 10 == 1) ? 64 : 128;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         if (a.g[gi].CK % 8 != 0) return -2;
@@ -497,6 +498,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
         else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0>), grid, block, lds, stream, a);                  \
     } while (0)
     if (tile == 22) AVC_LAUNCH_CONV(2, 2);
+    else if (tile == 12) AVC_LAUNCH_CONV(1, 2);
     else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
     else AVC_LAUNCH_CONV(1, 1);
 #undef AVC_LAUNCH_CONV

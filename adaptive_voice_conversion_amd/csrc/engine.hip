@@ -110,6 +110,7 @@ struct avc_plan {
     mutable hipStream_t wstream[2] = {nullptr, nullptr};
     mutable hipEvent_t wev[AVC_MAX_WEV];
     mutable hipEvent_t wjoin[2];
+    mutable hipEvent_t ev_pack[2];
     long dyarena = -1, dyarena_floats = 0;
 
     long alloc(long n) {
@@ -467,6 +468,7 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
         for (int i = 0; i < 2; ++i) {
             hipStreamDestroy(p->wstream[i]);
             hipEventDestroy(p->wjoin[i]);
+            hipEventDestroy(p->ev_pack[i]);
         }
         for (int i = 0; i < AVC_MAX_WEV; ++i) hipEventDestroy(p->wev[i]);
     }
@@ -492,6 +494,7 @@ static bool side_ready(const avc_plan* p) {
             for (int i = 0; i < 2; ++i) {
                 ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
                 ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&p->ev_pack[i], hipEventDisableTiming) == hipSuccess;
             }
             for (int i = 0; i < AVC_MAX_WEV; ++i) ok = ok && hipEventCreateWithFlags(&p->wev[i], hipEventDisableTiming) == hipSuccess;
             p->side_state = ok ? 1 : -1;
@@ -597,11 +600,11 @@ struct Reducer {
     std::vector<ReduceSeg> segs;
     hipStream_t s;
     bool dry;
-    int flush() {
+    int flush(hipStream_t st) {
         for (size_t i = 0; i < segs.size(); i += 16) {
             int n = (int)std::min<size_t>(16, segs.size() - i);
             if (!dry) {
-                int rc = avc_launch_reduce_segs(&segs[i], n, s);
+                int rc = avc_launch_reduce_segs(&segs[i], n, st);
                 if (rc) return rc;
             }
         }
@@ -629,6 +632,18 @@ struct BwdCtx {
         return dry ? nullptr : ws + p->dyarena + off;
     }
 };
+
+// Slab reduces of the weight gradients launched so far in this branch: queued on the branch's wgrad
+// stream right behind the kernels that fill the slabs, so they run under the other branches' work
+// instead of as a serial tail in front of the optimizer.
+static int flush_reduces(BwdCtx& c) {
+    if (!c.dry && c.wstream != c.s && c.nev < AVC_MAX_WEV) {  // (a wgrad that ran out of events was launched on c.s)
+        hipEvent_t e = c.p->wev[c.nev++];
+        hipEventRecord(e, c.s);
+        hipStreamWaitEvent(c.wstream, e, 0);
+    }
+    return c.red.flush(c.dry ? c.s : c.wstream);
+}
 
 // weight + bias gradient of layer L: x = forward input view, dy = output-gradient view
 static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, long xsc, int xst, const float* dy, long ysb,
@@ -834,10 +849,27 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
                         const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
     const int B = p->B;
     // 0. weights -> LDS-image order (they change every optimizer step)
+    // The conv banks and in_convs open both encoder branches and run for ~1 ms: only their images
+    // are packed up front; the rest is packed on a (forward-idle) wgrad stream under the bank convs.
+    bool pack_async = false;
     {
-        std::vector<PackArgs> packs;
-        for (const LayerP& L : p->layers) pack_layer(p, L, params, ws, packs);
-        RUN(avc_launch_pack_batch(packs.data(), (int)packs.size(), s));
+        std::vector<char> early(p->layers.size(), 0);
+        for (const EncNet* e : {&p->spk, &p->enc}) {
+            for (int g = 0; g < e->nb; ++g) early[e->bank[g]] = 1;
+            early[e->in_conv] = 1;
+        }
+        std::vector<PackArgs> first, rest;
+        for (size_t i = 0; i < p->layers.size(); ++i) pack_layer(p, p->layers[i], params, ws, early[i] ? first : rest);
+        RUN(avc_launch_pack_batch(first.data(), (int)first.size(), s));
+        pack_async = side_ready(p) && !rest.empty();
+        hipStream_t ps = s;
+        if (pack_async) {
+            ps = p->wstream[0];
+            hipEventRecord(p->ev_pack[0], s);  // parameters are final (the optimizer ran on s)
+            hipStreamWaitEvent(ps, p->ev_pack[0], 0);
+        }
+        if (!rest.empty()) RUN(avc_launch_pack_batch(rest.data(), (int)rest.size(), ps));
+        if (pack_async) hipEventRecord(p->ev_pack[1], ps);
     }
 
     // ---------------- speaker encoder (model.py:265-277), concurrent with the content encoder
@@ -853,6 +885,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             ConvArgs a = mk_fwd(p, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
             RUN(avc_launch_conv(a, s, 0));
         }
+        if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
@@ -900,6 +933,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             RUN(avc_launch_conv(a, s, 0));
             RUN(in_fwd(ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
         }
+        if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
@@ -1084,6 +1118,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             float lk = lambda_kl / (float)((long)B * Cz * Tb);
             RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Cz, Tb, lk, ws + p->dmuls, s));
         }
+        RUN(flush_reduces(c));  // decoder gradients are complete
     }
 
     // ---------------- speaker encoder (side stream, own temporaries: concurrent with the content encoder)
@@ -1169,6 +1204,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
+        RUN(flush_reduces(c));
         c.s = mainS;
         c.wstream = overlap ? p->wstream[0] : mainS;
     }
@@ -1206,6 +1242,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         dyA = c.fresh((long)B * C * e.T[0]);
         if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
+        RUN(flush_reduces(c));
     }
 
     if (!dry) join_side(p, mainS, sideS);
@@ -1215,7 +1252,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             hipStreamWaitEvent(mainS, p->wjoin[i], 0);
         }
     }
-    RUN(c.red.flush());
+    RUN(c.red.flush(s));
     if (slab_need) {
         slab_need[0] = c.slab_used;
         slab_need[1] = c.dy_used;

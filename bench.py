@@ -154,6 +154,9 @@ def main():
                     help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--presleep-ms", type=float, default=0.0,
+                    help="tracing aid: park the GPU this long before every timed step so that the (tracer-slowed) host has "
+                         "the whole step enqueued when it starts; the reported time is then meaningless")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
     a = ap.parse_args()
 
@@ -217,6 +220,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        if a.presleep_ms > 0:
+            torch.cuda._sleep(int(a.presleep_ms * 2.0e6))
         solver.ae_step(x, 1.0, eps=eps, sync=False)
     barrier()
     elapsed = time.perf_counter() - t0

@@ -20,7 +20,7 @@ def run(B, Cin, Cout, T, KS, tiles, mode="f"):
     flops = 2.0 * Cout * Cin * KS * B * T
     for tile in tiles:
         res = []
-        for dbg, name in ((0, "full"), (1, "noDMA"), (5, "noDMA,noBar"), (2, "noMFMA"), (3, "barrier only"), (7, "empty")):
+        for dbg, name in ((0, "full"), (1, "noDMA"), (5, "noDMA,noBar"), (2, "noMFMA"), (7, "empty"), (15, "empty,noEpi")):
             os.environ["AVC_CONV_DBG"] = str(dbg)
             if mode == "f":
                 f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wp), P(b), Cout, KS, 1, 1, P(out),
@@ -36,9 +36,9 @@ def run(B, Cin, Cout, T, KS, tiles, mode="f"):
 
 if __name__ == "__main__":
     B = 256
-    run(B, 128, 128, 128, 5, (11, 21, 22))
+    run(B, 128, 128, 128, 5, (11,))
     run(B, 128, 128, 128, 5, (11,), "d")
     run(B, 128, 128, 32, 5, (11,))
-    run(B, 128, 128, 16, 5, (11,))
-    run(B, 1104, 128, 128, 1, (11, 21))
-    run(B, 1024, 128, 128, 1, (21, 22), "d")   # in_conv dgrad shape: K = 128, M = 1024
+    run(B, 1104, 128, 128, 1, (21,))
+    run(B, 1024, 128, 128, 1, (21,), "d")   # in_conv dgrad shape: K = 128, M = 1024
+    run(1, 128, 128, 64, 1, (11,))

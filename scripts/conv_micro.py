@@ -58,12 +58,12 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
 
 if __name__ == "__main__":
     B = 256
-    run(B, 128, 128, 128, 5, 1)
-    run(B, 128, 128, 64, 5, 1)
-    run(B, 128, 128, 32, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 128, 5, 1, tiles=(21, 11, 12))
+    run(B, 128, 128, 64, 5, 1, tiles=(21, 11, 12))
+    run(B, 128, 128, 32, 5, 1, tiles=(11, 12))
     run(B, 128, 128, 16, 5, 1, tiles=(21, 11))
     run(B, 128, 128, 128, 5, 2, tiles=(21, 11))
-    run(B, 1104, 128, 128, 1, 1, tiles=(22, 21, 11))
-    run(B, 80, 128, 128, 8, 1, tiles=(22, 21, 11), which="fw")
-    run(B, 128, 1024, 128, 1, 1, tiles=(22, 21, 11), which="f")
+    run(B, 1104, 128, 128, 1, 1, tiles=(22, 21, 11, 12))
+    run(B, 80, 128, 128, 8, 1, tiles=(21, 11, 12), which="fw")
+    run(B, 128, 1024, 128, 1, 1, tiles=(22, 21, 11, 12), which="f")
     run(1, 128, 128, 256, 1, 1, tiles=(11,))
