@@ -83,10 +83,39 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
     // chunk origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
     constexpr int NPD = (TCO * WG_DYROW + 255) / 256;  // dy pieces per wave
     constexpr int NPX = (TCI * (KS == 1 ? 33 : 71) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
-    const bool fastp = (spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256);
+    // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the
+    // reflection is chunk-invariant, so the x offsets are complete and only the base moves.
+    const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
+    const bool fastp = fastm || ((spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256));
     unsigned dyo[NPD], xo[NPX];
     int xq[NPX];
-    if (fastp && producer) {
+    if (fastm && producer) {
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            const int f = (wave + 4 * i) * 64 + lane;
+            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+            row = row < TCO ? row : TCO - 1;
+            qcol = qcol < 32 ? qcol : 31;
+            int co = co0 + row;
+            co = co < a.Cout ? co : a.Cout - 1;
+            const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
+            dyo[i] = 4u * (unsigned)((long)sl * a.dy.sb + src_chan_off(a.dy, co) + (long)tl * a.dy.st);
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int f = (wave + 4 * i) * 64 + lane;
+            int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
+            row = row < TCI ? row : TCI - 1;
+            int sl = pp / XSEG, p = pp - sl * XSEG;
+            if (sl >= spc) { sl = spc - 1; p = XSEG - 1; }  // the odd-stride padding column
+            int ci = ci0 + row;
+            ci = ci < a.Cin ? ci : a.Cin - 1;
+            int r = avc_reflect(p - a.padL, a.Tin);
+            r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);
+            xo[i] = 4u * (unsigned)((long)sl * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st);
+            xq[i] = 0;
+        }
+    } else if (fastp && producer) {
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
             const int f = (wave + 4 * i) * 64 + lane;
@@ -112,6 +141,17 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
     auto issue_fast = [&](int chunk, int buf) {
         float* dd = dyT + buf * DYSP;
         float* xd = xT + buf * XSP;
+        if (fastm) {
+            const float* dyb = dyptr + (long)chunk * spc * a.dy.sb;
+            const float* xb = xptr + (long)chunk * spc * a.x.sb;
+#pragma unroll
+            for (int i = 0; i < NPD; ++i)
+                if ((wave + 4 * i) * 64 < DYSP) avc_glds4_s(dyb, dyo[i], dd + (wave + 4 * i) * 64);
+#pragma unroll
+            for (int i = 0; i < NPX; ++i)
+                if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xb, xo[i], xd + (wave + 4 * i) * 64);
+            return;
+        }
         const int cb = chunk / a.chunks_per_sample;
         const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
         const float* dyb = dyptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);

@@ -187,6 +187,11 @@ WG = [
     (1, 16, 130, 200, 3, 1),
     (2, 130, 40, 40, 1, 1),      # 1x1 with the 128x128 four-accumulator tile
     (2, 80, 32, 33, 4, 1),       # Cin = 80: 128co x 32ci tile
+    (8, 16, 32, 16, 5, 1),       # whole short samples per chunk (precomputed descriptors incl. reflection)
+    (8, 16, 32, 32, 5, 2),
+    (16, 8, 32, 8, 5, 1),
+    (7, 16, 32, 16, 5, 1),       # ... B not a multiple of samples-per-chunk: generic path
+    (4, 16, 32, 64, 5, 1),       # whole 32-column chunks of longer samples
     pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
     pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
     pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
