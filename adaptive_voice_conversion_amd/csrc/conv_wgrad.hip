@@ -9,6 +9,7 @@
 // tile they already hold in LDS.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -31,7 +32,7 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // k-loop is matrix-pipe idle time (measured: 62 % MFMA duty even with DMA and barriers removed).
 // So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
 // issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
-template <int KS, int NB, int WCO>
+template <int KS, int NB, int WCO, bool LIN>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int WCI = 4 / WCO;            // waves along ci
     constexpr int TCO = 32 * WCO;           // co rows per workgroup
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
         return;
     }
 
+    {
     f32x16 acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j)
@@ -262,28 +264,41 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
         if (!(a.dbg & 2)) {
             const float* arow = dyT + buf * DYSP + (wave_m * 32 + li) * WG_DYROW;
             const float* brow = xT + buf * XSP + (wave_n * NB * 32 + li) * XROW;
-            auto ldfrag = [&](int s, float& av, float (&bv)[NACC]) {
-                const int qcol = 2 * s + h;
-                const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
-                av = arow[qcol];
-                const float* bp = brow + sl * XSEG + tl * a.stride;
+            // fragments of k-step s+1 are requested before the MFMAs of step s are queued.  LIN (template): whole
+            // 32-column chunks of a stride-1 layer -- column 2s+h of the chunk is element 2s+h of both
+            // LDS rows, so every fragment address is base + immediate (the general form costs ~30
+            // hoisted address registers, which decides whether two workgroups fit on a CU).
+            {
+                const float* arow_h = arow + h;
+                const float* brow_h = brow + h;
+                auto ldfrag = [&](int s, float& av, float (&bv)[NACC]) {
+                    const float* bp;
+                    if constexpr (LIN) {
+                        av = arow_h[2 * s];
+                        bp = brow_h + 2 * s;
+                    } else {
+                        const int qcol = 2 * s + h;
+                        const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
+                        av = arow[qcol];
+                        bp = brow + sl * XSEG + tl * a.stride;
+                    }
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
-            };
-            // fragments of k-step s+1 are requested before the MFMAs of step s are queued
-            float av[2], bv[2][NACC];
-            ldfrag(0, av[0], bv[0]);
+                        for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
+                };
+                float av[2], bv[2][NACC];
+                ldfrag(0, av[0], bv[0]);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int cur = s & 1;
-                if (s + 1 < 16) ldfrag(s + 1, av[cur ^ 1], bv[cur ^ 1]);
-                __builtin_amdgcn_sched_barrier(0);  // reads stay in front of the MFMAs they overlap with ...
+                for (int s = 0; s < 16; ++s) {
+                    const int cur = s & 1;
+                    if (s + 1 < 16) ldfrag(s + 1, av[cur ^ 1], bv[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);  // reads stay in front of the MFMAs they overlap with ...
 #pragma unroll
-                for (int k = 0; k < NACC; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][k], acc[k], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
+                    for (int k = 0; k < NACC; ++k)
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][k], acc[k], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
+                }
             }
         }
         if (!(a.dbg & 4)) __syncthreads();
@@ -305,6 +320,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
                 for (int j = 0; j < KS; ++j) slab[((long)j * a.Cout + co) * a.Cin + ci] = acc[nb * KS + j][r];
             }
         }
+    }
     }
 }
 
@@ -392,7 +408,8 @@ static int launch_wgrad_t(const WgradArgs& a, int nsplit, hipStream_t stream) {
     const int ng = a.ngroups > 1 ? a.ngroups : 1;
     dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit, ng);
     ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * ng * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO>), grid, dim3(WG_THREADS), lds, stream, a);
+    if (a.Tc == 32 && a.stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true>), grid, dim3(WG_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false>), grid, dim3(WG_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }
 
