@@ -410,7 +410,14 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
-extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? 8 : (KS >= 2 ? 16 : 32); }
+extern "C" int avc_conv_ck(int KS) {
+    static int ck5 = -1;
+    if (ck5 < 0) {
+        const char* e = getenv("AVC_CONV_CK5");  // micro-benchmark knob: chunk depth of the k >= 4 layers at the op level
+        ck5 = e ? atoi(e) : 8;
+    }
+    return KS >= 4 ? ck5 : (KS >= 2 ? 16 : 32);
+}
 
 // tile choice shared by the launcher and the plan (which sizes CK from it)
 int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {
@@ -437,6 +444,10 @@ int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) 
         int BN = (tile % 10 == 1) ? 64 : 128;
         ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
         if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;
+        // at most one workgroup per CU: the forward kernel gains another ~6 % from four chunks of 32
+        // (r1 sweep: T_l = 16/32 forward 26.0 -> 24.5 us; the dgrad variant does not move)
+        int BM = (tile / 10 == 1) ? 64 : 128;
+        if (KS == 5 && mode == 0 && wgs <= 256 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
     }
     return ck;
 }
@@ -487,14 +498,16 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     const bool mir = a.mode == 1 && a.mirror;
     // the model's kernel_size (5) with the two chunk depths the plan uses gets straight-line chunks
-    const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : 0)) : 0;
+    const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0))) : 0;
 #define AVC_LAUNCH_CONV(WM_, WN_)                                                                                      \
     do {                                                                                                               \
         if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 1>), grid, block, lds, stream, a);    \
         else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 2>), grid, block, lds, stream, a); \
+        else if (mir && fast == 4) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 4>), grid, block, lds, stream, a); \
         else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 0, 0>), grid, block, lds, stream, a);          \
         else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 1>), grid, block, lds, stream, a);   \
         else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 2>), grid, block, lds, stream, a);   \
+        else if (fast == 4) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 4>), grid, block, lds, stream, a);   \
         else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0>), grid, block, lds, stream, a);                  \
     } while (0)
     if (tile == 22) AVC_LAUNCH_CONV(2, 2);

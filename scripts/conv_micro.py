@@ -56,7 +56,7 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
         us = timeit(f); res.append(f"wgrad(+reduce): {us:7.1f}us {flops/us/1e6:6.1f}TF")
     print(f"B={B} {Cin}->{Cout} T={T} k={KS} s={stride}: " + " | ".join(res), flush=True)
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 0 and sys.argv[0] != "x":
     B = 256
     run(B, 128, 128, 128, 5, 1, tiles=(21, 11, 12))
     run(B, 128, 128, 64, 5, 1, tiles=(21, 11, 12))
