@@ -161,14 +161,21 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
     }
 }
 
-template <int WM, int WN, bool MIRROR, int KSC, int GRC>
-__global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a) {
+// KG > 1: intra-workgroup split-K for layers that cannot fill the chip (T_l <= 32: 128-256 tiles, each
+// wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
+// runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
+// summed through LDS in a fixed order at the end (deterministic).
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG>
+__global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int NTHREADS = AVC_THREADS * KG;
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[blockIdx.z];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
+    const int kg = (KG > 1) ? (wave_all >> 2) : 0;
+    const int wave = wave_all & 3;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int li = lane & 31, h = lane >> 5;
 
@@ -180,8 +187,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
 
     const int AS = KS * CK * BM;  // floats per A stage
     const int XS = CK * ROW;      // floats per X stage
-    float* As = smem;
-    float* Xs = smem + 2 * AS;
+    float* As = smem + kg * 2 * AS;                 // this group's two A stages
+    float* Xs = smem + KG * 2 * AS + kg * 2 * XS;   // ... and X stages
 
     // ---- per-lane source descriptors of the X tile: lane l owns LDS positions p = 64*j + l of every
     // row (one row = one reduction channel), so the descriptor depends on p only and each chunk's
@@ -213,7 +220,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         xoff[j] = sp;
     }
     // both X stages start as zeros; structural zeros are never overwritten afterwards
-    for (int e = tid; e < 2 * XS; e += AVC_THREADS) Xs[e] = 0.f;
+    for (int e = tid; e < KG * 2 * XS; e += NTHREADS) smem[KG * 2 * AS + e] = 0.f;
 
     // ---- per-lane column bases into an LDS row
     int cb[WN], cbl[WN], cbr[WN], colb[WN], colt[WN];
@@ -303,25 +310,53 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_gemm_kernel(const ConvArgs a
         }
     };
 
-    load_a(0, 0);
-    load_x(0, 0);
+    if (kg < nchunk) {
+        load_a(kg, 0);
+        load_x(kg, 0);
+    }
     __syncthreads();
 
     const int a_lane = wave_m * (32 * WM) + li;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const bool more = (chunk + 1 < nchunk);
-        if (more && !((a.dbg & 1) && chunk >= 1)) {
-            load_a(chunk + 1, (chunk + 1) & 1);  // both land while this chunk is multiplied; drained at the barrier
-            load_x(chunk + 1, (chunk + 1) & 1);
+    const int nit = (nchunk + KG - 1) / KG;
+    for (int it = 0; it < nit; ++it) {
+        const int chunk = it * KG + kg;
+        const bool more = (chunk + KG < nchunk);
+        if (more && !((a.dbg & 1) && it >= 1)) {
+            load_a(chunk + KG, (it + 1) & 1);  // both land while this chunk is multiplied; drained at the barrier
+            load_x(chunk + KG, (it + 1) & 1);
         }
-        const float* Ab = As + (chunk & 1) * AS;
-        const float* Xb = Xs + (chunk & 1) * XS;
-        if (a.dbg & 2) {
+        const float* Ab = As + (it & 1) * AS;
+        const float* Xb = Xs + (it & 1) * XS;
+        if ((a.dbg & 2) || chunk >= nchunk) {
         } else if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
             conv_chunk_mma<WM, WN, true, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else
             conv_chunk_mma<WM, WN, false, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         if (!(a.dbg & 4)) __syncthreads();
+    }
+
+    if (KG > 1) {  // fixed-order sum of the groups' partial tiles through the (now free) stage memory
+        float* red = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (WM * WN * 16 * 64) + lane;
+        if (kg > 0) {
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wm * WN + wn) * 16 + r) * 64] = acc[wm][wn][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int k2 = 1; k2 < KG; ++k2) {
+            const float* rk = smem + ((k2 - 1) * 4 + wave) * (WM * WN * 16 * 64) + lane;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[wm][wn][r] += rk[((wm * WN + wn) * 16 + r) * 64];
+        }
     }
 
     // ---- epilogue
@@ -447,7 +482,7 @@ int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) 
         // at most one workgroup per CU: the forward kernel gains another ~6 % from four chunks of 32
         // (r1 sweep: T_l = 16/32 forward 26.0 -> 24.5 us; the dgrad variant does not move)
         int BM = (tile / 10 == 1) ? 64 : 128;
-        if (KS == 5 && mode == 0 && wgs <= 256 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
+        if (KS == 5 && mode == 0 && wgs <= 256 && tile != 11 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
     }
     return ck;
 }
@@ -490,30 +525,35 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
         if (q.ROW > 64 * AVC_CONV_NJ) return -3;
     }
     size_t lds = conv_lds_bytes(a, BM, BN);
+    dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
+    // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
+    int kgroups = 1;
+    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= 256 && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
+    lds *= kgroups;
     if (lds > 160 * 1024) return -5;
-    dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups), block(AVC_THREADS);
+    dim3 block(AVC_THREADS * kgroups);
     double flops = 0;
     for (int gi = 0; gi < a.ngroups; ++gi)
         flops += 2.0 * a.M * a.Cred * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     const bool mir = a.mode == 1 && a.mirror;
-    // the model's kernel_size (5) with the two chunk depths the plan uses gets straight-line chunks
+    // the model's kernel_size (5) with the chunk depths the plan uses gets straight-line chunks
     const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0))) : 0;
-#define AVC_LAUNCH_CONV(WM_, WN_)                                                                                      \
+#define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                                 \
     do {                                                                                                               \
-        if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 1>), grid, block, lds, stream, a);    \
-        else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 2>), grid, block, lds, stream, a); \
-        else if (mir && fast == 4) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 4>), grid, block, lds, stream, a); \
-        else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 0, 0>), grid, block, lds, stream, a);          \
-        else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 1>), grid, block, lds, stream, a);   \
-        else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 2>), grid, block, lds, stream, a);   \
-        else if (fast == 4) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 4>), grid, block, lds, stream, a);   \
-        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0>), grid, block, lds, stream, a);                  \
+        if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 1, KG_>), grid, block, lds, stream, a);    \
+        else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 2, KG_>), grid, block, lds, stream, a); \
+        else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 0, 0, KG_>), grid, block, lds, stream, a);          \
+        else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 1, KG_>), grid, block, lds, stream, a);   \
+        else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 2, KG_>), grid, block, lds, stream, a);   \
+        else if (fast == 4 && KG_ == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 4, 1>), grid, block, lds, stream, a); \
+        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0, KG_>), grid, block, lds, stream, a);                  \
     } while (0)
-    if (tile == 22) AVC_LAUNCH_CONV(2, 2);
-    else if (tile == 12) AVC_LAUNCH_CONV(1, 2);
-    else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
-    else AVC_LAUNCH_CONV(1, 1);
+    if (tile == 22) AVC_LAUNCH_CONV(2, 2, 1);
+    else if (tile == 12) AVC_LAUNCH_CONV(1, 2, 1);
+    else if (tile == 21) AVC_LAUNCH_CONV(2, 1, 1);
+    else if (kgroups == 2) AVC_LAUNCH_CONV(1, 1, 2);
+    else AVC_LAUNCH_CONV(1, 1, 1);
 #undef AVC_LAUNCH_CONV
     return (int)hipGetLastError();
 }
