@@ -56,6 +56,8 @@ FWD = [
     (1, 16, 128, 130, 5, 1, 22),  # 128x128 tile
     (5, 16, 32, 3, 5, 1, 11),     # bottleneck-sized rows
     (2, 16, 32, 21, 5, 2, 11),    # stride 2, odd T
+    (2, 40, 32, 32, 5, 1, 11),    # 5 K-chunks: two split-K wave groups with unequal chunk counts
+    (3, 64, 64, 16, 5, 1, 11),    # 8 K-chunks, several short samples per tile, split-K
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(8, 128, 256, 64, 5, 1, 0, marks=GPU),
