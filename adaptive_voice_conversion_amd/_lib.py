@@ -52,6 +52,10 @@ def declare(lib):
     lib.avc_plan_buffer.restype = c_long
     lib.avc_plan_num_relu_sites.argtypes = [c_void_p]
     lib.avc_plan_relu_site.argtypes = [c_void_p, c_int, ctypes.POINTER(ReluSite)]
+    lib.avc_plan_set_compute_dtype.argtypes = [c_void_p, c_int]
+    lib.avc_plan_compute_dtype.argtypes = [c_void_p]
+    lib.avc_set_op_compute_dtype.argtypes = [c_int]
+    lib.avc_set_op_compute_dtype.restype = None
     lib.avc_plan_out_len.argtypes = [c_void_p]
     lib.avc_plan_latent_len.argtypes = [c_void_p]
     lib.avc_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,

@@ -11,6 +11,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short avc_s16x4 __attribute__((ext_vector_type(4)));
+
+// compute dtype of the conv / Linear matrix products (storage is fp32 either way)
+enum {
+    AVC_COMPUTE_F32 = 0,   // v_mfma_f32_32x32x2_f32: bit-exact fp32 (reference precision)
+    AVC_COMPUTE_BF16 = 1,  // operands rounded to bf16 (RNE) at fragment time, fp32 accumulate: v_mfma_f32_32x32x8_bf16
+};
 
 // ---- residual / gradient-join modes used by conv epilogues and row kernels
 enum {
@@ -55,6 +62,8 @@ struct ConvArgs {
     int rt, Tres;
     int ngroups;
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
+    int bf16; // AVC_COMPUTE_*
+    int pad2_;
     ConvGroup g[AVC_MAX_GROUPS];
 };
 
@@ -69,6 +78,7 @@ struct WgradArgs {
     long slab_stride, db_stride;
     int wrow0;     // row offset (bank/grouped layers write a sub-block)
     int dbg;       // ablation switches of the micro-benchmarks (0 in the product path)
+    int bf16;      // AVC_COMPUTE_*
     // grouped launch (ngroups > 1): blockIdx.z selects the operand pair of one of several layers of
     // identical geometry (the speaker encoder's Linear stack); slab/dbslab advance by the group strides
     int ngroups;
@@ -177,6 +187,32 @@ static __device__ __forceinline__ void avc_glds16_s(const float* sbase, unsigned
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// four fp32 -> four bf16 (round to nearest even), packed as the A/B operand of v_mfma_f32_32x32x8_bf16:
+// slot j of lane-half h carries reduction index k = 2j + h in BOTH operands (any bijection works as
+// long as A and B agree, the sum over k does not care about the order)
+#ifndef AVC_EMU
+static __device__ __forceinline__ avc_s16x4 avc_pack_bf16x4(float a, float b, float c, float d) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};  // v_cvt_pk_bf16_f32 x2
+    return __builtin_bit_cast(avc_s16x4, v);
+}
+static __device__ __forceinline__ f32x16 avc_mfma_bf16(avc_s16x4 a, avc_s16x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+}
+#else
+static inline short avc_bf16_bits(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+static inline avc_s16x4 avc_pack_bf16x4(float a, float b, float c, float d) {
+    avc_s16x4 v = {avc_bf16_bits(a), avc_bf16_bits(b), avc_bf16_bits(c), avc_bf16_bits(d)};
+    return v;
+}
+static inline f32x16 avc_mfma_bf16(avc_s16x4 a, avc_s16x4 b, f32x16 c) { return emu::mfma_32x32x8_bf16(a, b, c); }
+#endif
 
 // f / d for 0 <= f < 2^22 with a precomputed float reciprocal (one fix-up step; integer division
 // by a run-time divisor costs ~25 instructions on gfx950, this costs ~6)

@@ -105,8 +105,20 @@ static __device__ __forceinline__ void conv_load_unit(float (&av)[4][WM], float 
         }
     }
 }
-template <int WM, int WN>
+template <int WM, int WN, bool BF>
 static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const float (&av)[4][WM], const float (&bv)[4][WN]) {
+    if constexpr (BF) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
+        avc_s16x4 ap[WM], bp[WN];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) ap[wm] = avc_pack_bf16x4(av[0][wm], av[1][wm], av[2][wm], av[3][wm]);
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) bp[wn] = avc_pack_bf16x4(bv[0][wn], bv[1][wn], bv[2][wn], bv[3][wn]);
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) acc[wm][wn] = avc_mfma_bf16(ap[wm], bp[wn], acc[wm][wn]);
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -119,7 +131,7 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], cons
 // KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
 // block with the fragments of unit u+1 fetched from LDS before the MFMAs of unit u are issued
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
-template <int WM, int WN, bool MIRROR, int KSC, int GRC>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, bool BF>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
                                                       int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
                                                       const int (&cbr)[WN]) {
@@ -143,7 +155,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
                 conv_load_unit<WM, WN, MIRROR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
             }
             // (pinning this order with sched_barrier(0) was measured: no gain with 4 waves/SIMD, r1 log)
-            conv_mma_unit<WM, WN>(acc, av[u & 1], bv[u & 1]);
+            conv_mma_unit<WM, WN, BF>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
         const int groups = CK >> 3;
@@ -153,7 +165,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
             for (int g4 = 0; g4 < groups; ++g4) {
                 float av[4][WM], bv[4][WN];
                 conv_load_unit<WM, WN, MIRROR>(av, bv, Arow, Xrow, ROW, cb, cbl, cbr);
-                conv_mma_unit<WM, WN>(acc, av, bv);
+                conv_mma_unit<WM, WN, BF>(acc, av, bv);
                 Arow += 8 * BM;
                 Xrow += 8 * ROW;
             }
@@ -165,7 +177,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
 // runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
 // summed through LDS in a fixed order at the end (deterministic).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -329,9 +341,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         const float* Xb = Xs + (it & 1) * XS;
         if ((a.dbg & 2) || chunk >= nchunk) {
         } else if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, WN, true, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, WN, true, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else
-            conv_chunk_mma<WM, WN, false, KSC, GRC>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, WN, false, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         if (!(a.dbg & 4)) __syncthreads();
     }
 
@@ -504,6 +516,17 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
     return avc_cdiv(a.B, spt);
 }
 
+template <int WM, int WN, int KG, bool BF>
+static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 0, 0, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
+}
+
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     ConvArgs a = a_in;
@@ -515,7 +538,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     if (a.Mp % 128 != 0) return -2;
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
-    int tile = force_tile;
+    int tile = force_tile == 12 ? 11 : force_tile;  // (the 64x128 tile measured no better than 64x64 and was dropped)
     if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups);
     int BM = (tile / 10 == 1) ? 64 : 128;
     int BN = (tile % 10 == 1) ? 64 : 128;
@@ -539,18 +562,13 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     const bool mir = a.mode == 1 && a.mirror;
     // the model's kernel_size (5) with the chunk depths the plan uses gets straight-line chunks
     const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0))) : 0;
-#define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                                 \
-    do {                                                                                                               \
-        if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 1, KG_>), grid, block, lds, stream, a);    \
-        else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 5, 2, KG_>), grid, block, lds, stream, a); \
-        else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, true, 0, 0, KG_>), grid, block, lds, stream, a);          \
-        else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 1, KG_>), grid, block, lds, stream, a);   \
-        else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 2, KG_>), grid, block, lds, stream, a);   \
-        else if (fast == 4 && KG_ == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 5, 4, 1>), grid, block, lds, stream, a); \
-        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, false, 0, 0, KG_>), grid, block, lds, stream, a);                  \
+    const bool bf = a.bf16 == AVC_COMPUTE_BF16;
+#define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                             \
+    do {                                                                                                           \
+        if (bf) conv_launch_variant<WM_, WN_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
+        else conv_launch_variant<WM_, WN_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
     } while (0)
     if (tile == 22) AVC_LAUNCH_CONV(2, 2, 1);
-    else if (tile == 12) AVC_LAUNCH_CONV(1, 2, 1);
     else if (tile == 21) AVC_LAUNCH_CONV(2, 1, 1);
     else if (kgroups == 2) AVC_LAUNCH_CONV(1, 1, 2);
     else AVC_LAUNCH_CONV(1, 1, 1);

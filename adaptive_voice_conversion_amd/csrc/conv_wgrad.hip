@@ -32,7 +32,7 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // k-loop is matrix-pipe idle time (measured: 62 % MFMA duty even with DMA and barriers removed).
 // So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
 // issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
-template <int KS, int NB, int WCO, bool LIN>
+template <int KS, int NB, int WCO, bool LIN, bool BF>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int WCI = 4 / WCO;            // waves along ci
     constexpr int TCO = 32 * WCO;           // co rows per workgroup
@@ -287,6 +287,27 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
 #pragma unroll
                         for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
                 };
+                if constexpr (BF) {
+                    // four k-steps (8 columns) per v_mfma_f32_32x32x8_bf16: slot j of lane-half h carries
+                    // column 2(4g + j) + h of the chunk in both operands; operands are rounded to bf16 here
+                    float av4[2][4], bv4[2][4][NACC];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ldfrag(j, av4[0][j], bv4[0][j]);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int cur = g4 & 1;
+                        if (g4 + 1 < 4) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ldfrag(4 * (g4 + 1) + j, av4[cur ^ 1][j], bv4[cur ^ 1][j]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const avc_s16x4 ap = avc_pack_bf16x4(av4[cur][0], av4[cur][1], av4[cur][2], av4[cur][3]);
+#pragma unroll
+                        for (int k = 0; k < NACC; ++k)
+                            acc[k] = avc_mfma_bf16(ap, avc_pack_bf16x4(bv4[cur][0][k], bv4[cur][1][k], bv4[cur][2][k], bv4[cur][3][k]), acc[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
                 float av[2], bv[2][NACC];
                 ldfrag(0, av[0], bv[0]);
 #pragma unroll
@@ -298,6 +319,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
                     for (int k = 0; k < NACC; ++k)
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][k], acc[k], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
+                }
                 }
             }
         }
@@ -408,8 +430,12 @@ static int launch_wgrad_t(const WgradArgs& a, int nsplit, hipStream_t stream) {
     const int ng = a.ngroups > 1 ? a.ngroups : 1;
     dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit, ng);
     ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * ng * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
-    if (a.Tc == 32 && a.stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true>), grid, dim3(WG_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false>), grid, dim3(WG_THREADS), lds, stream, a);
+    const bool lin = a.Tc == 32 && a.stride == 1;
+    if (a.bf16 == AVC_COMPUTE_BF16) {
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, a);
+    } else if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }
 

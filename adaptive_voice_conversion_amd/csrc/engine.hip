@@ -49,6 +49,7 @@ struct ParamT {
 };
 
 struct LayerP {
+    int bf16 = 0;  // AVC_COMPUTE_* of this layer's matrix products (avc_plan_set_compute_dtype)
     int Cout = 0, Cin = 0, KS = 1, stride = 1;
     int nsrc = 1, rows = 0;
     int w[12], b[12];
@@ -104,6 +105,7 @@ struct avc_plan {
     long gA2 = -1, gB2 = -1, gC2 = -1, dyA2 = -1, dyB2 = -1;
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int compute = 0;             // AVC_COMPUTE_*
     mutable int side_state = 0;  // 0 = not created, 1 = ready, -1 = disabled
     // weight-gradient kernels depend on nothing downstream: they run on their own (low priority)
     // streams beside the dgrad / InstanceNorm-backward chain of each branch
@@ -479,6 +481,14 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
 static int g_force_single = 0;
 extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
 
+extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
+    if (!p || (dtype != AVC_COMPUTE_F32 && dtype != AVC_COMPUTE_BF16)) return fail(-1, "avc_plan_set_compute_dtype: dtype must be 0 (fp32) or 1 (bf16 operands)");
+    p->compute = dtype;
+    for (LayerP& L : p->layers) L.bf16 = dtype;
+    return 0;
+}
+extern "C" int avc_plan_compute_dtype(const avc_plan* p) { return p ? p->compute : -1; }
+
 static bool side_ready(const avc_plan* p) {
     if (g_force_single) return false;
     if (p->side_state == 0) {
@@ -563,7 +573,7 @@ static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, 
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = 1;
     a.B = Bn; a.Cred = L.Cin; a.Tsrc = Tsrc;
-    a.mode = 0; a.stride = L.stride;
+    a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
     a.M = L.Cout; a.Mp = L.Mp_f;
     a.ngroups = 1;
     set_group(a.g[0], ws + L.wpf, layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
@@ -580,7 +590,7 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     memset(&a, 0, sizeof(a));
     a.x.ptr = dy; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = ps;
     a.B = Bn; a.Cred = L.Cout; a.Tsrc = Tdy;
-    a.mode = 1; a.stride = L.stride; a.mirror = (L.KS > 1) ? 1 : 0;
+    a.mode = 1; a.stride = L.stride; a.mirror = (L.KS > 1) ? 1 : 0; a.bf16 = L.bf16;
     a.M = L.dgM; a.Mp = L.Mp_d; a.Tout = Tin;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
@@ -655,7 +665,7 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.x.ptr = x; a.x.sb = xsb; a.x.sc = xsc; a.x.st = xst; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = ysb; a.dy.sc = ysc; a.dy.st = yst; a.dy.ps = yps;
     a.B = Bn; a.Cin = L.Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
-    a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
+    a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride; a.bf16 = L.bf16;
     int nsplit;
     avc_wgrad_plan(Bn, L.Cin, Cout, Tout, L.KS, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
     long wsz = (long)Cout * L.Cin * L.KS;
@@ -719,7 +729,7 @@ static int wgrad_dense_group(BwdCtx& c, const LayerP* const* Ls, const float* co
         a.x.ptr = xs[i]; a.x.sb = 0; a.x.sc = Bn; a.x.st = 1; a.x.ps = 1;
         a.dy.ptr = dys[i]; a.dy.sb = 0; a.dy.sc = Bn; a.dy.st = 1; a.dy.ps = 1;
         a.B = 1; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Bn; a.Tout = Bn;
-        a.KS = 1; a.padL = 0; a.stride = 1;
+        a.KS = 1; a.padL = 0; a.stride = 1; a.bf16 = L.bf16;
         int nsplit;
         avc_wgrad_plan(1, L.Cin, L.Cout, Bn, 1, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
         const long wsz = (long)L.Cout * L.Cin;
@@ -829,7 +839,7 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.B = B; a.Cred = e.c.c_in; a.Tsrc = T0;
-    a.mode = 0; a.stride = 1;
+    a.mode = 0; a.stride = 1; a.bf16 = p->compute;
     a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128; a.Tout = T0;
     a.ob = (long)e.CC * T0; a.oc = T0; a.ot = 1; a.ops = 1;
     a.act = 1;
@@ -1098,7 +1108,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             w.x.ptr = ws + d.dcond; w.x.sb = 0; w.x.sc = csb; w.x.st = 1; w.x.ps = 1;
             w.dy.ptr = ws + La.wpf; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
-            w.KS = 1; w.padL = 0; w.stride = 1;
+            w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = p->compute;
             int nsplit;
             avc_wgrad_plan(1, w.Cin, w.Cout, w.Tout, 1, &w.Tc, &w.spc, &w.chunks_per_sample, &w.total_chunks, &w.chunks_per_wg, &nsplit);
             const long wsz = (long)w.Cout * w.Cin;

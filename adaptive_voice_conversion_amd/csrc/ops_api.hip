@@ -10,6 +10,10 @@
 
 extern "C" {
 
+// compute dtype of the op-level conv entry points (the whole-model path takes it from the plan)
+static int g_op_compute = AVC_COMPUTE_F32;
+void avc_set_op_compute_dtype(int dtype) { g_op_compute = (dtype == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; }
+
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
     int CK = avc_conv_ck(KS);
     int red = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
@@ -44,6 +48,7 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
                    int tile, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    a.bf16 = g_op_compute;
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.B = B; a.Cred = Cin; a.Tsrc = Tin;
     a.mode = 0; a.stride = stride; a.mirror = 0;
@@ -69,6 +74,7 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
                      void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    a.bf16 = g_op_compute;
     a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
     a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
     a.mode = 1; a.stride = stride;
@@ -100,6 +106,7 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
                      void* stream) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.bf16 = g_op_compute;
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;

@@ -56,7 +56,11 @@ class Plan:
     """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
     tests may inject the CPU lane-level simulation build instead."""
 
-    def __init__(self, config, B, T, T_cond=None, lib=None):
+    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1}
+
+    def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32"):
+        """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
+        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3)."""
         self.lib = lib if lib is not None else _lib.load()
         self.cfg = cfg_from_dict(config)
         self.B, self.T, self.T_cond = int(B), int(T), int(T_cond or T)
@@ -65,6 +69,12 @@ class Plan:
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
+        key = str(compute_dtype).lower()
+        if key not in self.COMPUTE:
+            raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE)}, got {compute_dtype!r}")
+        self.compute_dtype = "bf16" if self.COMPUTE[key] else "fp32"
+        if self.lib.avc_plan_set_compute_dtype(h, self.COMPUTE[key]) != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
         self.num_params = self.lib.avc_plan_num_params(h)
         self.param_floats = self.lib.avc_plan_param_floats(h)
         self.workspace_floats = self.lib.avc_plan_workspace_floats(h)

@@ -109,10 +109,13 @@ class _AEFunction(torch.autograd.Function):
 class AE(nn.Module):
     """model.py:373-395."""
 
-    def __init__(self, config, lib=None):
+    def __init__(self, config, lib=None, compute_dtype=None):
+        """``compute_dtype`` ("fp32" default | "bf16"; also read from ``config["compute_dtype"]``) is an
+        extension over the reference: the precision of the conv / Linear matrix products (engine.Plan)."""
         super().__init__()
         self.config = config
         self._lib = lib
+        self.compute_dtype = compute_dtype or (config.get("compute_dtype") if isinstance(config, dict) else None) or "fp32"
         cfg_from_dict(config)  # validates (raises on sn / lrelu / dropout)
         self.speaker_encoder = SpeakerEncoder(**config["SpeakerEncoder"])
         self.content_encoder = ContentEncoder(**config["ContentEncoder"])
@@ -169,7 +172,7 @@ class AE(nn.Module):
         key = (int(B), int(T), int(Tc), str(device))
         hit = self._plans.get(key)
         if hit is None:
-            plan = Plan(self.config, B, T, Tc, lib=self._lib)
+            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")
             ws = torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device)

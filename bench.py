@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 
 
@@ -152,6 +153,9 @@ def main():
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--mode", choices=("train", "infer"), default="train",
                     help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the headline (BASELINE configs[1]); bf16 = configs[2]'s compute mode (bf16 matrix products, "
+                         "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--presleep-ms", type=float, default=0.0,
@@ -177,6 +181,8 @@ def main():
 
     from adaptive_voice_conversion_amd.solver import Solver
     cfg = stock_config(a.mels)
+    if a.dtype == "bf16":
+        cfg["compute_dtype"] = "bf16"
     torch.manual_seed(0)
     args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log")
     solver = Solver(cfg, args)
@@ -239,9 +245,12 @@ def main():
         out = {
             "metric": "mel-segments/sec (80x128) train step", "value": value, "unit": "mel-segments/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: recon+KL train step (fwd, loss, bwd, clip, Adam-amsgrad), "
-                                   f"{a.mels}-mel x {T}-frame segments, batch {B}/GPU, fp32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[1]: recon+KL train step (fwd, loss, bwd, clip, Adam-amsgrad), "
+                                    f"{a.mels}-mel x {T}-frame segments, batch {B}/GPU, fp32") if a.dtype == "f32" else
+                                   (f"BASELINE configs[2]'s compute mode on {world} GPU(s): same train step, conv/Linear operands bf16 "
+                                    f"(fp32 accumulate, fp32 master weights and optimizer state), {a.mels}-mel x {T}-frame "
+                                    f"segments, batch {B}/GPU -- NOT the headline metric"),
                        "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
                        "final_losses": meta},
         }
@@ -249,8 +258,9 @@ def main():
             prof = profile_classes(solver, x, eps, steps=3)
             dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
             d = prof[dom]
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
+                               "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": None,
                                "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
                                "ms_per_step": d["ms_per_step"]}
             ib = [prof[k] for k in ("instnorm_fwd", "instnorm_bwd") if k in prof]

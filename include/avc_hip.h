@@ -86,6 +86,16 @@ int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 /* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
 void avc_set_single_stream(int on);
 
+/* Compute dtype of the Conv1d / Linear matrix products (BASELINE config 3: "bf16 compute, fp32 master
+ * and optimizer state").  0 = fp32 MFMA, bit-exact fp32 arithmetic (default, the reference's precision);
+ * 1 = operands rounded to bf16 (round-to-nearest-even) when they enter the matrix core, fp32 accumulate.
+ * Parameters, activations, statistics, gradients and the optimizer stay fp32 in memory either way.
+ * Applies to the whole-model entry points of this plan; the op-level conv entry points follow
+ * avc_set_op_compute_dtype (process-wide, default 0). */
+int avc_plan_set_compute_dtype(avc_plan* p, int dtype);
+int avc_plan_compute_dtype(const avc_plan* p);
+void avc_set_op_compute_dtype(int dtype);
+
 /* ---- whole-model entry points (replace AE.forward / AE.inference, model.py:380-391) */
 /* x: source mel [B,M,T]; x_cond: speaker mel [B,M,T_cond] (may alias x); eps: [B,c_out,Tb]
  * reparameterisation noise (model.py:383) or NULL for z = mu (AE.inference).

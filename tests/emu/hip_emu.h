@@ -95,6 +95,36 @@ static inline f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
     wave_sync();
     return c;
 }
+// v_mfma_f32_32x32x8_bf16 (_1k): A[i=l&31][k=4*(l>>5)+j], B[k=4*(l>>5)+j][col=l&31], j = 0..3 in the
+// lane's four bf16 slots; C/D as the fp32 32x32 shape; products exact in fp32, fp32 accumulate
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+static inline float bf16_to_f32(short s) {
+    unsigned u = ((unsigned)(unsigned short)s) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline f32x16_t mfma_32x32x8_bf16(s16x4_t a, s16x4_t b, f32x16_t c) {
+    struct Slot { s16x4_t a, b; };
+    Slot* buf = (Slot*)wave_buf();  // 16-byte slots
+    int l = lane();
+    buf[l].a = a;
+    buf[l].b = b;
+    wave_sync();
+    int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 8; ++k) {
+            float av = bf16_to_f32(buf[row + 32 * (k >> 2)].a[k & 3]);
+            float bv = bf16_to_f32(buf[col + 32 * (k >> 2)].b[k & 3]);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C: col=l&15,row=4*(l>>4)+r
 static inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
     float2* buf = (float2*)wave_buf();

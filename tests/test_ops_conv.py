@@ -234,3 +234,56 @@ def test_conv_wgrad_many_short_samples_per_chunk(kind, B, Cin, Cout, T, KS, stri
     """T_l of a few frames (e.g. T=24 inputs reach T_l=3): many samples share a 32-column
     K-chunk and the X tile is staged without registers."""
     test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride)
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", [(2, 40, 32, 32, 5, 1), (3, 16, 32, 20, 5, 2), (2, 24, 32, 33, 1, 1),
+                                                     pytest.param(8, 128, 128, 128, 5, 1, marks=GPU),
+                                                     pytest.param(64, 128, 128, 16, 5, 1, marks=GPU)])
+def test_conv_bf16_operand_mode(kind, B, Cin, Cout, T, KS, stride):
+    """avc_set_op_compute_dtype(1): operands rounded to bf16 (RNE) inside the matrix core, fp32
+    accumulate.  bf16 x bf16 products are exact in fp32, so forward and wgrad must equal the fp32
+    ops applied to bf16-rounded operands up to summation order; dgrad rounds the reflect-folded
+    gradient, so it is compared with the fp32 result at bf16 accuracy."""
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(7 * B + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    lib.avc_set_op_compute_dtype(1)
+    try:
+        out, _ = conv_fwd(lib, dev, x.to(dev), w.to(dev), b.to(dev), stride=stride, act=1)
+        ref = torch.relu(O.pad_conv(bf16r(x), bf16r(w), b, stride))
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+        assert (out.cpu() - torch.relu(O.pad_conv(x, w, b, stride))).abs().max() > 1e-4  # really a different precision
+        # wgrad
+        xr, wr = x.clone(), w.clone().requires_grad_(True)
+        y = O.pad_conv(bf16r(xr), wr, None, stride)
+        dy = torch.randn(y.shape, generator=g)
+        (dw_ref,) = torch.autograd.grad(y, [wr], bf16r(dy))
+        To = y.shape[2]
+        ws = torch.zeros(lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, To, KS), device=dev)
+        dW = torch.zeros(Cout, Cin, KS, device=dev)
+        db = torch.zeros(Cout, device=dev)
+        xd, dyd = x.to(dev), dy.to(dev)
+        assert lib.avc_conv1d_wgrad(P(xd), xd.stride(0), xd.stride(1), 1, P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cin, Cout,
+                                    T, To, KS, stride, P(dW), P(db), P(ws), None) == 0
+        torch.testing.assert_close(dW.cpu(), dw_ref, rtol=1e-4, atol=1e-5 * max(1.0, dw_ref.abs().max().item()))
+        torch.testing.assert_close(db.cpu(), dy.sum((0, 2)), rtol=1e-4, atol=1e-4)   # the bias gradient stays fp32
+        # dgrad
+        xg = x.clone().requires_grad_(True)
+        (dx_ref,) = torch.autograd.grad(O.pad_conv(xg, w, None, stride), [xg], dy)
+        wpd = pack(lib, dev, [w.to(dev)], 1)
+        dx = torch.zeros(B, Cin, T, device=dev)
+        assert lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cout, To, P(wpd), Cin, KS, stride, T, P(dx),
+                                    dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, 0, None) == 0
+        err = ((dx.cpu() - dx_ref).norm() / dx_ref.norm()).item()
+        assert 1e-5 < err < 1e-2, err
+    finally:
+        lib.avc_set_op_compute_dtype(0)
