@@ -214,8 +214,9 @@ def main():
             print(json.dumps({"metric": "utterances/sec one-shot conversion (AE.inference)", "value": world * B * a.steps / el,
                               "unit": "utterances/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"BASELINE configs[3]: AE.inference, {a.mels}-mel x {T}-frame source and target, batch {B}/GPU, fp32"}}),
+                              "dtype": a.dtype, "data": "synthetic",
+                              "config": {"workload": f"BASELINE configs[3]: AE.inference, {a.mels}-mel x {T}-frame source and target, batch {B}/GPU, "
+                                                     + ("fp32" if a.dtype == "f32" else "bf16 matrix products (fp32 storage)")}}),
                   flush=True)
         if world > 1:
             dist.destroy_process_group()
