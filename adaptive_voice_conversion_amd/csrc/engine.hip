@@ -480,6 +480,8 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
 // fork/join helpers: `side` runs one independent branch while the caller's stream runs the other
 static int g_force_single = 0;
 extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
+static int g_dec_split_min = 0;  // smallest batch whose decoder forward runs as two half-batch chains (0 = default 32 / env)
+extern "C" void avc_set_decoder_split_min(int n) { g_dec_split_min = n < 2 ? 2 : n; }
 
 extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
     if (!p || (dtype != AVC_COMPUTE_F32 && dtype != AVC_COMPUTE_BF16)) return fail(-1, "avc_plan_set_compute_dtype: dtype must be 0 (fp32) or 1 (bf16 operands)");
@@ -809,9 +811,12 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
 }
 
 static int in_fwd(const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
-                  int res_mode, int Tres, float* out, float* stats, hipStream_t s) {
+                  int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0) {
+    // stats = [mean[Bfull*C] | rstd[Bfull*C]]; a sub-batch launch (b0, Bn) of a Bfull-sample tensor passes
+    // y/out/res/cond already offset to sample b0
+    if (Bfull == 0) Bfull = Bn;
     INFwdArgs a;
-    a.y = y; a.out = out; a.mean = stats; a.rstd = stats + (long)Bn * C;
+    a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
     a.R = Bn * C; a.C = C; a.T = T; a.relu = 1;
@@ -970,26 +975,51 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
             RUN(avc_launch_conv(a, s, 0));
         }
-        {
-            ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z, (long)Cz * Tb, Tb, 1, B, Tb, ws + d.y0, (long)C * Tb, Tb, 1, 0);
-            RUN(avc_launch_conv(a, s, 0));
-            RUN(in_fwd(ws + d.y0, B, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0], ws + d.st0, s));
+        // The decoder is one serial chain of ~40 small kernels (T_l = 16..128): alone on the GPU it leaves
+        // most CUs waiting on launch / pipeline latency (0.86 ms with one kernel in flight, traced).  Two
+        // half-batch chains on two streams interleave their phases; every tensor is [B, ...], so a half is
+        // a pointer offset.
+        auto dec_chain = [&](int b0, int Bn, hipStream_t s) -> int {
+            const long oz = (long)b0 * Cz * Tb, ob0 = (long)b0 * C * Tb;
+            const float* cond = ws + d.cond + (long)b0 * csb;
+            {
+                ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
+                RUN(avc_launch_conv(a, s, 0));
+                RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
+            }
+            for (int l = 0; l < d.n; ++l) {
+                const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
+                const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
+                ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
+                RUN(avc_launch_conv(a, s, 0));
+                RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
+                // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
+                ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
+                b.ops = up;
+                RUN(avc_launch_conv(b, s, 0));
+                RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                           ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
+            }
+            const int To = p->Tout;
+            ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
+                                ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
+            RUN(avc_launch_conv(o, s, 0));
+            return 0;
+        };
+        if (g_dec_split_min == 0) {
+            const char* e = getenv("AVC_DEC_SPLIT_MIN");
+            g_dec_split_min = e ? atoi(e) : 32;
+            if (g_dec_split_min < 2) g_dec_split_min = 2;
         }
-        for (int l = 0; l < d.n; ++l) {
-            const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
-            ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + d.y1[l], (long)C * Ti, Ti, 1, 0);
-            RUN(avc_launch_conv(a, s, 0));
-            RUN(in_fwd(ws + d.y1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l], ws + d.st1[l], s));
-            // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
-            ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + d.y2[l], (long)C * To, To, 1, 0);
-            b.ops = up;
-            RUN(avc_launch_conv(b, s, 0));
-            RUN(in_fwd(ws + d.y2[l], B, C, To, ws + d.cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l], up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
-                       ws + d.out[l + 1], ws + d.st2[l], s));
+        if (B >= g_dec_split_min && side_ready(p)) {
+            const int Bh = B / 2;
+            const hipStream_t s2 = fork_side(p, s);
+            RUN(dec_chain(0, Bh, s));
+            RUN(dec_chain(Bh, B - Bh, s2));
+            join_side(p, s, s2);
+        } else {
+            RUN(dec_chain(0, B, s));
         }
-        const int To = p->Tout;
-        ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n], (long)C * To, To, 1, B, To, ws + p->decb, (long)p->M * To, To, 1, 0);
-        RUN(avc_launch_conv(o, s, 0));
     }
     return 0;
 }

@@ -86,6 +86,10 @@ int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 /* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
 void avc_set_single_stream(int on);
 
+/* smallest batch whose decoder forward is issued as two half-batch kernel chains on two streams
+ * (default 32; tuning / test knob, results are the same function either way) */
+void avc_set_decoder_split_min(int n);
+
 /* Compute dtype of the Conv1d / Linear matrix products (BASELINE config 3: "bf16 compute, fp32 master
  * and optimizer state").  0 = fp32 MFMA, bit-exact fp32 arithmetic (default, the reference's precision);
  * 1 = operands rounded to bf16 (round-to-nearest-even) when they enter the matrix core, fp32 accumulate.

@@ -320,3 +320,33 @@ def test_bf16_compute_mode_vs_fp32_oracle(kind, cfgname, B, T):
           f"oracle's own branch cosine {cos_r:.5f} rel-L2 {rel_l2(g, gr):.3e}")
     assert cos_m > 0.995 and rel_l2(g, gm) < 1e-1   # measured: 0.998 / 6e-2 on the tiny net, closer on the stock one
     assert cos_r > 0.98
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 33, 64, marks=GPU)])
+def test_decoder_forward_as_two_half_batch_chains(kind, cfgname, B, T):
+    """Large batches run the decoder forward as two half-batch kernel chains on two streams
+    (engine.hip); every tensor is [B, ...] so the split is a pointer offset.  Same function."""
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 2)
+    x, eps = O.make_inputs(cfg, B, T, 2)
+    plan = Plan(cfg, B, T, lib=lib)
+    params = flat_params(plan, sd, dev)
+    outs, _ = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    res = []
+    try:
+        for split_min in (10 ** 6, 2):
+            lib.avc_set_decoder_split_min(split_min)
+            ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+            plan.forward(params, x.to(dev), None, eps.to(dev), ws)
+            res.append(plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu().clone())
+            torch.testing.assert_close(res[-1], outs["dec"], rtol=1e-4, atol=2e-5)
+            grads = torch.full((plan.param_floats,), float("nan"), device=dev)
+            plan.loss(x.to(dev), 10.0, ws)
+            plan.backward(params, x.to(dev), None, eps.to(dev), grads, ws, lambda_kl=1.0)   # consumes the split forward's saved tensors
+            assert torch.isfinite(grads).all()
+            res.append(grads.cpu().clone())
+    finally:
+        lib.avc_set_decoder_split_min(32)
+    torch.testing.assert_close(res[0], res[2], rtol=1e-5, atol=1e-6)
+    assert ((res[1] - res[3]).norm() / res[1].norm()).item() < 1e-3
