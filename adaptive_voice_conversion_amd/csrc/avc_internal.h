@@ -59,3 +59,6 @@ struct ProfScope {
 };
 int avc_launch_dense(const DenseArgs& a, int backward, hipStream_t s);
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);
+
+void avc_set_conv_ablation(int bits);
+void avc_set_wgrad_ablation(int bits);

@@ -527,13 +527,14 @@ static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid
     else hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
 }
 
+// ablation bits of scripts/conv_ablate.py (timing experiments; results are wrong by construction when set)
+static int g_conv_ablation = 0;
+void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
+
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     ConvArgs a = a_in;
-    {
-        const char* e = getenv("AVC_CONV_DBG");
-        a.dbg = e ? atoi(e) : 0;
-    }
+    a.dbg = g_conv_ablation;
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
     if (a.Mp % 128 != 0) return -2;
     for (int gi = 0; gi < a.ngroups; ++gi)

@@ -444,12 +444,13 @@ static int launch_wgrad_ks(const WgradArgs& a, int nsplit, int WCO, hipStream_t 
     return WCO == 4 ? launch_wgrad_t<KS, 1, 4>(a, nsplit, stream) : launch_wgrad_t<KS, 1, 2>(a, nsplit, stream);
 }
 
+// ablation bits of scripts/wgrad_ablate.py (timing experiments; results are wrong by construction when set)
+static int g_wgrad_ablation = 0;
+void avc_set_wgrad_ablation(int bits) { g_wgrad_ablation = bits; }
+
 int avc_launch_wgrad(const WgradArgs& a_in, int nsplit, hipStream_t stream) {
     WgradArgs a = a_in;
-    {
-        const char* e = getenv("AVC_WGRAD_DBG");
-        a.dbg = e ? atoi(e) : 0;
-    }
+    a.dbg = g_wgrad_ablation;
     if (a.KS < 1 || a.KS > 8 || a.ngroups > AVC_WGRAD_MAXG) return -1;
     if (a.padL >= a.Tin) return -6;
     int NB, WCO;

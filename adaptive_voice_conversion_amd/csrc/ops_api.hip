@@ -12,6 +12,11 @@ extern "C" {
 
 // compute dtype of the op-level conv entry points (the whole-model path takes it from the plan)
 static int g_op_compute = AVC_COMPUTE_F32;
+// diagnostics: main-loop ablation switches of the conv / wgrad kernels (scripts/*_ablate.py); 0 = off
+void avc_set_debug_ablation(int conv_bits, int wgrad_bits) {
+    avc_set_conv_ablation(conv_bits);
+    avc_set_wgrad_ablation(wgrad_bits);
+}
 void avc_set_op_compute_dtype(int dtype) { g_op_compute = (dtype == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; }
 
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {

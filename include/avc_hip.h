@@ -17,7 +17,9 @@
  *  - return value: 0 = ok, < 0 = bad argument / unsupported shape,
  *    > 0 = hipError_t.  avc_last_error() describes the last failure.
  *  - re-entrant; the stream is always an argument (backward runs on PyTorch's
- *    autograd thread).
+ *    autograd thread).  The only process-wide state are the
+ *    diagnostic / tuning knobs set by the avc_set_* functions below (defaults:
+ *    all off), which must not be changed while another thread is inside the library.
  */
 #ifndef AVC_HIP_H
 #define AVC_HIP_H
@@ -85,6 +87,11 @@ int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 
 /* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
 void avc_set_single_stream(int on);
+
+/* diagnostics only: ablation bits of the conv / wgrad main loops for the timing experiments of
+ * scripts/conv_ablate.py and scripts/wgrad_ablate.py (bit0 no DMA, bit1 no MFMA, bit2 no barrier,
+ * bit3 no epilogue store).  Non-zero bits produce WRONG results by construction; default 0. */
+void avc_set_debug_ablation(int conv_bits, int wgrad_bits);
 
 /* smallest batch whose decoder forward is issued as two half-batch kernel chains on two streams
  * (default 32; tuning / test knob, results are the same function either way) */
