@@ -56,6 +56,8 @@ def declare(lib):
     lib.avc_plan_compute_dtype.argtypes = [c_void_p]
     lib.avc_set_op_compute_dtype.argtypes = [c_int]
     lib.avc_set_decoder_split_min.argtypes = [c_int]
+    lib.avc_set_in_fusion.argtypes = [c_int]
+    lib.avc_set_in_fusion.restype = None
     lib.avc_set_debug_ablation.argtypes = [c_int, c_int]
     lib.avc_set_debug_ablation.restype = None
     lib.avc_set_decoder_split_min.restype = None

@@ -63,7 +63,16 @@ struct ConvArgs {
     int ngroups;
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16; // AVC_COMPUTE_*
-    int pad2_;
+    // fused InstanceNorm epilogue (64x64 tile, Tout in {16, 32, 64}: every (b, m) row is complete inside the
+    // tile): g[0].out <- conv + bias (y, kept for the backward), in_out <- relu(IN(y) * gamma + beta) [+ residual],
+    // in_mean / in_rstd <- row statistics (index b * in_C + m)
+    int in_fuse;
+    const float* in_cond;  // AdaIN affine [B][in_cond_sb]: beta = [off + m], gamma = [off + in_C + m]; null = plain IN
+    long in_cond_sb;
+    int in_cond_off, in_C;
+    float* in_out;
+    float* in_mean;
+    float* in_rstd;
     ConvGroup g[AVC_MAX_GROUPS];
 };
 
@@ -187,6 +196,13 @@ static __device__ __forceinline__ void avc_glds16_s(const float* sbase, unsigned
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+#define AVC_IN_EPS 1e-5f
+// x_hat and the ReLU pre-activation of the InstanceNorm family are computed by the SAME explicitly
+// rounded sequence wherever they appear (row kernels forward and backward, fused conv epilogue), so a
+// recomputed ReLU mask is bit-identical to the forward decision whatever the compiler contracts.
+static __device__ __forceinline__ float in_xhat(float y, float mean, float rstd) { return __fmul_rn(__fsub_rn(y, mean), rstd); }
+static __device__ __forceinline__ float in_preact(float xh, float gamma, float beta) { return __fmaf_rn(xh, gamma, beta); }
 
 // four fp32 -> four bf16 (round to nearest even), packed as the A/B operand of v_mfma_f32_32x32x8_bf16:
 // slot j of lane-half h carries reduction index k = 2j + h in BOTH operands (any bijection works as

@@ -177,7 +177,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
 // runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
 // summed through LDS in a fixed order at the end (deterministic).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool INF = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -373,6 +373,75 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     // ---- epilogue
     if (a.dbg & 8) return;
+    if constexpr (INF && WM == 1 && WN == 1) {  // (its own instantiation: the row statistics cost ~90 registers)
+        {
+            // Fused InstanceNorm (+ AdaIN affine + ReLU + residual): the tile holds whole (b, m) rows
+            // (Tout = 16 / 32: inside one wave's 32 columns; 64: the two wave_n halves, joined through LDS).
+            // Two-pass statistics like the row kernel; the normalise step is the shared in_xhat / in_preact.
+            const bool v = colv[0];
+            const int b = colb[0], t = colt[0];
+            const int G = Tout < 32 ? Tout : 32;
+            const float invT = 1.0f / (float)Tout;
+            float* red = smem + KG * 4 * 1024;  // behind the split-K exchange area: [pass][wave_m][wave_n][32 rows]
+            float val[16], mean[16], rstd[16];
+            auto row_total = [&](float (&x)[16], int pass) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = x[r];
+                    for (int o = G >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+                    x[r] = s;
+                }
+                if (Tout == 64) {
+                    float* rp = red + pass * 128 + wave_m * 64;
+                    if (li == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rp[wave_n * 32 + h * 16 + r] = x[r];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] = rp[h * 16 + r] + rp[32 + h * 16 + r];
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_tile0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                val[r] = acc[0][0][r] + ((g.bias && m < a.M) ? g.bias[m] : 0.f);
+                mean[r] = v ? val[r] : 0.f;
+            }
+            row_total(mean, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mean[r] *= invT;
+                const float d = v ? val[r] - mean[r] : 0.f;
+                rstd[r] = d * d;
+            }
+            row_total(rstd, 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rstd[r] = 1.0f / sqrtf(rstd[r] * invT + AVC_IN_EPS);  // biased variance
+            if (!v) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_tile0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= a.M) continue;
+                const long o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
+                g.out[o] = val[r];
+                float gamma = 1.f, beta = 0.f;
+                if (a.in_cond) {
+                    const float* cr = a.in_cond + (long)b * a.in_cond_sb + a.in_cond_off;
+                    beta = cr[m];
+                    gamma = cr[a.in_C + m];
+                }
+                float w = fmaxf(in_preact(in_xhat(val[r], mean[r], rstd[r]), gamma, beta), 0.f);
+                if (a.res_mode != AVC_RES_NONE) w += conv_load_res(a, g.res, b, m, t);
+                a.in_out[o] = w;
+                if (t == 0) {
+                    a.in_mean[(long)b * a.in_C + m] = mean[r];
+                    a.in_rstd[(long)b * a.in_C + m] = rstd[r];
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         if (!colv[wn]) continue;
@@ -516,6 +585,13 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
     return avc_cdiv(a.B, spt);
 }
 
+template <int KG, bool BF>
+static void conv_launch_infuse(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, BF, true>), grid, block, lds, stream, a);
+}
+
 template <int WM, int WN, int KG, bool BF>
 static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
@@ -548,12 +624,19 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
         if (a.g[gi].CK % 8 != 0) return -2;
         if (q.ROW > 64 * AVC_CONV_NJ) return -3;
     }
+    if (a.in_fuse && !(tile == 11 && a.mode == 0 && a.ops == 1 && a.ngroups == 1 && a.ot == 1 && (a.Tout == 16 || a.Tout == 32 || a.Tout == 64) &&
+                       a.g[0].out && a.in_out && a.in_mean && a.in_rstd))
+        return -7;
     size_t lds = conv_lds_bytes(a, BM, BN);
     dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
     // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
     int kgroups = 1;
     if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= 256 && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
+    if (a.in_fuse) {  // row-statistics exchange area behind the split-K exchange area
+        size_t need = ((size_t)kgroups * 4096 + 256) * 4;
+        lds = lds > need ? lds : need;
+    }
     if (lds > 160 * 1024) return -5;
     dim3 block(AVC_THREADS * kgroups);
     double flops = 0;
@@ -569,7 +652,11 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
         if (bf) conv_launch_variant<WM_, WN_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
         else conv_launch_variant<WM_, WN_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
     } while (0)
-    if (tile == 22) AVC_LAUNCH_CONV(2, 2, 1);
+    if (a.in_fuse) {  // (validated above: 64x64 tile, forward)
+        const int f = fast == 4 ? 0 : fast;
+        if (kgroups == 2) { if (bf) conv_launch_infuse<2, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<2, false>(a, f, grid, block, lds, stream); }
+        else { if (bf) conv_launch_infuse<1, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<1, false>(a, f, grid, block, lds, stream); }
+    } else if (tile == 22) AVC_LAUNCH_CONV(2, 2, 1);
     else if (tile == 21) AVC_LAUNCH_CONV(2, 1, 1);
     else if (kgroups == 2) AVC_LAUNCH_CONV(1, 1, 2);
     else AVC_LAUNCH_CONV(1, 1, 1);

@@ -480,6 +480,8 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
 // fork/join helpers: `side` runs one independent branch while the caller's stream runs the other
 static int g_force_single = 0;
 extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
+static int g_no_in_fusion = 1;  // 1 = InstanceNorm always as its own row kernel (default: the fused epilogue measured slower)
+extern "C" void avc_set_in_fusion(int on) { g_no_in_fusion = on ? 0 : 1; }
 static int g_dec_split_min = 0;  // smallest batch whose decoder forward runs as two half-batch chains (0 = default 32 / env)
 extern "C" void avc_set_decoder_split_min(int n) { g_dec_split_min = n < 2 ? 2 : n; }
 
@@ -833,6 +835,28 @@ static int in_bwd(const float* g, const float* y, const float* stats, int Bn, in
     return avc_launch_in_bwd(a, s);
 }
 
+// InstanceNorm fused into the producing conv's epilogue where a 64x64 tile holds whole rows
+// (conv_gemm.hip): returns true and fills the epilogue fields, or false (caller launches in_fwd).
+static bool fuse_in(ConvArgs& a, const LayerP& L, int Bn, int C, const float* cond, long cond_sb, int cond_off, const float* res,
+                    int res_mode, long rb, int Tres, float* out, float* stats, int Bfull, int b0) {
+    if (g_no_in_fusion) return false;
+    const int T = a.Tout;
+    if (!(T == 16 || T == 32 || T == 64) || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
+    if (avc_conv_pick_tile(a.Mp, Bn, T, 1) != 11) return false;
+    if (res && !(res_mode == AVC_RES_IDENTITY || res_mode == AVC_RES_AVGPOOL2)) return false;
+    a.in_fuse = 1;
+    a.in_cond = cond; a.in_cond_sb = cond_sb; a.in_cond_off = cond_off; a.in_C = C;
+    a.in_out = out;
+    a.in_mean = stats + (long)b0 * C;
+    a.in_rstd = stats + (long)Bfull * C + (long)b0 * C;
+    if (res) {
+        a.g[0].res = res;
+        a.res_mode = res_mode;
+        a.rb = rb; a.rc = Tres; a.rt = 1; a.Tres = Tres;
+    }
+    return true;
+}
+
 // --------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------
@@ -952,12 +976,14 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
+            const bool f1 = fuse_in(a, p->layers[e.c1[l]], B, C, nullptr, 0, 0, nullptr, 0, 0, 0, ws + e.a1[l], ws + e.st1[l], B, 0);
             RUN(avc_launch_conv(a, s, 0));
-            RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
+            if (!f1) RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
             ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
+            const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
+            const bool f2 = fuse_in(b, p->layers[e.c2[l]], B, C, nullptr, 0, 0, ws + e.out[l], rmode, (long)C * Ti, Ti, ws + e.out[l + 1], ws + e.st2[l], B, 0);
             RUN(avc_launch_conv(b, s, 0));
-            RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, Ti,
-                       ws + e.out[l + 1], ws + e.st2[l], s));
+            if (!f2) RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
         }
         const int Tb = p->Tb;
         ConvArgs h = mk_fwd(p, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
@@ -984,21 +1010,25 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             const float* cond = ws + d.cond + (long)b0 * csb;
             {
                 ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
+                const bool f0 = fuse_in(a, p->layers[d.in_conv], Bn, C, nullptr, 0, 0, nullptr, 0, 0, 0, ws + d.out[0] + ob0, ws + d.st0, B, b0);
                 RUN(avc_launch_conv(a, s, 0));
-                RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
+                if (!f0) RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
             }
             for (int l = 0; l < d.n; ++l) {
                 const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
                 const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
                 ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
+                const bool f1 = fuse_in(a, p->layers[d.c1[l]], Bn, C, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], B, b0);
                 RUN(avc_launch_conv(a, s, 0));
-                RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
+                if (!f1) RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
                 // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
                 ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
                 b.ops = up;
+                const bool f2 = up == 1 && fuse_in(b, p->layers[d.c2[l]], Bn, C, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, AVC_RES_IDENTITY,
+                                                   (long)C * Ti, Ti, ws + d.out[l + 1] + oo, ws + d.st2[l], B, b0);
                 RUN(avc_launch_conv(b, s, 0));
-                RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
-                           ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
+                if (!f2) RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                                    ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
             }
             const int To = p->Tout;
             ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,

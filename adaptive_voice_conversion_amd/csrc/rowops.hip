@@ -16,13 +16,7 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 
-#define AVC_IN_EPS 1e-5f
-
-// x_hat and the ReLU pre-activation are computed by the SAME explicitly rounded sequence in the
-// forward and in the backward kernels, so the recomputed ReLU mask is bit-identical to the
-// forward decision (no reliance on the compiler's fma contraction choices).
-static __device__ __forceinline__ float in_xhat(float y, float mean, float rstd) { return __fmul_rn(__fsub_rn(y, mean), rstd); }
-static __device__ __forceinline__ float in_preact(float xh, float gamma, float beta) { return __fmaf_rn(xh, gamma, beta); }
+// (in_xhat / in_preact / AVC_IN_EPS: avc_common.h, shared with the fused conv epilogue)
 
 template <int LPR>
 static __device__ __forceinline__ float group_sum(float v) {

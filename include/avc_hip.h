@@ -93,6 +93,11 @@ void avc_set_single_stream(int on);
  * bit3 no epilogue store).  Non-zero bits produce WRONG results by construction; default 0. */
 void avc_set_debug_ablation(int conv_bits, int wgrad_bits);
 
+/* 1 = InstanceNorm / AdaIN / ReLU of rows that fit one conv tile (T_l = 16, 32, 64) run in the producing
+ * conv's epilogue; 0 (default) = always as their own row kernels.  Experimental: same results, but the
+ * fused epilogue measured 2-4 % slower end to end on MI355X than the stand-alone row kernels. */
+void avc_set_in_fusion(int on);
+
 /* smallest batch whose decoder forward is issued as two half-batch kernel chains on two streams
  * (default 32; tuning / test knob, results are the same function either way) */
 void avc_set_decoder_split_min(int n);

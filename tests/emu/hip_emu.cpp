@@ -20,7 +20,7 @@ ucontext_t g_sched;
 std::vector<Fiber> g_fibers;
 char* g_stacks = nullptr;
 const std::function<void()>* g_body = nullptr;
-int g_cur = 0, g_nthreads = 0;
+int g_cur = 0, g_nthreads = 0, g_alive = 0;
 long g_progress = 0;
 int g_bar_count = 0;
 long g_bar_gen = 0;
@@ -42,6 +42,12 @@ void trampoline() {
     (*g_body)();
     g_fibers[g_cur].done = true;
     ++g_progress;
+    // as on the hardware, a finished wave no longer takes part in s_barrier
+    --g_alive;
+    if (g_bar_count > 0 && g_bar_count >= g_alive) {
+        g_bar_count = 0;
+        ++g_bar_gen;
+    }
     swapcontext(&g_fibers[g_cur].ctx, &g_sched);
 }
 }  // namespace
@@ -57,7 +63,7 @@ void* dyn_smem() { return g_smem.data(); }
 void block_barrier() {
     long gen = g_bar_gen;
     ++g_progress;
-    if (++g_bar_count == g_nthreads) {
+    if (++g_bar_count >= g_alive) {
         g_bar_count = 0;
         ++g_bar_gen;
     } else {
@@ -102,6 +108,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
                     memcpy(&g_smem[i], &nan, 4);
                 }
                 g_bar_count = 0;
+                g_alive = nt;
                 for (auto& c : g_wave_count) c = 0;
                 for (int i = 0; i < nt; ++i) {
                     getcontext(&g_fibers[i].ctx);

@@ -350,3 +350,30 @@ def test_decoder_forward_as_two_half_batch_chains(kind, cfgname, B, T):
         lib.avc_set_decoder_split_min(32)
     torch.testing.assert_close(res[0], res[2], rtol=1e-5, atol=1e-6)
     assert ((res[1] - res[3]).norm() / res[1].norm()).item() < 1e-3
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 2, 64), pytest.param("gpu", "m80", 4, 128, marks=GPU)])
+def test_instnorm_fused_into_conv_epilogue_is_the_same_function(kind, cfgname, B, T):
+    """avc_set_in_fusion(1) (experimental, off by default): InstanceNorm / AdaIN / ReLU / residual of rows
+    that fit one conv tile (T_l = 16 / 32 inside a wave, 64 across the two wave halves) computed in the
+    producing conv's epilogue.  Must match the oracle like the default path, forward and backward."""
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 5)
+    x, eps = O.make_inputs(cfg, B, T, 5)
+    plan = Plan(cfg, B, T, lib=lib)
+    params = flat_params(plan, sd, dev)
+    outs, _ = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    lib.avc_set_in_fusion(1)
+    try:
+        ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+        plan.forward(params, x.to(dev), None, eps.to(dev), ws)
+        dec = plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu()
+        torch.testing.assert_close(dec, outs["dec"], rtol=1e-4, atol=2e-5)
+        plan.loss(x.to(dev), cfg["lambda"]["lambda_rec"], ws)
+        grads = torch.full((plan.param_floats,), float("nan"), device=dev)
+        plan.backward(params, x.to(dev), None, eps.to(dev), grads, ws, lambda_kl=1.0)
+        _, grads_m = branch_matched_oracle(plan, ws, x, eps, sd, cfg)
+        check_grads(plan, grads, grads_m, tol=1e-4, cfg=cfg)
+    finally:
+        lib.avc_set_in_fusion(0)
