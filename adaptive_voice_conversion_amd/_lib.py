@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libavc_hip.so")
 _lib = None
 
 MAX_BLOCKS = 8
+PLAN_INFERENCE, PLAN_SPEAKER_ONLY = 1, 2
+GRADS_ALL, GRADS_DECODER, GRADS_ENCODERS = 0, 1, 2
 
 
 class EncoderCfg(ctypes.Structure):
@@ -40,6 +42,14 @@ def declare(lib):
     lib.avc_version.restype = c_int
     lib.avc_last_error.restype = ctypes.c_char_p
     lib.avc_plan_create.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.avc_plan_create_ex.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.avc_plan_flags.argtypes = [c_void_p]
+    lib.avc_plan_param_range.argtypes = [c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
+    lib.avc_plan_stream_wait_grads.argtypes = [c_void_p, c_int, c_void_p]
+    lib.avc_set_tuning.argtypes = [ctypes.c_char_p, c_int]
+    lib.avc_set_single_stream.argtypes = [c_int]
+    lib.avc_set_single_stream.restype = None
+    lib.avc_gather_segments.argtypes = [c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.avc_plan_destroy.argtypes = [c_void_p]
     lib.avc_plan_destroy.restype = None
     lib.avc_plan_num_params.argtypes = [c_void_p]

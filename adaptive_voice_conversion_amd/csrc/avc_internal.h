@@ -58,7 +58,12 @@ struct ProfScope {
     hipStream_t s_;
 };
 int avc_launch_dense(const DenseArgs& a, int backward, hipStream_t s);
+int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out,
+                               hipStream_t s);
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);
 
+void avc_set_conv_ck5(int ck);
+void avc_set_wgrad_target_wgs(int n);
+void avc_set_in_variant(int v);
 void avc_set_conv_ablation(int bits);
 void avc_set_wgrad_ablation(int bits);

@@ -526,14 +526,9 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
-extern "C" int avc_conv_ck(int KS) {
-    static int ck5 = -1;
-    if (ck5 < 0) {
-        const char* e = getenv("AVC_CONV_CK5");  // micro-benchmark knob: chunk depth of the k >= 4 layers at the op level
-        ck5 = e ? atoi(e) : 8;
-    }
-    return KS >= 4 ? ck5 : (KS >= 2 ? 16 : 32);
-}
+static int g_conv_ck5 = 8;  // chunk depth of the k >= 4 layers at the op level (micro-benchmark knob, avc_set_tuning)
+void avc_set_conv_ck5(int ck) { g_conv_ck5 = (ck == 8 || ck == 16 || ck == 32) ? ck : 8; }
+extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? g_conv_ck5 : (KS >= 2 ? 16 : 32); }
 
 // tile choice shared by the launcher and the plan (which sizes CK from it)
 int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {

@@ -386,6 +386,9 @@ static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
     }
 }
 
+static int g_wgrad_target_wgs = 256;  // workgroups per launch the split-K aims for (avc_set_tuning)
+void avc_set_wgrad_target_wgs(int n) { g_wgrad_target_wgs = n >= 1 ? n : 256; }
+
 void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit) {
     if (Tout >= 32) {
@@ -406,13 +409,7 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* sp
     int NB, WCO;
     wgrad_shape(Cin, Cout, KS, &NB, &WCO);
     int tiles = avc_cdiv(Cout, 32 * WCO) * avc_cdiv(Cin, 32 * NB * (4 / WCO));
-    static int target_wgs = 0;
-    if (target_wgs == 0) {
-        const char* e = getenv("AVC_WGRAD_WGS");  // tuning knob (workgroups per launch the split-K aims for)
-        target_wgs = e ? atoi(e) : 256;
-        if (target_wgs < 1) target_wgs = 256;
-    }
-    int want = target_wgs / tiles;
+    int want = g_wgrad_target_wgs / tiles;
     if (want < 1) want = 1;
     int maxsplit = avc_cdiv(*total_chunks, 4);
     if (want > maxsplit) want = maxsplit;

@@ -41,7 +41,6 @@ static int fail(int rc, const char* what) {
 extern "C" const char* avc_last_error(void) { return g_err.c_str(); }
 extern "C" int avc_version(void) { return 100; }
 
-#define AVC_MAX_WEV 192
 
 struct ParamT {
     long off, numel;
@@ -94,15 +93,15 @@ struct avc_plan {
     long ws_top = 0;
     std::map<std::string, long> named;
     // shared gradient temporaries
-    long gA = -1, gB = -1, gC = -1, dyA = -1, dyB = -1;
+    long gA = -1, gB = -1, gC = -1;
     long muls = -1, dmuls = -1, emb = -1, demb = -1, decb = -1, ddec = -1, dz = -1;
     long losses = -1, loss_partial = -1;
     long slab = -1, slab_floats = 0;
-    long dhA = -1, dhB = -1, dzA = -1, dzB = -1;
+    long dhA = -1;
     std::vector<avc_relu_site> sites;
     // second gradient-temporary set + side stream: the speaker and content encoders are independent
     // branches (model.py:381-382) and run concurrently so that their small-T layers fill the chip
-    long gA2 = -1, gB2 = -1, gC2 = -1, dyA2 = -1, dyB2 = -1;
+    long gA2 = -1, gB2 = -1, gC2 = -1;
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int compute = 0;             // AVC_COMPUTE_*
@@ -110,10 +109,15 @@ struct avc_plan {
     // weight-gradient kernels depend on nothing downstream: they run on their own (low priority)
     // streams beside the dgrad / InstanceNorm-backward chain of each branch
     mutable hipStream_t wstream[2] = {nullptr, nullptr};
-    mutable hipEvent_t wev[AVC_MAX_WEV];
+    mutable std::vector<hipEvent_t> wev;   // sized by the dry run of the backward pass (one per ordering edge)
     mutable hipEvent_t wjoin[2];
     mutable hipEvent_t ev_pack[2];
+    mutable hipEvent_t ev_dec_grads = nullptr;   // recorded when the decoder's parameter gradients are final
+    mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
+    int flags = 0;            // AVC_PLAN_*
+    int nev_need = 0;         // events one backward pass records on the wgrad streams
+    long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
 
     long alloc(long n) {
         long o = ws_top;
@@ -209,9 +213,18 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
     }
 }
 
+static void plan_init_streams(avc_plan* p);
+
 extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out) {
+    return avc_plan_create_ex(cfg, B, T, T_cond, 0, out);
+}
+
+extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, avc_plan** out) {
     if (!cfg || !out || B < 1 || T < 1) return fail(-1, "avc_plan_create: bad arguments");
+    if (flags & ~(AVC_PLAN_INFERENCE | AVC_PLAN_SPEAKER_ONLY)) return fail(-1, "avc_plan_create_ex: unknown flag");
+    if (flags & AVC_PLAN_SPEAKER_ONLY) flags |= AVC_PLAN_INFERENCE;
     if (T_cond <= 0) T_cond = T;
+    const bool infer = (flags & AVC_PLAN_INFERENCE) != 0, spk_only = (flags & AVC_PLAN_SPEAKER_ONLY) != 0;
     if (validate_enc(cfg->spk, true) || validate_enc(cfg->enc, false)) return fail(-2, "avc_plan_create: unsupported encoder config");
     const avc_decoder_cfg& dc = cfg->dec;
     if (dc.n_conv_blocks < 1 || dc.n_conv_blocks > AVC_MAX_BLOCKS || 2 * dc.n_conv_blocks > 12 || dc.kernel_size < 1 || dc.kernel_size > 8)
@@ -223,6 +236,7 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
 
     avc_plan* p = new avc_plan();
     p->cfg = *cfg;
+    p->flags = flags;
     p->B = B;
     p->T = T;
     p->Tc = T_cond;
@@ -234,6 +248,7 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     DecNet& d = p->dec;
     d.c = dc;
     d.n = dc.n_conv_blocks;
+    p->dec_param_off = p->param_floats;
     d.in_conv = add_layer(p, dc.c_h, dc.c_in, 1, 1, true);
     for (int l = 0; l < d.n; ++l) d.c1.push_back(add_layer(p, dc.c_h, dc.c_h, dc.kernel_size, 1, true));
     for (int l = 0; l < d.n; ++l) d.c2.push_back(add_layer(p, dc.c_h * dc.upsample[l], dc.c_h, dc.kernel_size, 1, true));
@@ -277,35 +292,40 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
     }
     p->Tout = d.T[d.n];
 
-    // ---- packed weights
+    // ---- packed weights (inference plans keep no dgrad images; speaker-only plans only the speaker encoder's)
+    const bool dg = !infer;
     for (EncNet* e : {&p->spk, &p->enc}) {
+        if (spk_only && e == &p->enc) continue;
         for (int id : e->bank) finish_layer(p, p->layers[id], false, 0, B, e->T[0], e->T[0], e->nb);
-        finish_layer(p, p->layers[e->in_conv], true, e->CC - e->c.c_in, B, e->T[0], e->T[0]);
+        finish_layer(p, p->layers[e->in_conv], dg, e->CC - e->c.c_in, B, e->T[0], e->T[0]);
         for (int l = 0; l < e->n; ++l) {
-            finish_layer(p, p->layers[e->c1[l]], true, 0, B, e->T[l], e->T[l]);
-            finish_layer(p, p->layers[e->c2[l]], true, 0, B, e->T[l + 1], e->T[l]);
+            finish_layer(p, p->layers[e->c1[l]], dg, 0, B, e->T[l], e->T[l]);
+            finish_layer(p, p->layers[e->c2[l]], dg, 0, B, e->T[l + 1], e->T[l]);
         }
     }
     for (int l = 0; l < p->spk.nd; ++l) {
-        finish_layer(p, p->layers[p->spk.dn1[l]], true, 0, 1, B, B);
-        finish_layer(p, p->layers[p->spk.dn2[l]], true, 0, 1, B, B);
+        finish_layer(p, p->layers[p->spk.dn1[l]], dg, 0, 1, B, B);
+        finish_layer(p, p->layers[p->spk.dn2[l]], dg, 0, 1, B, B);
     }
-    finish_layer(p, p->layers[p->spk.outl], true, 0, 1, B, B);
-    finish_layer(p, p->layers[p->enc.heads], true, 0, B, p->Tb, p->Tb);
-    finish_layer(p, p->layers[d.in_conv], true, 0, B, p->Tb, p->Tb);
-    for (int l = 0; l < d.n; ++l) {
-        finish_layer(p, p->layers[d.c1[l]], true, 0, B, d.T[l], d.T[l]);
-        finish_layer(p, p->layers[d.c2[l]], true, 0, B, d.T[l], d.T[l]);
+    finish_layer(p, p->layers[p->spk.outl], dg, 0, 1, B, B);
+    if (!spk_only) {
+        finish_layer(p, p->layers[p->enc.heads], dg, 0, B, p->Tb, p->Tb);
+        finish_layer(p, p->layers[d.in_conv], dg, 0, B, p->Tb, p->Tb);
+        for (int l = 0; l < d.n; ++l) {
+            finish_layer(p, p->layers[d.c1[l]], dg, 0, B, d.T[l], d.T[l]);
+            finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l]);
+        }
+        finish_layer(p, p->layers[d.affine], dg, 0, 1, B, B);
+        finish_layer(p, p->layers[d.out_conv], dg, 0, B, p->Tout, p->Tout);
     }
-    finish_layer(p, p->layers[d.affine], true, 0, 1, B, B);
-    finish_layer(p, p->layers[d.out_conv], true, 0, B, p->Tout, p->Tout);
 
-    // ---- activations
+    // ---- activations.  Inference plans (AVC_PLAN_INFERENCE) keep only what the forward pass touches;
+    // speaker-only plans (AVC_PLAN_SPEAKER_ONLY) only the speaker encoder's buffers.
     const long Bl = B;
     auto alloc_enc = [&](EncNet& e, bool spk) {
         const long C = e.c.c_h;
         e.cat = p->alloc(Bl * e.CC * e.T[0]);
-        e.dcat = p->alloc(Bl * e.CC * e.T[0]);
+        if (!infer) e.dcat = p->alloc(Bl * e.CC * e.T[0]);
         e.h0 = p->alloc(Bl * C * e.T[0]);
         e.out[0] = spk ? e.h0 : p->alloc(Bl * C * e.T[0]);
         if (!spk) e.st0 = p->alloc(2 * Bl * C);
@@ -334,75 +354,74 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
         }
     };
     alloc_enc(p->spk, true);
-    alloc_enc(p->enc, false);
     const long Cz = dc.c_in, Cd = dc.c_h;
-    p->muls = p->alloc(Bl * 2 * Cz * p->Tb);
-    p->dmuls = p->alloc(Bl * 2 * Cz * p->Tb);
     p->emb = p->alloc(Bl * dc.c_cond);
-    p->demb = p->alloc(Bl * dc.c_cond);
-    d.z = p->alloc(Bl * Cz * p->Tb);
-    p->dz = p->alloc(Bl * Cz * p->Tb);
-    d.cond = p->alloc(Bl * 2 * d.n * 2 * Cd);
-    d.dcond = p->alloc(Bl * 2 * d.n * 2 * Cd);
-    d.y0 = p->alloc(Bl * Cd * d.T[0]);
-    d.out[0] = p->alloc(Bl * Cd * d.T[0]);
-    d.st0 = p->alloc(2 * Bl * Cd);
-    for (int l = 0; l < d.n; ++l) {
-        d.y1[l] = p->alloc(Bl * Cd * d.T[l]);
-        d.a1[l] = p->alloc(Bl * Cd * d.T[l]);
-        d.y2[l] = p->alloc(Bl * Cd * d.T[l + 1]);
-        d.out[l + 1] = p->alloc(Bl * Cd * d.T[l + 1]);
-        d.st1[l] = p->alloc(2 * Bl * Cd);
-        d.st2[l] = p->alloc(2 * Bl * Cd);
+    if (!spk_only) {
+        alloc_enc(p->enc, false);
+        p->muls = p->alloc(Bl * 2 * Cz * p->Tb);
+        d.z = p->alloc(Bl * Cz * p->Tb);
+        d.cond = p->alloc(Bl * 2 * d.n * 2 * Cd);
+        d.y0 = p->alloc(Bl * Cd * d.T[0]);
+        d.out[0] = p->alloc(Bl * Cd * d.T[0]);
+        d.st0 = p->alloc(2 * Bl * Cd);
+        for (int l = 0; l < d.n; ++l) {
+            d.y1[l] = p->alloc(Bl * Cd * d.T[l]);
+            d.a1[l] = p->alloc(Bl * Cd * d.T[l]);
+            d.y2[l] = p->alloc(Bl * Cd * d.T[l + 1]);
+            d.out[l + 1] = p->alloc(Bl * Cd * d.T[l + 1]);
+            d.st1[l] = p->alloc(2 * Bl * Cd);
+            d.st2[l] = p->alloc(2 * Bl * Cd);
+        }
+        p->decb = p->alloc(Bl * p->M * p->Tout);
     }
-    p->decb = p->alloc(Bl * p->M * p->Tout);
-    p->ddec = p->alloc(Bl * p->M * p->Tout);
-    p->losses = p->alloc(64);
-    p->loss_partial = p->alloc(2 * 1024);
+    if (!infer) {
+        p->dmuls = p->alloc(Bl * 2 * Cz * p->Tb);
+        p->demb = p->alloc(Bl * dc.c_cond);
+        p->dz = p->alloc(Bl * Cz * p->Tb);
+        d.dcond = p->alloc(Bl * 2 * d.n * 2 * Cd);
+        p->ddec = p->alloc(Bl * p->M * p->Tout);
+        p->losses = p->alloc(64);
+        p->loss_partial = p->alloc(2 * 1024);
+        // ---- gradient temporaries (sized for the largest [B, C, T] they ever hold)
+        long maxCT = 0;
+        auto upd = [&](long c, long t) { maxCT = (c * t > maxCT) ? c * t : maxCT; };
+        for (int l = 0; l <= p->spk.n; ++l) upd(p->spk.c.c_h, p->spk.T[l]);
+        for (int l = 0; l <= p->enc.n; ++l) upd(p->enc.c.c_h, p->enc.T[l]);
+        for (int l = 0; l <= d.n; ++l) upd(Cd, d.T[l]);
+        upd(p->M, p->Tout);
+        p->gA = p->alloc(Bl * maxCT);
+        p->gB = p->alloc(Bl * maxCT);
+        p->gC = p->alloc(Bl * maxCT);
+        p->gA2 = p->alloc(Bl * maxCT);
+        p->gB2 = p->alloc(Bl * maxCT);
+        p->gC2 = p->alloc(Bl * maxCT);
+        p->dhA = p->alloc((long)p->spk.c.c_h * Bl);
+    }
 
-    // ---- gradient temporaries (sized for the largest [B, C, T] they ever hold)
-    long maxCT = 0;
-    auto upd = [&](long c, long t) { maxCT = (c * t > maxCT) ? c * t : maxCT; };
-    for (int l = 0; l <= p->spk.n; ++l) upd(p->spk.c.c_h, p->spk.T[l]);
-    for (int l = 0; l <= p->enc.n; ++l) upd(p->enc.c.c_h, p->enc.T[l]);
-    for (int l = 0; l <= d.n; ++l) upd(Cd, d.T[l]);
-    upd(p->M, p->Tout);
-    p->gA = p->alloc(Bl * maxCT);
-    p->gB = p->alloc(Bl * maxCT);
-    p->gC = p->alloc(Bl * maxCT);
-    p->dyA = p->alloc(Bl * maxCT);
-    p->dyB = p->alloc(Bl * maxCT);
-    p->gA2 = p->alloc(Bl * maxCT);
-    p->gB2 = p->alloc(Bl * maxCT);
-    p->gC2 = p->alloc(Bl * maxCT);
-    p->dyA2 = p->alloc(Bl * maxCT);
-    p->dyB2 = p->alloc(Bl * maxCT);
-    long Cs = p->spk.c.c_h;
-    p->dhA = p->alloc(Cs * Bl);
-    p->dhB = p->alloc(Cs * Bl);
-    p->dzA = p->alloc(Cs * Bl);
-    p->dzB = p->alloc(Cs * Bl);
-
-    p->named["muls"] = p->muls;
     p->named["emb"] = p->emb;
-    p->named["dec"] = p->decb;
-    p->named["z"] = d.z;
-    p->named["losses"] = p->losses;
-    p->named["d_dec"] = p->ddec;
-    p->named["cond"] = d.cond;
     p->named["spk_cat"] = p->spk.cat;
-    p->named["enc_cat"] = p->enc.cat;
-    p->named["enc_out0"] = p->enc.out[0];
     p->named["spk_out0"] = p->spk.out[0];
     p->named["spk_pooled"] = p->spk.pooled;
-    p->named["enc_outN"] = p->enc.out[p->enc.n];
     p->named["spk_outN"] = p->spk.out[p->spk.n];
-    p->named["dec_out0"] = d.out[0];
-    p->named["dec_outN"] = d.out[d.n];
-    p->named["d_z"] = p->dz;
-    p->named["d_muls"] = p->dmuls;
-    p->named["d_emb"] = p->demb;
-    p->named["d_cond"] = d.dcond;
+    if (!spk_only) {
+        p->named["muls"] = p->muls;
+        p->named["dec"] = p->decb;
+        p->named["z"] = d.z;
+        p->named["cond"] = d.cond;
+        p->named["enc_cat"] = p->enc.cat;
+        p->named["enc_out0"] = p->enc.out[0];
+        p->named["enc_outN"] = p->enc.out[p->enc.n];
+        p->named["dec_out0"] = d.out[0];
+        p->named["dec_outN"] = d.out[d.n];
+    }
+    if (!infer) {
+        p->named["losses"] = p->losses;
+        p->named["d_dec"] = p->ddec;
+        p->named["d_z"] = p->dz;
+        p->named["d_muls"] = p->dmuls;
+        p->named["d_emb"] = p->demb;
+        p->named["d_cond"] = d.dcond;
+    }
 
     // ---- ReLU site table in the reference's forward call order (avc_plan_relu_site)
     {
@@ -434,6 +453,7 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
         }
         const EncNet& en = p->enc;
         const int Ce_ = en.c.c_h;
+        if (!spk_only) {
         for (int g = 0; g < en.nb; ++g) conv_site(en.cat + (long)g * en.c.c_bank * en.T[0], B, en.c.c_bank, en.T[0], (long)en.CC * en.T[0], en.T[0], 1);
         in_site(en.h0, en.st0, Ce_, en.T[0], -1, 0);
         for (int l = 0; l < en.n; ++l) {
@@ -446,18 +466,25 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
             in_site(d.y1[l], d.st1[l], (int)Cd, d.T[l], d.cond + (long)(2 * l) * 2 * Cd, csb_);
             in_site(d.y2[l], d.st2[l], (int)Cd, d.T[l + 1], d.cond + (long)(2 * l + 1) * 2 * Cd, csb_);
         }
+        }
     }
 
-    // ---- split-K slabs: size them with a dry run of the backward pass
-    p->slab = p->ws_top;
-    long need[2] = {0, 0};
-    avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
-                      nullptr, nullptr, true, need);
-    p->slab_floats = need[0];
-    p->ws_top += (need[0] + 63) / 64 * 64;
-    p->dyarena = p->ws_top;
-    p->dyarena_floats = need[1];
-    p->ws_top += (need[1] + 63) / 64 * 64;
+    // ---- split-K slabs, dy arena and the event pool: sized with a dry run of the backward pass
+    if (!infer) {
+        p->slab = p->ws_top;
+        long need[3] = {0, 0, 0};
+        avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
+                          nullptr, nullptr, true, need);
+        p->slab_floats = need[0];
+        p->ws_top += (need[0] + 63) / 64 * 64;
+        p->dyarena = p->ws_top;
+        p->dyarena_floats = need[1];
+        p->ws_top += (need[1] + 63) / 64 * 64;
+        p->nev_need = (int)need[2];
+    }
+    // helper streams / events belong to the plan from here on (created on the device that is current NOW;
+    // a process without a GPU -- host-only plan queries -- simply gets a single-stream plan)
+    plan_init_streams(p);
     *out = p;
     return 0;
 }
@@ -472,7 +499,9 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
             hipEventDestroy(p->wjoin[i]);
             hipEventDestroy(p->ev_pack[i]);
         }
-        for (int i = 0; i < AVC_MAX_WEV; ++i) hipEventDestroy(p->wev[i]);
+        for (hipEvent_t e : p->wev) hipEventDestroy(e);
+        hipEventDestroy(p->ev_dec_grads);
+        hipEventDestroy(p->ev_all_grads);
     }
     delete p;
 }
@@ -482,7 +511,7 @@ static int g_force_single = 0;
 extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
 static int g_no_in_fusion = 1;  // 1 = InstanceNorm always as its own row kernel (default: the fused epilogue measured slower)
 extern "C" void avc_set_in_fusion(int on) { g_no_in_fusion = on ? 0 : 1; }
-static int g_dec_split_min = 0;  // smallest batch whose decoder forward runs as two half-batch chains (0 = default 32 / env)
+static int g_dec_split_min = 32;  // smallest batch whose decoder forward runs as two half-batch chains
 extern "C" void avc_set_decoder_split_min(int n) { g_dec_split_min = n < 2 ? 2 : n; }
 
 extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
@@ -493,31 +522,28 @@ extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
 }
 extern "C" int avc_plan_compute_dtype(const avc_plan* p) { return p ? p->compute : -1; }
 
-static bool side_ready(const avc_plan* p) {
-    if (g_force_single) return false;
-    if (p->side_state == 0) {
-        const char* e = getenv("AVC_SINGLE_STREAM");
-        if (e && e[0] == '1') {
-            p->side_state = -1;
-        } else if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess) {
-            int lo = 0, hi = 0;
-            hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
-            bool ok = true;
-            for (int i = 0; i < 2; ++i) {
-                ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
-                ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
-                ok = ok && hipEventCreateWithFlags(&p->ev_pack[i], hipEventDisableTiming) == hipSuccess;
-            }
-            for (int i = 0; i < AVC_MAX_WEV; ++i) ok = ok && hipEventCreateWithFlags(&p->wev[i], hipEventDisableTiming) == hipSuccess;
-            p->side_state = ok ? 1 : -1;
-        } else {
-            p->side_state = -1;
-        }
+static void plan_init_streams(avc_plan* p) {
+    p->side_state = -1;
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();  // no device: single-stream plan
+        return;
     }
-    return p->side_state == 1;
+    bool ok = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_dec_grads, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
+    for (int i = 0; i < 2; ++i) {
+        ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->ev_pack[i], hipEventDisableTiming) == hipSuccess;
+    }
+    p->wev.assign((size_t)p->nev_need, nullptr);
+    for (hipEvent_t& e : p->wev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    p->side_state = ok ? 1 : -1;
 }
+static bool side_ready(const avc_plan* p) { return !g_force_single && p->side_state == 1; }
 static hipStream_t fork_side(const avc_plan* p, hipStream_t mainS) {
     if (!side_ready(p)) return mainS;
     hipEventRecord(p->ev_fork, mainS);
@@ -548,6 +574,33 @@ extern "C" int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out) 
     if (i < 0 || i >= (int)p->sites.size()) return -1;
     *out = p->sites[i];
     return 0;
+}
+extern "C" int avc_plan_flags(const avc_plan* p) { return p ? p->flags : -1; }
+// Data-parallel hook: the decoder's parameters are the tail of the flat buffer and their
+// gradients are final well before the encoders' (the backward pass walks decoder -> encoders).
+extern "C" int avc_plan_param_range(const avc_plan* p, int part, long* offset, long* numel) {
+    if (!p || !offset || !numel) return -1;
+    if (part == AVC_GRADS_DECODER) {
+        *offset = p->dec_param_off;
+        *numel = p->param_floats - p->dec_param_off;
+    } else if (part == AVC_GRADS_ENCODERS) {
+        *offset = 0;
+        *numel = p->dec_param_off;
+    } else if (part == AVC_GRADS_ALL) {
+        *offset = 0;
+        *numel = p->param_floats;
+    } else {
+        return -1;
+    }
+    return 0;
+}
+// make `stream` wait until the gradients of `part` written by the LAST avc_backward call on this plan are final
+// (a no-op before the first call, and for single-stream plans whose caller already orders on its own stream)
+extern "C" int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream) {
+    if (!p || (p->flags & AVC_PLAN_INFERENCE)) return fail(-1, "avc_plan_stream_wait_grads: not a training plan");
+    if (p->side_state != 1) return 0;
+    hipEvent_t e = (part == AVC_GRADS_DECODER) ? p->ev_dec_grads : p->ev_all_grads;
+    return (int)hipStreamWaitEvent((hipStream_t)stream, e, 0);
 }
 extern "C" int avc_plan_out_len(const avc_plan* p) { return p->Tout; }
 extern "C" int avc_plan_latent_len(const avc_plan* p) { return p->Tb; }
@@ -647,16 +700,24 @@ struct BwdCtx {
     }
 };
 
+// One ordering edge "everything queued on c.s so far -> the branch's wgrad stream"; returns the stream
+// to launch on.  Edges are counted in the dry run too: that count sizes the plan's event pool, so the
+// index is always valid at run time.
+static hipStream_t wgrad_edge(BwdCtx& c) {
+    const int i = c.nev++;
+    if (c.dry || c.wstream == c.s) return c.s;
+    hipEvent_t e = c.p->wev[i];
+    hipEventRecord(e, c.s);
+    hipStreamWaitEvent(c.wstream, e, 0);
+    return c.wstream;
+}
+
 // Slab reduces of the weight gradients launched so far in this branch: queued on the branch's wgrad
 // stream right behind the kernels that fill the slabs, so they run under the other branches' work
 // instead of as a serial tail in front of the optimizer.
 static int flush_reduces(BwdCtx& c) {
-    if (!c.dry && c.wstream != c.s && c.nev < AVC_MAX_WEV) {  // (a wgrad that ran out of events was launched on c.s)
-        hipEvent_t e = c.p->wev[c.nev++];
-        hipEventRecord(e, c.s);
-        hipStreamWaitEvent(c.wstream, e, 0);
-    }
-    return c.red.flush(c.dry ? c.s : c.wstream);
+    hipStream_t ls = wgrad_edge(c);
+    return c.red.flush(ls);
 }
 
 // weight + bias gradient of layer L: x = forward input view, dy = output-gradient view
@@ -676,18 +737,12 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     long need = (long)nsplit * (wsz + Cout);
     long off = c.slab_used;
     c.slab_used += (need + 63) / 64 * 64;
+    hipStream_t ls = wgrad_edge(c);  // order after the producer of dy, then run beside the main chain
     if (c.dry) return 0;
     a.slab = c.ws + c.p->slab + off;
     a.slab_stride = wsz;
     a.dbslab = a.slab + (long)nsplit * wsz;
     a.db_stride = Cout;
-    hipStream_t ls = c.s;
-    if (c.wstream != c.s && c.nev < AVC_MAX_WEV) {  // order after the producer of dy, then run beside the main chain
-        hipEvent_t e = c.p->wev[c.nev++];
-        hipEventRecord(e, c.s);
-        hipStreamWaitEvent(c.wstream, e, 0);
-        ls = c.wstream;
-    }
     int rc = avc_launch_wgrad(a, nsplit, ls);
     if (rc) return rc;
     for (int s = 0; s < L.nsrc; ++s) {
@@ -740,6 +795,7 @@ static int wgrad_dense_group(BwdCtx& c, const LayerP* const* Ls, const float* co
         const long per = ((long)nsplit * (wsz + L.Cout) + 63) / 64 * 64;
         const long off = c.slab_used;
         c.slab_used += per * m;
+        hipStream_t ls = wgrad_edge(c);
         if (!c.dry) {
             a.slab = c.ws + c.p->slab + off;
             a.slab_stride = wsz;
@@ -751,13 +807,6 @@ static int wgrad_dense_group(BwdCtx& c, const LayerP* const* Ls, const float* co
             for (int g = 0; g < m; ++g) {
                 a.gx[g] = xs[i + g];
                 a.gdy[g] = dys[i + g];
-            }
-            hipStream_t ls = c.s;
-            if (c.wstream != c.s && c.nev < AVC_MAX_WEV) {
-                hipEvent_t e = c.p->wev[c.nev++];
-                hipEventRecord(e, c.s);
-                hipStreamWaitEvent(c.wstream, e, 0);
-                ls = c.wstream;
             }
             int rc = avc_launch_wgrad(a, nsplit, ls);
             if (rc) return rc;
@@ -898,7 +947,8 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             early[e->in_conv] = 1;
         }
         std::vector<PackArgs> first, rest;
-        for (size_t i = 0; i < p->layers.size(); ++i) pack_layer(p, p->layers[i], params, ws, early[i] ? first : rest);
+        for (size_t i = 0; i < p->layers.size(); ++i)
+            if (p->layers[i].wpf >= 0) pack_layer(p, p->layers[i], params, ws, early[i] ? first : rest);
         RUN(avc_launch_pack_batch(first.data(), (int)first.size(), s));
         pack_async = side_ready(p) && !rest.empty();
         hipStream_t ps = s;
@@ -963,7 +1013,8 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     }
 
     // ---------------- content encoder (model.py:301-323)
-    {
+    const bool spk_only = (p->flags & AVC_PLAN_SPEAKER_ONLY) != 0;  // AE.get_speaker_embeddings (model.py:393-395)
+    if (!spk_only) {
         const EncNet& e = p->enc;
         const int C = e.c.c_h;
         RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
@@ -992,7 +1043,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
 
     join_side(p, mainS, sideS);
     // ---------------- reparameterisation (model.py:383-384) + decoder (model.py:347-371)
-    {
+    if (!spk_only) {
         const DecNet& d = p->dec;
         const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb;
         RUN(avc_launch_reparam_fwd(ws + p->muls, eps, B, Cz, Tb, ws + d.z, s));
@@ -1036,11 +1087,6 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             RUN(avc_launch_conv(o, s, 0));
             return 0;
         };
-        if (g_dec_split_min == 0) {
-            const char* e = getenv("AVC_DEC_SPLIT_MIN");
-            g_dec_split_min = e ? atoi(e) : 32;
-            if (g_dec_split_min < 2) g_dec_split_min = 2;
-        }
         if (B >= g_dec_split_min && side_ready(p)) {
             const int Bh = B / 2;
             const hipStream_t s2 = fork_side(p, s);
@@ -1065,6 +1111,7 @@ extern "C" int avc_forward(const avc_plan* p, const float* params, const float* 
 
 extern "C" int avc_loss(const avc_plan* p, const float* x, long sxb, long sxc, int sxt, float lambda_rec, float* ws,
                         void* stream) {
+    if (p->flags & AVC_PLAN_INFERENCE) return fail(-8, "avc_loss: the plan was created with AVC_PLAN_INFERENCE");
     if (p->Tout != p->T) return fail(-7, "avc_loss: L1Loss needs dec and x of equal length (T % 8 == 0 for the stock config)");
     RUN(avc_launch_loss(ws + p->decb, x, sxb, sxc, sxt, p->B, p->M, p->T, ws + p->muls, p->dec.c.c_in, p->Tb, lambda_rec,
                         ws + p->ddec, ws + p->loss_partial, ws + p->losses, (hipStream_t)stream));
@@ -1189,6 +1236,9 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Cz, Tb, lk, ws + p->dmuls, s));
         }
         RUN(flush_reduces(c));  // decoder gradients are complete
+        // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
+        // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
+        if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
     }
 
     // ---------------- speaker encoder (side stream, own temporaries: concurrent with the content encoder)
@@ -1323,9 +1373,11 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
     }
     RUN(c.red.flush(s));
+    if (!dry && p->side_state == 1) hipEventRecord(p->ev_all_grads, s);
     if (slab_need) {
         slab_need[0] = c.slab_used;
         slab_need[1] = c.dy_used;
+        slab_need[2] = c.nev;
     }
     return 0;
 }
@@ -1335,6 +1387,7 @@ extern "C" int avc_backward(const avc_plan* p, const float* params, const float*
                             const float* d_muls_up, const float* d_emb_up, float lambda_kl, float* grads, float* ws,
                             void* stream) {
     if (!p || !params || !x || !ws || !grads) return fail(-1, "avc_backward: null argument");
+    if (p->flags & AVC_PLAN_INFERENCE) return fail(-8, "avc_backward: the plan was created with AVC_PLAN_INFERENCE (no gradient buffers)");
     if (!x_cond) {
         x_cond = x; scb = sxb; scc = sxc; sct = sxt;
     }

@@ -17,6 +17,21 @@ void avc_set_debug_ablation(int conv_bits, int wgrad_bits) {
     avc_set_conv_ablation(conv_bits);
     avc_set_wgrad_ablation(wgrad_bits);
 }
+// device-side segment feed: out[b, m, t] = corpus[starts[b] + t, m]   (data_utils.py:10-22,51-54 on the device)
+int avc_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out, void* stream) {
+    if (!corpus || !starts || !out) return -1;
+    return avc_launch_gather_segments(corpus, n_rows, M, starts, B, T, out, (hipStream_t)stream);
+}
+
+// tuning / diagnostic knobs of the micro-benchmark scripts (they used to be environment variables)
+int avc_set_tuning(const char* name, int value) {
+    if (!name) return -1;
+    if (!strcmp(name, "conv_ck5")) avc_set_conv_ck5(value);
+    else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
+    else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
+    else return -1;
+    return 0;
+}
 void avc_set_op_compute_dtype(int dtype) { g_op_compute = (dtype == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; }
 
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {

@@ -304,6 +304,32 @@ copy_rows_kernel(const float* x, long sxb, long sxc, int sxt, int B, int M, int 
     }
 }
 
+// Device-side data feed (reference: PickleDataset.__getitem__ + CollateFn, data_utils.py:10-22,
+// 51-54): segment b = rows [start[b], start[b]+T) of the HBM-resident corpus [sum_T][M] (mel bins contiguous),
+// emitted as out[b][m][t] with t contiguous -- the layout every first-layer loader reads with unit stride.
+// One workgroup = one sample x 32 frames: coalesced row reads -> LDS tile (odd row pitch) -> coalesced
+// 128-byte time runs per mel bin.
+__global__ void __launch_bounds__(AVC_THREADS)
+gather_segments_kernel(const float* corpus, long n_rows, int M, const long* starts, int T, float* out) {
+    HIP_DYNAMIC_SHARED(float, tile)
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int pitch = M | 1;
+    const long r0 = starts[b] + t0;
+    const int nt = (T - t0) < 32 ? (T - t0) : 32;
+    for (int e = threadIdx.x; e < 32 * M; e += AVC_THREADS) {
+        const int row = e / M, col = e - row * M;
+        long r = r0 + row;
+        r = r < n_rows ? r : n_rows - 1;  // (rows past the segment / corpus end are never stored)
+        tile[row * pitch + col] = (row < nt) ? corpus[r * M + col] : 0.f;
+    }
+    __syncthreads();
+    float* ob = out + ((long)b * M) * T + t0;
+    for (int e = threadIdx.x; e < 32 * M; e += AVC_THREADS) {
+        const int m = e >> 5, t = e & 31;
+        if (t < nt) ob[(long)m * T + t] = tile[t * pitch + m];
+    }
+}
+
 // dst[c][b] += src[b][c]   (upstream d(emb) of the autograd seam joins the channel-major gradient)
 __global__ void __launch_bounds__(AVC_THREADS) add_transposed_kernel(float* dst, const float* src, int B, int C) {
     int e = blockIdx.x * AVC_THREADS + threadIdx.x;
@@ -480,14 +506,9 @@ __global__ void __launch_bounds__(AVC_THREADS) clip_adam_kernel(const AdamArgs a
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
-static int in_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("AVC_IN_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+static int g_in_variant = 0;  // InstanceNorm kernel variant sweep of scripts/in_micro.py (avc_set_tuning)
+void avc_set_in_variant(int v) { g_in_variant = v; }
+static int in_variant() { return g_in_variant; }
 
 template <int LPR, int NV>
 static void launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
@@ -564,6 +585,14 @@ int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int
     ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_blocks((long)B * M * T)), dim3(AVC_THREADS), 0, s, x, sxb, sxc, sxt, B,
                        M, T, dst, db, dc);
+    return (int)hipGetLastError();
+}
+int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out,
+                               hipStream_t s) {
+    if (B < 1 || T < 1 || M < 1 || (size_t)32 * (M | 1) * 4 > 64 * 1024) return -1;
+    ProfScope ps(AVC_K_MISC, 0.0, 8.0 * (double)B * M * T, s);
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(avc_cdiv(T, 32), B), dim3(AVC_THREADS), (size_t)32 * (M | 1) * 4, s, corpus,
+                       n_rows, M, starts, T, out);
     return (int)hipGetLastError();
 }
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s) {

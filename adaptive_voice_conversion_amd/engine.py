@@ -3,6 +3,7 @@
 PyTorch is plumbing here: it owns device memory and the stream; every kernel is
 launched by libavc_hip.so.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -52,20 +53,33 @@ def _stream(t):
     return None
 
 
+def _on(t):
+    """Make the tensor's device the current HIP device for the duration of a C-ABI call: the library
+    launches on (and its plans create helper streams on) whatever device is current."""
+    return torch.cuda.device(t.device) if (t is not None and t.is_cuda) else contextlib.nullcontext()
+
+
 class Plan:
     """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
     tests may inject the CPU lane-level simulation build instead."""
 
     COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1}
 
-    def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32"):
+    def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None):
         """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
-        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3)."""
+        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3).
+        mode: "train" (forward + loss + backward), "inference" (forward only: the workspace holds no gradient,
+        slab or dy buffers) or "speaker" (only the speaker encoder runs, AE.get_speaker_embeddings).
+        device: the plan's helper streams are created on it (default: the current device)."""
         self.lib = lib if lib is not None else _lib.load()
         self.cfg = cfg_from_dict(config)
         self.B, self.T, self.T_cond = int(B), int(T), int(T_cond or T)
+        self.mode = mode
+        flags = {"train": 0, "inference": _lib.PLAN_INFERENCE, "speaker": _lib.PLAN_INFERENCE | _lib.PLAN_SPEAKER_ONLY}[mode]
         h = ctypes.c_void_p()
-        rc = self.lib.avc_plan_create(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, ctypes.byref(h))
+        dev = torch.device(device) if device is not None else None
+        with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
+            rc = self.lib.avc_plan_create_ex(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(h))
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
@@ -86,13 +100,29 @@ class Plan:
             self.lib.avc_plan_param_info(h, i, ctypes.byref(off), ctypes.byref(n), ctypes.byref(dims))
             self.param_info.append((off.value, n.value, tuple(d for d in dims if d > 0)))
 
+    def close(self):
+        """avc_plan_destroy: releases the plan's helper streams / events (the workspace is the caller's)."""
+        if getattr(self, "h", None):
+            self.lib.avc_plan_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.avc_plan_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
+
+    def param_range(self, part):
+        """(offset, numel) of a part of the flat parameter / gradient buffer (_lib.GRADS_*)."""
+        off, n = ctypes.c_long(), ctypes.c_long()
+        if self.lib.avc_plan_param_range(self.h, int(part), ctypes.byref(off), ctypes.byref(n)) != 0:
+            raise ValueError(part)
+        return off.value, n.value
+
+    def stream_wait_grads(self, part, stream):
+        """Make ``stream`` (a torch.cuda.Stream) wait until that part of the gradients of the last
+        ``backward`` call is final (data-parallel overlap)."""
+        self._chk(self.lib.avc_plan_stream_wait_grads(self.h, int(part), ctypes.c_void_p(stream.cuda_stream)))
 
     def buffer(self, name):
         off = self.lib.avc_plan_buffer(self.h, name.encode())
@@ -142,14 +172,17 @@ class Plan:
 
     def forward(self, params, x, x_cond, eps, ws):
         xc = x if x_cond is None else x_cond
-        self._chk(self.lib.avc_forward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
-                                       xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(ws), _stream(ws)))
+        with _on(ws):
+            self._chk(self.lib.avc_forward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
+                                           xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(ws), _stream(ws)))
 
     def loss(self, x, lambda_rec, ws):
-        self._chk(self.lib.avc_loss(self.h, _ptr(x), x.stride(0), x.stride(1), x.stride(2), float(lambda_rec), _ptr(ws), _stream(ws)))
+        with _on(ws):
+            self._chk(self.lib.avc_loss(self.h, _ptr(x), x.stride(0), x.stride(1), x.stride(2), float(lambda_rec), _ptr(ws), _stream(ws)))
 
     def backward(self, params, x, x_cond, eps, grads, ws, d_dec=None, d_muls=None, d_emb=None, lambda_kl=0.0):
         xc = x if x_cond is None else x_cond
-        self._chk(self.lib.avc_backward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
-                                        xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(d_dec), _ptr(d_muls),
-                                        _ptr(d_emb), float(lambda_kl), _ptr(grads), _ptr(ws), _stream(ws)))
+        with _on(ws):
+            self._chk(self.lib.avc_backward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
+                                            xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(d_dec), _ptr(d_muls),
+                                            _ptr(d_emb), float(lambda_kl), _ptr(grads), _ptr(ws), _stream(ws)))

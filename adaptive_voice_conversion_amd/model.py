@@ -74,14 +74,83 @@ class Decoder(_ParamHolder):
         self.out_conv_layer = nn.Conv1d(c_h, c_out, kernel_size=1)
 
 
+class _Token:
+    """Liveness marker of one autograd forward: while it is alive and not yet consumed, the workspace it
+    was run in holds activations a pending backward() needs."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
+class _Entry:
+    """One cached (plan, workspace)."""
+    __slots__ = ("plan", "ws", "pending")
+
+    def __init__(self, plan, ws):
+        self.plan, self.ws, self.pending = plan, ws, None
+
+    def busy(self):
+        t = self.pending() if self.pending is not None else None
+        return t is not None and not t.done
+
+
+class _PlanCache:
+    """Bounded LRU of launch plans + workspaces keyed by (mode, B, T, T_cond, device).  An evicted plan is
+    destroyed (avc_plan_destroy releases its helper streams / events) and its workspace goes back to
+    torch's caching allocator -- real inference traffic sees a new (T, T') for almost every utterance."""
+
+    def __init__(self, capacity):
+        from collections import OrderedDict
+        self.capacity = dict(capacity)
+        self.d = {m: OrderedDict() for m in self.capacity}
+
+    def get(self, mode, key, factory):
+        lru = self.d[mode]
+        hit = lru.get(key)
+        if hit is None:
+            hit = lru[key] = factory()
+            while len(lru) > self.capacity[mode]:
+                _, old = lru.popitem(last=False)
+                if not old.busy():          # (a workspace a pending backward still needs dies with its ctx instead)
+                    old.plan.close()
+                old.ws = None
+        else:
+            lru.move_to_end(key)
+        return hit
+
+    def clear(self):
+        for lru in self.d.values():
+            for e in lru.values():
+                if not e.busy():
+                    e.plan.close()
+            lru.clear()
+
+    def __len__(self):
+        return sum(len(v) for v in self.d.values())
+
+
 class _AEFunction(torch.autograd.Function):
-    """Autograd seam for drop-in use with arbitrary torch losses/optimizers."""
+    """Autograd seam for drop-in use with arbitrary torch losses/optimizers.
+
+    The engine saves its activations in the plan's workspace.  Each autograd forward marks the workspace
+    it ran in as pending until its backward() has consumed it; a second autograd forward of the same shape
+    that arrives meanwhile (micro-batches, an extra evaluation pass with grad enabled) gets a private
+    workspace instead of overwriting the saved activations.  no_grad / inference / embedding calls run in
+    separate forward-only plans and never touch a training workspace."""
 
     @staticmethod
     def forward(ctx, ae, x, eps, *params):
-        plan, ws = ae._plan(x.shape[0], x.shape[2], x.shape[2], x.device)
+        entry = ae._entry("train", x.shape[0], x.shape[2], x.shape[2], x.device)
+        plan, ws = entry.plan, entry.ws
+        if entry.busy():
+            ws = torch.zeros(plan.workspace_floats, dtype=torch.float32, device=x.device)   # private to this forward
+        token = _Token()
+        if ws is entry.ws:
+            import weakref
+            entry.pending = weakref.ref(token)
         plan.forward(ae._flat, x, None, eps, ws)
-        ctx.ae, ctx.plan, ctx.ws = ae, plan, ws
+        ctx.ae, ctx.plan, ctx.ws, ctx.token = ae, plan, ws, token
         ctx.save_for_backward(x, eps)
         muls, emb, dec = ae._outputs(plan, ws)
         C = muls.shape[1] // 2
@@ -90,6 +159,10 @@ class _AEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_mu, d_ls, d_emb, d_dec):
         ae, plan, ws = ctx.ae, ctx.plan, ctx.ws
+        if ctx.token.done:
+            raise RuntimeError("AE: backward through the same forward twice (the engine keeps one set of saved activations)")
+        if plan.h is None:
+            raise RuntimeError("AE: the launch plan of this forward was released (model moved / cache cleared) before backward()")
         x, eps = ctx.saved_tensors
         B = x.shape[0]
         C, Tb = ae._c_lat, plan.latent_len
@@ -102,6 +175,7 @@ class _AEFunction(torch.autograd.Function):
         d_emb = None if d_emb is None else d_emb.contiguous().float()
         g = torch.empty_like(ae._flat)
         plan.backward(ae._flat, x, None, eps, g, ws, d_dec=d_dec, d_muls=d_muls, d_emb=d_emb, lambda_kl=0.0)
+        ctx.token.done = True
         grads = tuple(g[off:off + n].view(shape) for off, n, shape in ae._layout)
         return (None, None, None) + grads
 
@@ -134,7 +208,8 @@ class AE(nn.Module):
                 self._flat[o:o + n] = p.detach().reshape(-1)
         self._gflat = None
         self._alias()
-        self._plans = {}
+        # train: the regular batch + the short last batch of an epoch; inference / speaker: a few recent shapes
+        self._plans = _PlanCache({"train": 2, "inference": 8, "speaker": 4})
 
     # ---- flat storage ------------------------------------------------------
     def _alias(self):
@@ -151,7 +226,7 @@ class AE(nn.Module):
         if self._gflat is not None:
             self._gflat = fn(self._gflat).contiguous()
         self._alias()
-        self._plans = {}
+        self._plans.clear()
         return self
 
     def flat_parameters(self):
@@ -168,16 +243,25 @@ class AE(nn.Module):
         return out
 
     # ---- plans ---------------------------------------------------------------
-    def _plan(self, B, T, Tc, device):
+    def _entry(self, mode, B, T, Tc, device):
         key = (int(B), int(T), int(Tc), str(device))
-        hit = self._plans.get(key)
-        if hit is None:
-            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype)
+
+        def make():
+            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype, mode=mode, device=device)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")
-            ws = torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device)
-            hit = self._plans[key] = (plan, ws)
-        return hit
+            return _Entry(plan, torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device))
+        return self._plans.get(mode, key, make)
+
+    def _plan(self, B, T, Tc, device, mode="train"):
+        e = self._entry(mode, B, T, Tc, device)
+        return e.plan, e.ws
+
+    def set_plan_cache_size(self, train=None, inference=None, speaker=None):
+        """How many (shape, device) launch plans + workspaces each mode keeps (LRU)."""
+        for k, v in (("train", train), ("inference", inference), ("speaker", speaker)):
+            if v is not None:
+                self._plans.capacity[k] = max(1, int(v))
 
     def _outputs(self, plan, ws):
         B = plan.B
@@ -185,6 +269,10 @@ class AE(nn.Module):
         emb = plan.view(ws, "emb", (B, self._c_emb))
         dec = plan.view(ws, "dec", (B, self._n_mels, plan.out_len))
         return muls, emb, dec
+
+    def _check_device(self, x):
+        if x.device != self._flat.device:
+            raise RuntimeError(f"input on {x.device} but parameters on {self._flat.device}")
 
     @staticmethod
     def _prep(x):
@@ -196,16 +284,17 @@ class AE(nn.Module):
     def forward(self, x, eps=None):
         """model.py:380-385; ``eps`` may be injected for parity tests."""
         x = self._prep(x)
-        if x.device != self._flat.device:
-            raise RuntimeError(f"input on {x.device} but parameters on {self._flat.device}")
-        T = x.shape[2]
+        self._check_device(x)
+        B, T = x.shape[0], x.shape[2]
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        mode = "train" if grad else "inference"
         if eps is None:
-            Tb = self._plan(x.shape[0], T, T, x.device)[0].latent_len
-            eps = torch.randn(x.shape[0], self._c_lat, Tb, device=x.device, dtype=torch.float32)
+            Tb = self._plan(B, T, T, x.device, mode)[0].latent_len
+            eps = torch.randn(B, self._c_lat, Tb, device=x.device, dtype=torch.float32)
         eps = eps.contiguous()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if grad:
             return _AEFunction.apply(self, x, eps, *self.parameters())
-        plan, ws = self._plan(x.shape[0], T, T, x.device)
+        plan, ws = self._plan(B, T, T, x.device, "inference")   # forward-only workspace: never a training one
         plan.forward(self._flat, x, None, eps, ws)
         muls, emb, dec = self._outputs(plan, ws)
         C = self._c_lat
@@ -214,13 +303,15 @@ class AE(nn.Module):
     def inference(self, x, x_cond):
         """model.py:387-391: decoder(mu(x), speaker(x_cond)); lengths may differ."""
         x, x_cond = self._prep(x), self._prep(x_cond)
-        plan, ws = self._plan(x.shape[0], x.shape[2], x_cond.shape[2], x.device)
+        self._check_device(x)
+        plan, ws = self._plan(x.shape[0], x.shape[2], x_cond.shape[2], x.device, "inference")
         plan.forward(self._flat, x, x_cond, None, ws)
         return self._outputs(plan, ws)[2].clone()
 
     def get_speaker_embeddings(self, x):
-        """model.py:393-395."""
+        """model.py:393-395: only the speaker encoder runs (a speaker-only plan)."""
         x = self._prep(x)
-        plan, ws = self._plan(x.shape[0], x.shape[2], x.shape[2], x.device)
-        plan.forward(self._flat, x, None, None, ws)
-        return self._outputs(plan, ws)[1].clone()
+        self._check_device(x)
+        plan, ws = self._plan(x.shape[0], x.shape[2], x.shape[2], x.device, "speaker")
+        plan.forward(self._flat, x, x, None, ws)
+        return plan.view(ws, "emb", (x.shape[0], self._c_emb)).clone()

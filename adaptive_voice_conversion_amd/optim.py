@@ -6,6 +6,7 @@ solver.py:75-77,:91-93 (≈1,700 tiny per-tensor ops in the stock loop, SURVEY
 torch.optim.Adam's on-disk format so ``<path>.opt`` files stay interchangeable
 (solver.py:42,54).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -38,10 +39,11 @@ class FusedClipAdam:
         self.step_count += 1
         stream = ctypes.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream) if flat.is_cuda else None
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        rc = self.lib.avc_clip_adam_step(P(flat), P(g), P(self.m), P(self.v), P(self.vmax), flat.numel(), self.step_count,
-                                         self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                         int(self.amsgrad), float(max_norm), float(grad_prescale), int(write_clipped),
-                                         P(self.ws), P(self.gnorm), stream)
+        with (torch.cuda.device(flat.device) if flat.is_cuda else contextlib.nullcontext()):   # launch on the buffers' device
+            rc = self.lib.avc_clip_adam_step(P(flat), P(g), P(self.m), P(self.v), P(self.vmax), flat.numel(), self.step_count,
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                             int(self.amsgrad), float(max_norm), float(grad_prescale), int(write_clipped),
+                                             P(self.ws), P(self.gnorm), stream)
         if rc != 0:
             raise RuntimeError(f"avc_clip_adam_step failed: {rc}")
         return self.gnorm

@@ -38,22 +38,48 @@ class Solver(object):
             self.load_model()
 
     # ---- checkpoints (solver.py:39-55) ---------------------------------------
+    # The reference is single-process.  Under data parallelism the replicas are identical, so only rank 0
+    # writes -- to a temporary file that is renamed into place (a reader never sees a truncated
+    # checkpoint) -- and every rank waits for it.
+    @staticmethod
+    def _rank():
+        d = _dist()
+        return d.get_rank() if d is not None else 0
+
+    @staticmethod
+    def _atomic_save(obj, path):
+        tmp = f"{path}.tmp.{os.getpid()}"
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+
     def save_model(self, iteration=None):
-        torch.save(self.model.state_dict(), f"{self.args.store_model_path}.ckpt")
-        torch.save(self.opt.state_dict(), f"{self.args.store_model_path}.opt")
+        if self._rank() == 0:
+            self._atomic_save(self.model.state_dict(), f"{self.args.store_model_path}.ckpt")
+            self._atomic_save(self.opt.state_dict(), f"{self.args.store_model_path}.opt")
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:
+            d.barrier()
 
     def save_config(self):
-        with open(f"{self.args.store_model_path}.config.yaml", "w") as f:
-            yaml.dump(self.config, f)
-        with open(f"{self.args.store_model_path}.args.yaml", "w") as f:
-            yaml.dump(vars(self.args), f)
+        if self._rank() != 0:
+            return
+        for suffix, obj in ((".config.yaml", self.config), (".args.yaml", vars(self.args))):
+            path = f"{self.args.store_model_path}{suffix}"
+            tmp = f"{path}.tmp.{os.getpid()}"
+            with open(tmp, "w") as f:
+                yaml.dump(obj, f)
+            os.replace(tmp, path)
 
     def load_model(self):
+        """solver.py:50-54 loads the model and the optimizer state.  A missing ``.opt`` is tolerated (a bare
+        ``.ckpt`` such as the published vctk_model.ckpt) unless ``--load_opt`` asks for it explicitly."""
         dev = self.model.flat_parameters().device
         self.model.load_state_dict(torch.load(f"{self.args.load_model_path}.ckpt", map_location=dev))
         opt_path = f"{self.args.load_model_path}.opt"
         if os.path.exists(opt_path):
             self.opt.load_state_dict(torch.load(opt_path, map_location=dev))
+        elif getattr(self.args, "load_opt", False):
+            raise FileNotFoundError(f"--load_opt: {opt_path} does not exist")
 
     # ---- data (solver.py:57-68) ----------------------------------------------
     def get_data_loaders(self):
@@ -67,7 +93,8 @@ class Solver(object):
             self.train_iter = DeviceSegmentFeed.from_files(
                 os.path.join(d, f"{self.args.train_set}.pkl"), os.path.join(d, self.args.train_index_file),
                 self.config["data_loader"]["segment_size"], self.config["data_loader"]["batch_size"], local_device(),
-                shuffle=self.config["data_loader"]["shuffle"], seed=rank)   # every rank draws its own shard order
+                shuffle=self.config["data_loader"]["shuffle"], seed=0, rank=rank, world_size=world,   # disjoint shards of ONE permutation
+                lib=self._lib)
             return
         self.train_dataset = PickleDataset(os.path.join(d, f"{self.args.train_set}.pkl"),
                                            os.path.join(d, self.args.train_index_file),
@@ -88,8 +115,38 @@ class Solver(object):
         d = _dist()
         if d is not None and d.get_world_size() > 1:  # identical replicas: rank 0's init wins
             d.broadcast(self.model.flat_parameters(), src=0)
+        # reparameterisation noise (model.py:383): every rank draws from its OWN generator stream
+        self._eps_gen = None
+        self._comm_stream = None
 
     # ---- one training step (solver.py:81-97) -------------------------------------
+    def _draw_eps(self, B, C, Tb, device):
+        if self._eps_gen is None or self._eps_gen.device != device:
+            self._eps_gen = torch.Generator(device=device)
+            self._eps_gen.manual_seed(torch.initial_seed() + 7919 * self._rank())
+        return torch.randn(B, C, Tb, device=device, dtype=torch.float32, generator=self._eps_gen)
+
+    def _allreduce_grads(self, d, plan, grads):
+        """SUM over ranks of the flat gradient buffer (RCCL over xGMI when the backend is "nccl"); the 1/W of the
+        mean is folded into the optimizer kernel.  The decoder's range -- final long before the encoders'
+        (avc_backward walks decoder -> encoders) -- is reduced on a communication stream under the rest of the
+        backward pass; the encoders' range follows on the same stream once the whole backward is done."""
+        from . import _lib
+        if not grads.is_cuda:
+            d.all_reduce(grads)
+            return
+        if self._comm_stream is None or self._comm_stream.device != grads.device:
+            self._comm_stream = torch.cuda.Stream(device=grads.device)
+        cs, main = self._comm_stream, torch.cuda.current_stream(grads.device)
+        (do, dn), (eo, en) = plan.param_range(_lib.GRADS_DECODER), plan.param_range(_lib.GRADS_ENCODERS)
+        plan.stream_wait_grads(_lib.GRADS_DECODER, cs)
+        with torch.cuda.stream(cs):
+            d.all_reduce(grads[do:do + dn])
+        cs.wait_stream(main)                       # the whole backward (avc_backward joins its helper streams into main)
+        with torch.cuda.stream(cs):
+            d.all_reduce(grads[eo:eo + en])
+        main.wait_stream(cs)
+
     def ae_step(self, data, lambda_kl, eps=None, sync=True):
         model = self.model
         flat = model.flat_parameters()
@@ -99,15 +156,15 @@ class Solver(object):
         B, _, T = x.shape
         plan, ws = model._plan(B, T, T, x.device)
         if eps is None:
-            eps = torch.randn(B, model._c_lat, plan.latent_len, device=x.device, dtype=torch.float32)  # model.py:383
+            eps = self._draw_eps(B, model._c_lat, plan.latent_len, x.device)  # model.py:383
         grads = model.flat_grads()
         plan.forward(flat, x, None, eps, ws)
         plan.loss(x, self.config["lambda"]["lambda_rec"], ws)
         plan.backward(flat, x, None, eps, grads, ws, lambda_kl=float(lambda_kl))
         prescale = 1.0
         d = _dist()
-        if d is not None and d.get_world_size() > 1:
-            d.all_reduce(grads)  # ONE flat bucket (sum) over RCCL/xGMI; the 1/W mean is folded into the optimizer kernel
+        if d is not None:   # (also with world_size 1: the same code path a multi-GPU job runs)
+            self._allreduce_grads(d, plan, grads)
             prescale = 1.0 / d.get_world_size()
         gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)
         losses = plan.view(ws, "losses", (2,))

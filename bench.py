@@ -11,6 +11,13 @@ scaling: per-GPU batch fixed, global batch = 256*N).  Rank 0 prints ONE JSON
 line.  After the timed region (never inside it) two extra legs run on rank 0 at
 N = 1: a per-kernel-class HIP-event profile (-> "roofline") and the CPU oracle
 timed on the host cores (-> "cpu_baseline").
+
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or plain
+``python bench.py --gpus N`` re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1.  The JSON line reports the world size the process group
+actually had and every rank's step time.
 """
 import argparse
 import ctypes
@@ -28,6 +35,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+# algorithmic GFLOP of one train step per segment (fwd + dgrad + wgrad minus the bank-conv input gradient)
+TRAIN_GFLOP_PER_SEG = {(80, 128): 1.767}
 
 
 def stock_config(n_mels):
@@ -99,48 +108,137 @@ def instnorm_dominant_shape(B, C, T, launches=50):
     return res
 
 
-def pmc_traffic(kernel_prefix, grid):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled on gfx950,
-    MI355X_MICROARCH.md §HBM; KB units) — None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")
-    try:
-        d = json.load(open(path))
+PMC_SUMMARIES = ("r02_pmc_fetch_write_summary.json", "r01_pmc_fetch_write_summary.json")
+
+
+def pmc_traffic(kernel_prefix, grid=None):
+    """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (separate
+    --pmc runs of this same command; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md §HBM prescribes, KB
+    units).  Returns (bytes, source file) or (None, None).  It is a replayed profile of the same build,
+    not a counter read of THIS run -- the line says so in "traffic_source"."""
+    for fn in PMC_SUMMARIES:
+        path = os.path.join(ROOT, "profiles", fn)
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
         for name, grids in d.items():
-            if name.startswith(kernel_prefix) and str(grid) in grids:
-                c = grids[str(grid)]
-                return (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-    except Exception:
-        pass
-    return None
+            if not name.startswith(kernel_prefix):
+                continue
+            keys = [str(grid)] if grid is not None else sorted(grids, key=lambda k: -grids[k].get("FETCH_SIZE", {}).get("launches", 0))
+            for k in keys:
+                c = grids.get(k)
+                if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    return (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, f"profiles/{fn}"
+    return None, None
 
 
-def cpu_baseline(n_mels, T, budget_s=12.0):
-    """The oracle's train step (same ATen CPU ops as the reference) on the host cores, bounded sample."""
+def cpu_baseline(n_mels, T, budget_s=26.0):
+    """BASELINE.md §2 protocol on the host cores of this box with the oracle's forward (the same ATen CPU
+    ops the reference issues; the reference itself cannot travel to the GPU box -> kind "port"): real
+    in-place ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77,
+    81-97), a thread-count sweep, B in {4, 128, 256}, median of the timed steps, best segments/s reported.
+    Bounded: the sweep stops adding steps when the time budget is spent (>= 3 timed steps per point)."""
+    import statistics
     from oracle import avc_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    torch.set_num_threads(cores)
     cfg = O.stock_config(n_mels)
-    Bc = 128  # best CPU batch in BASELINE.md
-    sd = O.make_state_dict(cfg, 0)
-    x, eps = O.make_inputs(cfg, Bc, T, 0)
-    opt = O.make_opt(sd, cfg)
-    tw = time.perf_counter()
-    O.ae_step(x, eps, sd, opt, cfg, 1.0)  # warm-up
-    print(f"[bench] cpu_baseline warm-up step: {time.perf_counter() - tw:.2f}s on {cores} threads", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.ae_step(x, eps, sd, opt, cfg, 1.0)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 20:
+    o = cfg["optimizer"]
+    t_start = time.perf_counter()
+
+    def make(Bc):
+        sd = O.make_state_dict(cfg, 0)
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(params.values()), lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"],
+                               weight_decay=o["weight_decay"])
+        x, eps = O.make_inputs(cfg, Bc, T, 0)
+
+        def step():
+            mu, ls, emb, dec = O.ae_forward(x, eps, params, cfg)
+            loss_rec, loss_kl = O.losses(x, mu, ls, dec)
+            loss = cfg["lambda"]["lambda_rec"] * loss_rec + 1.0 * loss_kl
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=o["grad_norm"])
+            opt.step()
+        return step
+
+    def timed(step, n_max, deadline):
+        step()  # warm-up
+        ts = []
+        while len(ts) < n_max and (len(ts) < 3 or time.perf_counter() < deadline):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), len(ts)
+
+    # 1. thread sweep on a small batch
+    cands = sorted({c for c in (8, 16, 32, cores) if c <= cores} or {cores})
+    thr = {}
+    st = make(32)
+    for c in cands:
+        torch.set_num_threads(c)
+        med, _ = timed(st, 3, 0.0)
+        thr[c] = 32 / med
+    best_threads = max(thr, key=thr.get)
+    torch.set_num_threads(best_threads)
+    # 2. batch sweep at the best thread count
+    per_b = {}
+    for Bc in (4, 128, 256):
+        left = budget_s - (time.perf_counter() - t_start)
+        if Bc == 256 and left < 6.0:
             break
-    return dict(value=Bc * n / el, unit="mel-segments/sec", cores=cores, kind="port",
-                sample=f"{n} oracle train steps (+1 warm-up) at batch {Bc}, 80x{T} segments, torch CPU fp32, {cores} threads")
+        med, n = timed(make(Bc), 5, time.perf_counter() + left * (0.1 if Bc == 4 else 0.45))
+        per_b[Bc] = dict(median_step_s=med, steps=n, seg_per_s=Bc / med)
+    bb = max(per_b, key=lambda k: per_b[k]["seg_per_s"])
+    print(f"[bench] cpu_baseline: threads {thr} -> {best_threads}; batches {per_b}; {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
+    return dict(value=per_b[bb]["seg_per_s"], unit="mel-segments/sec", cores=best_threads, kind="port", host_cores=cores,
+                sample=(f"oracle forward + autograd backward + torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, torch CPU fp32; "
+                        f"thread sweep {sorted(thr)} at B=32 -> {best_threads} threads; B in {sorted(per_b)}: median of "
+                        f"{[per_b[k]['steps'] for k in sorted(per_b)]} timed steps (+1 warm-up each); best at B={bb}"),
+                thread_sweep_seg_per_s={str(k): round(v, 1) for k, v in thr.items()},
+                batch_sweep={str(k): {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per_b.items()})
+
+
+def workload_label(a, world):
+    """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
+    prec = "fp32" if a.dtype == "f32" else "bf16 matrix products (fp32 accumulate, fp32 master weights and optimizer state)"
+    if a.mode == "infer":
+        idx = 3 if (a.mels == 80 and a.frames == 128 and a.batch == 1024) else None
+        what = f"AE.inference one-shot conversion, {a.mels}-mel x {a.frames}-frame source and target, batch {a.batch}/GPU, {prec}"
+        metric = f"utterances/sec one-shot conversion (AE.inference, {a.mels}x{a.frames})"
+    else:
+        idx = None
+        if a.mels == 80 and a.frames == 128 and a.batch == 256:
+            idx = 1 if a.dtype == "f32" else 2
+        elif a.mels == 80 and a.frames == 1024 and a.batch == 64 and a.dtype == "f32":
+            idx = 4
+        what = (f"recon+KL train step (fwd, loss, bwd, {'RCCL all-reduce, ' if world > 1 else ''}clip, Adam-amsgrad), "
+                f"{a.mels}-mel x {a.frames}-frame segments, batch {a.batch}/GPU, {prec}")
+        metric = f"mel-segments/sec ({a.mels}x{a.frames}) train step"
+    tag = f"BASELINE configs[{idx}]" if idx is not None else "not a BASELINE.json config (shape given on the command line)"
+    if idx == 2:
+        tag += f" (its per-GPU workload on {world} GPU(s); configs[2] itself is 8 GPUs, global batch 2048)"
+    return metric, f"{tag}: {what}", idx
+
+
+def relaunch_ranks(a):
+    """``python bench.py --gpus N`` without a launcher: start N ranks (one per GPU) on this node."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -158,12 +256,17 @@ def main():
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: every kernel on the caller's stream")
+    ap.add_argument("--feed", action="store_true", help="draw every batch from an HBM-resident synthetic corpus through the "
+                                                        "device-side gather kernel (DeviceSegmentFeed) inside the timed loop")
     ap.add_argument("--presleep-ms", type=float, default=0.0,
                     help="tracing aid: park the GPU this long before every timed step so that the (tracer-slowed) host has "
                          "the whole step enqueued when it starts; the reported time is then meaningless")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_ranks(a)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,10 +279,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()   # what the RCCL process group actually has
     if a.gpus != world and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        print(f"warning: --gpus {a.gpus} but the process group has {world} rank(s)", file=sys.stderr)
 
+    from adaptive_voice_conversion_amd import _lib
     from adaptive_voice_conversion_amd.solver import Solver
+    if a.single_stream:
+        _lib.load().avc_set_single_stream(1)
     cfg = stock_config(a.mels)
     if a.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
@@ -189,19 +296,28 @@ def main():
     B, T = a.batch, a.frames
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # each rank: its own shard of the global batch
     x = torch.randn(B, a.mels, T, generator=g).to(dev)
-    plan, _ = solver.model._plan(B, T, T, dev)
-    eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], plan.latent_len, generator=g).to(dev)
+    metric, workload, cfg_idx = workload_label(a, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def rank_times(elapsed):
+        """max over ranks (the contract's number) + every rank's own time"""
+        if world == 1:
+            return elapsed, [elapsed]
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        ts = [float(v.item()) for v in allt]
+        return max(ts), ts
+
     if a.mode == "infer":
         # BASELINE configs[3]: batched one-shot conversion AE.inference(x, x_cond) (model.py:387-391), forward only
         xc = torch.randn(B, a.mels, T, generator=g).to(dev)
         model = solver.model
-        plan_i, ws_i = model._plan(B, T, T, dev)
+        plan_i, ws_i = model._plan(B, T, T, dev, "inference")
         for _ in range(a.warmup):
             plan_i.forward(model.flat_parameters(), x, xc, None, ws_i)
         barrier()
@@ -209,50 +325,61 @@ def main():
         for _ in range(a.steps):
             plan_i.forward(model.flat_parameters(), x, xc, None, ws_i)
         barrier()
-        el = time.perf_counter() - t0
+        el, per_rank = rank_times(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"metric": "utterances/sec one-shot conversion (AE.inference)", "value": world * B * a.steps / el,
+            print(json.dumps({"metric": metric, "value": world * B * a.steps / el,
                               "unit": "utterances/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": a.dtype, "data": "synthetic",
-                              "config": {"workload": f"BASELINE configs[3]: AE.inference, {a.mels}-mel x {T}-frame source and target, batch {B}/GPU, "
-                                                     + ("fp32" if a.dtype == "f32" else "bf16 matrix products (fp32 storage)")}}),
+                              "config": {"workload": workload, "baseline_config_index": cfg_idx, "world_size": world,
+                                         "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank]}}),
                   flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
 
+    plan, _ = solver.model._plan(B, T, T, dev)
+    eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], plan.latent_len, generator=g).to(dev)
+    feed = None
+    if a.feed:   # HBM-resident synthetic corpus (2048 utterances' worth of frames), per-rank disjoint shards
+        from adaptive_voice_conversion_amd.device_feed import DeviceSegmentFeed
+        gc = torch.Generator(device="cpu").manual_seed(99)
+        rows = 2048 * (T + 64)
+        data = {"corpus": torch.randn(rows, a.mels, generator=gc).numpy()}
+        n_idx = 64 * B * max(world, 1)
+        idx = [["corpus", int(t)] for t in torch.randint(0, rows - T, (n_idx,), generator=gc).tolist()]
+        feed = DeviceSegmentFeed(data, idx, T, B, dev, shuffle=True, seed=0, rank=rank, world_size=world)
+
+    def one_step():
+        xb = next(feed) if feed is not None else x
+        solver.ae_step(xb, 1.0, eps=eps, sync=False)
+
     for _ in range(a.warmup):
-        solver.ae_step(x, 1.0, eps=eps, sync=False)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         if a.presleep_ms > 0:
             torch.cuda._sleep(int(a.presleep_ms * 2.0e6))
-        solver.ae_step(x, 1.0, eps=eps, sync=False)
+        one_step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, per_rank = rank_times(time.perf_counter() - t0)
     meta = solver.ae_step(x, 1.0, eps=eps, sync=True)
     if not all(v == v and abs(v) < 1e6 for v in meta.values()):
         raise SystemExit(f"non-finite training state: {meta}")
 
     if rank == 0:
-        print(f"[bench] timed region: {a.steps} steps in {elapsed:.3f}s", file=sys.stderr, flush=True)
+        print(f"[bench] timed region: {a.steps} steps in {elapsed:.3f}s on {world} rank(s)", file=sys.stderr, flush=True)
         value = world * B * a.steps / elapsed
         out = {
-            "metric": "mel-segments/sec (80x128) train step", "value": value, "unit": "mel-segments/sec",
+            "metric": metric, "value": value, "unit": "mel-segments/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: recon+KL train step (fwd, loss, bwd, clip, Adam-amsgrad), "
-                                    f"{a.mels}-mel x {T}-frame segments, batch {B}/GPU, fp32") if a.dtype == "f32" else
-                                   (f"BASELINE configs[2]'s compute mode on {world} GPU(s): same train step, conv/Linear operands bf16 "
-                                    f"(fp32 accumulate, fp32 master weights and optimizer state), {a.mels}-mel x {T}-frame "
-                                    f"segments, batch {B}/GPU -- NOT the headline metric"),
-                       "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
+            "config": {"workload": workload + (" + device-side segment gather from an HBM-resident corpus inside the timed loop" if feed else ""),
+                       "baseline_config_index": cfg_idx, "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
+                       "world_size": world, "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
+                       "allreduce": ("decoder range on a communication stream under the encoders' backward, encoders' range after it; "
+                                     "RCCL via torch.distributed nccl") if world > 1 else None,
                        "final_losses": meta},
         }
         if world == 1 and not a.no_profile:
@@ -260,10 +387,17 @@ def main():
             dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
             d = prof[dom]
             peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            pmc_prefix = {"conv_wgrad": "conv_wgrad", "conv_fwd": "conv_gemm_kernel", "conv_dgrad": "conv_gemm_kernel"}.get(dom, dom)
+            traffic, tsrc = pmc_traffic(pmc_prefix) if (cfg_idx == 1) else (None, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
-                               "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": None,
+                               "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
+                               "traffic_source": (f"{tsrc}: HBM bytes per launch of the most-launched instance of this kernel class, rocprofv3 --pmc "
+                                                  "passes of this command on the same build (not a counter read of this run)") if tsrc else None,
                                "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
-                               "ms_per_step": d["ms_per_step"]}
+                               "ms_per_step": d["ms_per_step"],
+                               "whole_step": {"algorithmic_tflop_per_step": TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3,
+                                              "tflops": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps)) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None,
+                                              "frac": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps) / peak) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None}}
             ib = [prof[k] for k in ("instnorm_fwd", "instnorm_bwd") if k in prof]
             if ib:
                 C = cfg["ContentEncoder"]["c_h"]
@@ -273,15 +407,17 @@ def main():
                 gbs = bts / us / 1e3
                 tot_b = sum(p["bytes_per_launch"] * p["launches_per_step"] for p in ib)
                 tot_ms = sum(p["ms_per_step"] for p in ib)
-                tf = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
-                tb = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
+                tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
+                tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
+                have = bool(tf and tb and B == 256 and T == 128)
                 out["roofline_instnorm"] = {
                     "kernel": f"instnorm_fwd + instnorm_bwd (IN/AdaIN/ReLU) at the dominant shape [{B},{C},{T}]",
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    "traffic": (tf + tb) if (tf and tb and B == 256 and T == 128) else None,
+                    "traffic": (tf + tb) if have else None,
+                    "traffic_source": (f"{s1}: rocprofv3 --pmc passes of this command on the same kernels (replayed, not a counter read of this run)") if have else None,
                     "algorithmic_bytes": bts, "fwd": dom_s["fwd"], "bwd": dom_s["bwd"],
                     "all_shapes_per_step": {"gbs": tot_b / (tot_ms * 1e-3) / 1e9, "ms": tot_ms, "algorithmic_bytes": tot_b,
-                                            "note": "26+26 launches of all T_l, each bracketed by its own event pair"}}
+                                            "note": "all IN launches of one step (every T_l), each bracketed by its own event pair"}}
             out["kernel_classes"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
                                          if kk in ("ms_per_step", "launches_per_step", "avg_us", "tflops", "gbs")}
                                      for k, v in prof.items()}

@@ -16,10 +16,20 @@
  *    caller-owned workspace whose size the plan reports (graph-capture safe).
  *  - return value: 0 = ok, < 0 = bad argument / unsupported shape,
  *    > 0 = hipError_t.  avc_last_error() describes the last failure.
- *  - re-entrant; the stream is always an argument (backward runs on PyTorch's
- *    autograd thread).  The only process-wide state are the
- *    diagnostic / tuning knobs set by the avc_set_* functions below (defaults:
- *    all off), which must not be changed while another thread is inside the library.
+ *  - the stream is always an argument (backward runs on PyTorch's autograd
+ *    thread).  A plan owns a few helper HIP streams and events
+ *    (created by avc_plan_create on the device that is current at that moment,
+ *    destroyed by avc_plan_destroy) on which it overlaps independent branches;
+ *    every entry point joins them back into the caller's stream before it
+ *    returns.  ONE call per plan may be in flight on the host at a time (two
+ *    host threads need two plans); different plans are independent.
+ *  - the only process-wide state are the diagnostic / tuning knobs set by the
+ *    avc_set_* functions below (defaults: all off; no environment variable is
+ *    read), which must not be changed while another thread is inside the library.
+ *  - the gradient all-reduce of data-parallel training deliberately lives in
+ *    the host framework (torch.distributed "nccl" = RCCL over xGMI):
+ *    this library exposes where to cut (avc_plan_param_range) and when each
+ *    part of the flat gradient buffer is final (avc_plan_stream_wait_grads).
  */
 #ifndef AVC_HIP_H
 #define AVC_HIP_H
@@ -58,6 +68,13 @@ const char* avc_last_error(void);
  * differ (model.py:387-391).  Fails (like the reference, a1 in SURVEY §8a) when a
  * reflect pad is not smaller than the length it pads. */
 int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out);
+/* flags: AVC_PLAN_INFERENCE = forward only (AE.inference, model.py:387-391): no gradient / slab / dy buffers in
+ * the workspace, avc_loss / avc_backward are refused; AVC_PLAN_SPEAKER_ONLY (implies INFERENCE) = only the
+ * speaker encoder runs (AE.get_speaker_embeddings, model.py:393-395): T is ignored, the result is ws["emb"]. */
+#define AVC_PLAN_INFERENCE 1
+#define AVC_PLAN_SPEAKER_ONLY 2
+int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, avc_plan** out);
+int avc_plan_flags(const avc_plan* p);
 void avc_plan_destroy(avc_plan* p);
 /* flat parameter buffer: the 166 state_dict tensors in reference
  * registration order, each at a 16-byte aligned offset */
@@ -84,6 +101,17 @@ typedef struct avc_relu_site {
 } avc_relu_site;
 int avc_plan_num_relu_sites(const avc_plan* p);
 int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
+
+/* ---- data-parallel hooks: the flat gradient buffer is all-reduced by the caller (RCCL).
+ * The backward pass finishes the decoder's parameter gradients first; they are the TAIL of the flat buffer.
+ * avc_plan_param_range gives the float range of a part; avc_plan_stream_wait_grads makes `stream` wait until
+ * that part, as written by the last avc_backward call on this plan, is final -- so the reduce of the decoder
+ * range can run on a communication stream under the encoders' backward. */
+#define AVC_GRADS_ALL 0
+#define AVC_GRADS_DECODER 1
+#define AVC_GRADS_ENCODERS 2
+int avc_plan_param_range(const avc_plan* p, int part, long* offset, long* numel);
+int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream);
 
 /* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
 void avc_set_single_stream(int on);
@@ -139,6 +167,17 @@ long avc_clip_adam_ws_floats(long n);
 int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long n, int step, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int amsgrad, float max_norm, float grad_prescale,
                        int write_clipped, float* ws, float* gnorm_out, void* stream);
+
+/* tuning knobs of the micro-benchmark scripts: "conv_ck5" (8|16|32: chunk depth of k >= 4 convs at the op
+ * level), "wgrad_target_wgs" (split-K workgroups per weight-gradient launch, default 256), "in_variant"
+ * (InstanceNorm kernel variant).  Returns -1 for an unknown name. */
+int avc_set_tuning(const char* name, int value);
+
+/* ---- device-side segment feed (replaces PickleDataset.__getitem__ + CollateFn, data_utils.py:10-22,51-54,
+ * for an HBM-resident corpus): out[b, m, t] = corpus[starts[b] + t, m], corpus = [n_rows, M] fp32 (mel bins
+ * contiguous), starts = B device int64 row indices, out = [B, M, T] contiguous. */
+int avc_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out,
+                        void* stream);
 
 /* ---- op-level entry points (one per kernel family and direction) -------- */
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad);

@@ -4,7 +4,10 @@ the GPU box, so its outputs are committed as small fixtures; inputs and weights
 are regenerated from seeds by ``oracle.avc_oracle.make_state_dict/make_inputs``
 (identical torch build on both machines) and guarded by checksums stored here.
 
-Run:  python oracle/make_golden.py          (needs /root/reference)
+Run:  python oracle/make_golden.py [out_dir]     (needs /root/reference; default out_dir = tests/golden)
+
+tests/test_oracle_golden.py::test_committed_fixtures_equal_a_fresh_regeneration re-runs this recipe into
+a scratch directory whenever /root/reference is present and compares it with the committed files.
 """
 import os
 import sys
@@ -19,6 +22,7 @@ sys.path.insert(0, ROOT)
 from oracle import avc_oracle as O  # noqa: E402
 
 REF = "/root/reference"
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 def import_reference():
@@ -93,7 +97,7 @@ def run_case(model_mod, name, cfg, B, T, seed, n_steps, full_outputs=True):
         out[f"grad_norm_{step}"] = float(gn)
         psd = ref.state_dict()
         out[f"param_stats_{step}"] = np.stack([tensor_stats(psd[k]) for k in names])
-    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print(name, "loss_rec", out["loss_rec_0"], "loss_kl", out["loss_kl_0"], "gn", out["grad_norm_0"],
           os.path.getsize(path) // 1024, "KiB")
@@ -110,15 +114,29 @@ def run_inference_case(model_mod, name, cfg, Ts, Tc, seed):
     with torch.no_grad():
         dec = ref.inference(x, xc)
         emb = ref.get_speaker_embeddings(xc)
-    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, Ts=Ts, Tc=Tc, seed=seed, dec=dec.numpy(), emb=emb.numpy(),
                         x_stats=tensor_stats(x), xc_stats=tensor_stats(xc))
     print(name, tuple(dec.shape), os.path.getsize(path) // 1024, "KiB")
 
 
-def main():
+def make_init_golden(model_mod):
+    """Default-initialisation pin: AE(config) of the reference under torch.manual_seed(0)
+    (solver.py:72 builds the model with PyTorch's default Conv/Linear init)."""
+    out = {}
+    for name, cfg in (("m80", O.stock_config(80)), ("tiny", O.tiny_config())):
+        torch.manual_seed(0)
+        ref = model_mod.AE(cfg)
+        out[name] = np.stack([tensor_stats(v) for v in ref.state_dict().values()])
+    np.savez_compressed(os.path.join(OUT_DIR, "init_seed0.npz"), **out)
+
+
+def main(out_dir=None):
+    global OUT_DIR
+    if out_dir:
+        OUT_DIR = out_dir
     model_mod = import_reference()
-    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    os.makedirs(OUT_DIR, exist_ok=True)
     c80 = O.stock_config(80)
     run_case(model_mod, "train_m80_t128_b2", c80, B=2, T=128, seed=0, n_steps=3)
     run_case(model_mod, "train_m80_t128_b4_s1", c80, B=4, T=128, seed=1, n_steps=1, full_outputs=False)
@@ -128,20 +146,8 @@ def main():
     run_case(model_mod, "train_tiny_t24_b3", O.tiny_config(), B=3, T=24, seed=5, n_steps=1)
     run_inference_case(model_mod, "infer_m80_t100_c77", c80, Ts=100, Tc=77, seed=6)
     run_inference_case(model_mod, "infer_tiny_t37_c19", O.tiny_config(), Ts=37, Tc=19, seed=7)
+    make_init_golden(model_mod)
 
 
 if __name__ == "__main__":
-    main()
-    make_init_golden()
-
-
-def make_init_golden():
-    """Default-initialisation pin: AE(config) of the reference under torch.manual_seed(0)
-    (solver.py:72 builds the model with PyTorch's default Conv/Linear init)."""
-    model_mod = import_reference()
-    out = {}
-    for name, cfg in (("m80", O.stock_config(80)), ("tiny", O.tiny_config())):
-        torch.manual_seed(0)
-        ref = model_mod.AE(cfg)
-        out[name] = np.stack([tensor_stats(v) for v in ref.state_dict().values()])
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "init_seed0.npz"), **out)
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

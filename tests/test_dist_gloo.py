@@ -36,12 +36,15 @@ def _worker(rank, world, port, out_dir):
     B = 4
     x, eps = O.make_inputs(cfg, B, 32, 4)
     per = B // world
-    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir=out_dir)
+    args = types.SimpleNamespace(store_model_path=os.path.join(out_dir, "model"), load_model=False, data_dir=None, logdir=out_dir)
     s = Solver(cfg, args, lib=lib)
     s.model.load_state_dict(sd)
     sl = slice(rank * per, (rank + 1) * per)
     metas = [s.ae_step(x[sl].contiguous(), 1.0, eps=eps[sl].contiguous()) for _ in range(2)]
-    torch.save({"params": s.model.flat_parameters().clone(), "metas": metas}, os.path.join(out_dir, f"rank{rank}.pt"))
+    s.save_model()   # every rank calls it (as Solver.train does); only rank 0 writes, atomically, and all wait
+    assert os.path.exists(os.path.join(out_dir, "model.ckpt"))
+    torch.save({"params": s.model.flat_parameters().clone(), "metas": metas,
+                "eps_draw": s._draw_eps(2, 3, 4, torch.device("cpu"))}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -51,6 +54,9 @@ def test_two_rank_step_equals_global_batch_step(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["params"], r1["params"]), "replicas diverged"
+    assert not torch.equal(r0["eps_draw"], r1["eps_draw"]), "ranks must draw different reparameterisation noise"
+    ck = torch.load(tmp_path / "model.ckpt")
+    assert len(ck) == len(O.param_spec(O.tiny_config())) and not list(tmp_path.glob("*.tmp.*"))
     assert r0["metas"][0]["grad_norm"] == pytest.approx(r1["metas"][0]["grad_norm"], rel=1e-6)  # same global norm on both
     # single process, global batch
     from adaptive_voice_conversion_amd.solver import Solver

@@ -13,20 +13,46 @@ from oracle import avc_oracle as O
 from tests.emu_util import KINDS, backend
 
 
-def test_device_feed_equals_reference_collate():
+def _corpus(M=16, seg=24, n_idx=23):
     rng = np.random.RandomState(0)
-    data = {f"u{i}": rng.randn(40 + 7 * i, 16).astype(np.float32) for i in range(5)}
-    indexes = [[f"u{i % 5}", int(rng.randint(0, 40 + 7 * (i % 5) - 24))] for i in range(23)]
-    feed = DeviceSegmentFeed(data, indexes, segment_size=24, batch_size=8, device="cpu", shuffle=False)
+    data = {f"u{i}": rng.randn(40 + 7 * i, M).astype(np.float32) for i in range(5)}
+    indexes = [[f"u{i % 5}", int(rng.randint(0, 40 + 7 * (i % 5) - seg))] for i in range(n_idx)]
+    return data, indexes
+
+
+@pytest.mark.parametrize("kind,M,seg", [("emu", 16, 24), ("emu", 5, 37), pytest.param("gpu", 80, 128, marks=pytest.mark.gpu),
+                                        pytest.param("gpu", 512, 100, marks=pytest.mark.gpu)])
+def test_device_feed_equals_reference_collate(kind, M, seg):
+    """avc_gather_segments (the device-side feed kernel) vs PickleDataset.__getitem__ + CollateFn
+    (data_utils.py:10-22,51-54): bit-exact values; the time axis comes out contiguous."""
+    lib, dev = backend(kind)
+    rng = np.random.RandomState(1)
+    data = {f"u{i}": rng.randn(seg + 16 + 7 * i, M).astype(np.float32) for i in range(5)}
+    indexes = [[f"u{i % 5}", int(rng.randint(0, 16 + 7 * (i % 5) + 1))] for i in range(23)]   # incl. segments ending at the last row
+    indexes[0] = ["u4", 16 + 28]                                      # the very last rows of the corpus
+    feed = DeviceSegmentFeed(data, indexes, segment_size=seg, batch_size=8, device=dev, shuffle=False, lib=lib)
     got = [next(feed) for _ in range(len(feed))]
     assert [g.shape[0] for g in got] == [8, 8, 7]               # short last batch kept (drop_last ignored)
     collate = CollateFn(frame_size=1)
     for bi, g in enumerate(got):
-        items = [data[u][t:t + 24] for u, t in indexes[bi * 8:(bi + 1) * 8]]   # PickleDataset.__getitem__ (data_utils.py:51-54)
+        items = [data[u][t:t + seg] for u, t in indexes[bi * 8:(bi + 1) * 8]]   # PickleDataset.__getitem__ (data_utils.py:51-54)
         ref = collate(items)
-        assert g.shape == ref.shape and g.stride() == ref.stride()             # the [B,M,T] view over [B,T,M] memory
-        assert torch.equal(g, ref)
+        assert g.shape == ref.shape and g.is_contiguous()
+        assert torch.equal(g.cpu(), ref)
     assert next(feed).shape[0] == 8                               # wraps around like infinite_iter
+
+
+def test_device_feed_shards_are_disjoint_and_equal():
+    lib, dev = backend("emu")
+    data, indexes = _corpus()
+    W = 3
+    feeds = [DeviceSegmentFeed(data, indexes, 24, 4, dev, shuffle=True, seed=5, rank=r, world_size=W, lib=lib) for r in range(W)]
+    for f in feeds:
+        f._new_epoch()
+    shards = [set(f._perm.tolist()) for f in feeds]
+    assert all(len(s) == len(indexes) // W for s in shards)
+    assert not (shards[0] & shards[1]) and not (shards[0] & shards[2]) and not (shards[1] & shards[2])
+    assert len(feeds[0]) == len(feeds[1]) == len(feeds[2])
 
 
 @pytest.mark.parametrize("kind", KINDS)

@@ -1,0 +1,127 @@
+"""Oracle parity AT THE GRADED SHAPES (BASELINE.json configs; VERDICT r1 "next round" item 1).
+
+The launcher picks different kernel instances at the benchmarked sizes than at the B <= 36 cases of
+tests/test_engine.py (tile choice, intra-workgroup split-K only when <= 1 workgroup per CU, the wgrad
+split factor, the two half-batch decoder chains), so each graded config is compared with the CPU
+oracle through the C ABI at its own size:
+
+  config 2  B=256, 80x128 train step : forward atol 2e-5 / rtol 1e-4, losses 1e-5, per-tensor
+                                       gradients rel-L2 <= 1e-4 on the engine's ReLU branch
+  config 5  T=1024 whole model       : same bars at B=4
+  config 4  B=1024 inference         : samples are independent -> 16 random rows vs O.ae_inference
+  + a ReLU-branch check that does NOT take the masks from the engine (weak #2 of the verdict)
+
+Each has a kind='emu' twin on the tiny architecture so that the test logic itself runs in the CPU suite.
+"""
+import numpy as np
+import pytest
+import torch
+
+from adaptive_voice_conversion_amd.engine import Plan
+from oracle import avc_oracle as O
+from tests.emu_util import backend
+from tests.test_engine import branch_matched_oracle, check_grads, flat_params, get_cfg
+
+GPU = pytest.mark.gpu
+
+
+def _fwd_bwd(kind, cfgname, B, T, seed=0):
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, seed)
+    x, eps = O.make_inputs(cfg, B, T, seed)
+    plan = Plan(cfg, B, T, lib=lib)
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    xd, ed = x.to(dev), eps.to(dev)
+    plan.forward(params, xd, None, ed, ws)
+    Cz = cfg["ContentEncoder"]["c_out"]
+    out = dict(muls=plan.view(ws, "muls", (B, 2 * Cz, plan.latent_len)).cpu(),
+               emb=plan.view(ws, "emb", (B, cfg["SpeakerEncoder"]["c_out"])).cpu(),
+               dec=plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu())
+    plan.loss(xd, cfg["lambda"]["lambda_rec"], ws)
+    out["losses"] = plan.view(ws, "losses", (2,)).cpu()
+    grads = torch.full((plan.param_floats,), float("nan"), device=dev)
+    plan.backward(params, xd, None, ed, grads, ws, lambda_kl=1.0)
+    return cfg, sd, x, eps, plan, ws, out, grads
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T,label", [
+    ("emu", "tiny", 5, 32, "logic twin"),
+    pytest.param("gpu", "m80", 256, 128, "BASELINE configs[1]: B=256, 80x128, fp32 train step", marks=GPU),
+    pytest.param("gpu", "m80", 4, 1024, "BASELINE configs[4]'s segment length: T=1024 whole model", marks=GPU),
+    pytest.param("gpu", "m80", 64, 1024, "BASELINE configs[4]: T=1024, B=64 (forward + losses + gradient norm only)", marks=GPU),
+])
+def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
+    cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T)
+    Cz = cfg["ContentEncoder"]["c_out"]
+    outs, grads_ref = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    torch.testing.assert_close(out["emb"], outs["emb"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out["muls"][:, :Cz], outs["mu"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out["muls"][:, Cz:], outs["log_sigma"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out["dec"], outs["dec"], rtol=1e-4, atol=2e-5)
+    assert out["losses"][0].item() == pytest.approx(outs["loss_rec"].item(), rel=1e-5)
+    assert out["losses"][1].item() == pytest.approx(outs["loss_kl"].item(), rel=1e-5)
+    gtot = grads.cpu().norm().item()
+    rtot = float(np.sqrt(sum(float(g.double().pow(2).sum()) for g in grads_ref.values())))
+    assert gtot == pytest.approx(rtot, rel=5e-3)     # whole-gradient norm, no branch matching
+    if B * T > 256 * 128:                             # (the B=64 x T=1024 mask read-back is 8x config 2's; norms suffice there)
+        print(f"[{kind}/{cfgname} B={B} T={T}] {label}: forward/loss parity ok, |g| {gtot:.6f} vs oracle {rtot:.6f}")
+        return
+    _, grads_m = branch_matched_oracle(plan, ws, x, eps, sd, cfg)
+    worst, med, total = check_grads(plan, grads, grads_m, tol=1e-4, cfg=cfg, zero_abs=2e-6)
+    print(f"[{kind}/{cfgname} B={B} T={T}] {label}: grad rel-L2 on the engine's ReLU branch: worst tensor {worst:.2e}, "
+          f"median {med:.2e}, whole gradient {total:.2e}")
+    assert med < 2e-5
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 32, 128, marks=GPU)])
+def test_relu_branches_agree_with_the_oracle_without_engine_masks(kind, cfgname, B, T):
+    """Complement of the branch-matched gradient check: here NOTHING is taken from the engine's
+    workspace to drive the oracle.  The oracle logs its own pre-activations; the engine's ReLU decisions
+    (avc_plan_relu_site) must agree with sign(oracle pre-activation) everywhere except at kinks:
+    a handful of sites per segment, each with |pre-activation| below fp32 noise (1e-5)."""
+    cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T, seed=3)
+    log = []
+    with O.relu_masks(None, log=log):
+        O.ae_forward(x, eps, sd, cfg)
+    masks = plan.relu_masks(ws)
+    assert len(masks) == len(log)
+    flips, worst, nsites = 0, 0.0, 0
+    for m, pre in zip(masks, log):
+        m = m.cpu()
+        assert m.shape == pre.shape, (m.shape, pre.shape)
+        diff = m != (pre > 0)
+        nsites += m.numel()
+        if diff.any():
+            flips += int(diff.sum())
+            worst = max(worst, float(pre[diff].abs().max()))
+    print(f"[{kind}/{cfgname} B={B} T={T}] ReLU decisions differing from the oracle's: {flips} of {nsites} "
+          f"(largest |pre-activation| among them {worst:.2e})")
+    assert flips <= 4 * B + 4, flips
+    assert worst < 1e-5, worst
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T,rows", [("emu", "tiny", 9, 32, 3), pytest.param("gpu", "m80", 1024, 128, 16, marks=GPU)])
+def test_inference_batch_matches_oracle_on_random_rows(kind, cfgname, B, T, rows):
+    """BASELINE configs[3]: batch-1024 one-shot conversion through an inference plan.  Samples are
+    independent (no batch statistics anywhere), so `rows` random rows are compared with the
+    oracle run on those rows alone."""
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 11)
+    x, _ = O.make_inputs(cfg, B, T, 11)
+    xc, _ = O.make_inputs(cfg, B, T, 12)
+    plan = Plan(cfg, B, T, T, lib=lib, mode="inference")
+    train_plan = Plan(cfg, B, T, T, lib=lib)
+    assert plan.workspace_floats < 0.7 * train_plan.workspace_floats      # no gradient / slab / dy buffers
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    plan.forward(params, x.to(dev), xc.to(dev), None, ws)
+    dec = plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len))
+    sel = torch.from_numpy(np.random.RandomState(0).choice(B, size=rows, replace=False)).long()
+    ref = O.ae_inference(x[sel], xc[sel], sd, cfg)
+    torch.testing.assert_close(dec[sel.to(dev)].cpu(), ref, rtol=1e-4, atol=2e-5)
+    assert torch.isfinite(dec).all()
+    with pytest.raises(RuntimeError, match="AVC_PLAN_INFERENCE"):
+        plan.backward(params, x.to(dev), None, None, torch.zeros(plan.param_floats, device=dev), ws)

@@ -205,3 +205,92 @@ def test_bf16_compute_training_curve_tracks_fp32(kind, cfgname, B, T, steps):
         assert b == pytest.approx(a, rel=2e-2)
     assert c16[-1] < c16[0]
     assert all(v.dtype == torch.float32 for v in s16.model.state_dict().values())
+
+
+GOLDEN_INFER = {"tiny": "infer_tiny_t37_c19", "m80": "infer_m80_t100_c77"}
+
+
+@pytest.mark.parametrize("kind,cfgname", [("emu", "tiny"), pytest.param("gpu", "m80", marks=pytest.mark.gpu)])
+def test_get_speaker_embeddings_matches_reference_golden(kind, cfgname, golden_dir):
+    """AE.get_speaker_embeddings (model.py:393-395) through a speaker-only plan vs the embedding the REAL
+    reference produced (oracle/make_golden.py run_inference_case) and vs the oracle; AE.inference of the same
+    fixture alongside."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, GOLDEN_INFER[cfgname] + ".npz"))
+    cfg = O.tiny_config() if cfgname == "tiny" else O.stock_config(80)
+    Ts, Tc, seed = int(g["Ts"]), int(g["Tc"]), int(g["seed"])
+    sd = O.make_state_dict(cfg, seed)
+    x, _ = O.make_inputs(cfg, 1, Ts, seed)
+    xc, _ = O.make_inputs(cfg, 1, Tc, seed + 7)
+    ae, dev, lib = make_ae(kind, cfg)
+    ae.load_state_dict(sd)
+    ae.eval()
+    with torch.no_grad():
+        emb = ae.get_speaker_embeddings(xc.to(dev))
+        dec = ae.inference(x.to(dev), xc.to(dev))
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dec.cpu().numpy(), g["dec"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(emb.cpu(), O.speaker_encoder(xc, sd, cfg), rtol=1e-4, atol=2e-5)
+    # a batch of different utterances of one length: row-wise equal to single calls
+    xb, _ = O.make_inputs(cfg, 3, Tc, seed + 1)
+    eb = ae.get_speaker_embeddings(xb.to(dev)).cpu()
+    torch.testing.assert_close(eb, O.speaker_encoder(xb, sd, cfg), rtol=1e-4, atol=2e-5)
+    plan, ws = ae._plan(3, Tc, Tc, dev, "speaker")
+    full = ae._plan(3, Tc, Tc, dev, "inference")[0]
+    assert plan.workspace_floats < 0.5 * full.workspace_floats   # only the speaker encoder's buffers
+
+
+def test_interleaved_forwards_do_not_corrupt_a_pending_backward():
+    """the engine keeps its saved activations in the plan's workspace.  A no_grad
+    forward, an embedding call or a second autograd forward of the SAME shape between forward() and
+    backward() must not change the gradients."""
+    cfg = O.tiny_config()
+    sd = O.make_state_dict(cfg, 4)
+    x, eps = O.make_inputs(cfg, 2, 32, 4)
+    x2, eps2 = O.make_inputs(cfg, 2, 32, 9)
+    ae, dev, lib = make_ae("emu", cfg)
+    ae.load_state_dict(sd)
+
+    def loss_of(out, xx):
+        mu, ls, emb, dec = out
+        return 10 * torch.nn.L1Loss()(dec, xx) + 0.5 * torch.mean(torch.exp(ls) + mu ** 2 - 1 - ls)
+
+    _, gref = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    _, gref2 = O.loss_and_grads(x2, eps2, sd, cfg, 1.0)
+    out = ae(x, eps=eps)
+    with torch.no_grad():
+        ae(x2, eps=eps2)                       # same shape, forward-only plan
+        ae.get_speaker_embeddings(x2)
+        ae.inference(x2, x2)
+    out2 = ae(x2, eps=eps2)                    # second autograd forward before the first backward (micro-batches)
+    loss_of(out, x).backward()
+    for k, p in ae.named_parameters():
+        d, e = gref[k].norm().item(), (p.grad - gref[k]).norm().item()
+        assert e <= 1e-4 * d + 1e-6, (k, e, d)
+    for p in ae.parameters():
+        p.grad = None
+    loss_of(out2, x2).backward()
+    for k, p in ae.named_parameters():
+        d, e = gref2[k].norm().item(), (p.grad - gref2[k]).norm().item()
+        assert e <= 1e-4 * d + 1e-6, (k, e, d)
+    with pytest.raises(RuntimeError):
+        loss_of(out2, x2).backward()           # graph already consumed
+
+
+def test_plan_cache_is_bounded_and_releases_plans():
+    """real inference traffic has a new (T, T') per utterance; the cache must not grow."""
+    cfg = O.tiny_config()
+    ae, dev, lib = make_ae("emu", cfg)
+    ae.set_plan_cache_size(inference=3)
+    seen = []
+    with torch.no_grad():
+        for T in (24, 32, 40, 48, 56, 64):
+            x, _ = O.make_inputs(cfg, 1, T, 0)
+            ae.inference(x, x)
+            seen.append(ae._plan(1, T, T, dev, "inference")[0])
+    assert len(ae._plans.d["inference"]) == 3
+    assert [p.h is None for p in seen] == [True, True, True, False, False, False]   # evicted plans were destroyed
+    train_ws = ae._plan(2, 32, 32, dev)[1]
+    infer_ws = ae._plan(2, 32, 32, dev, "inference")[1]
+    assert infer_ws.numel() < train_ws.numel() and infer_ws.data_ptr() != train_ws.data_ptr()
