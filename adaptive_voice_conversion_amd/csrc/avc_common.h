@@ -7,7 +7,6 @@
 
 #define AVC_MAX_GROUPS 8
 #define AVC_THREADS 256
-#define AVC_WGRAD_MAXG 16
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +62,7 @@ struct ConvArgs {
     int ngroups;
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16; // AVC_COMPUTE_*
+    int rs;   // 1: g[0].wp is a register-stationary weight image -> conv_rs.hip
     // fused InstanceNorm epilogue (64x64 tile, Tout in {16, 32, 64}: every (b, m) row is complete inside the
     // tile): g[0].out <- conv + bias (y, kept for the backward), in_out <- relu(IN(y) * gamma + beta) [+ residual],
     // in_mean / in_rstd <- row statistics (index b * in_C + m)
@@ -76,24 +76,27 @@ struct ConvArgs {
     ConvGroup g[AVC_MAX_GROUPS];
 };
 
+// One layer of a weight-gradient launch.  Several layers that share a kernel instance (taps, tile shape,
+// addressing form) run as ONE batched launch: workgroup ids [wg_begin, wg_begin + tiles * nsplit) belong to
+// this layer, every workgroup of the launch walks the same number of 32-column K-chunks (balanced).
 struct WgradArgs {
     ConvSrc x;    // conv input  [B, Cin, Tin]   (reflect padded on the fly)
     ConvSrc dy;   // output grad [B, Cout, Tout]
     int B, Cin, Cout, Tin, Tout;
     int KS, padL, stride;
     int chunks_per_sample, total_chunks, chunks_per_wg, Tc, spc;  // K-split geometry (32 columns per chunk)
-    float* slab;   // [nsplit][Cout][Cin][KS] partial sums
+    float* slab;   // [nsplit][KS][Cout][Cin] partial sums (tap-major)
     float* dbslab; // [nsplit][Cout] partial bias sums (may be null)
     long slab_stride, db_stride;
-    int wrow0;     // row offset (bank/grouped layers write a sub-block)
-    int dbg;       // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16;      // AVC_COMPUTE_*
-    // grouped launch (ngroups > 1): blockIdx.z selects the operand pair of one of several layers of
-    // identical geometry (the speaker encoder's Linear stack); slab/dbslab advance by the group strides
-    int ngroups;
-    long gslab_stride, gdb_stride;
-    const float* gx[AVC_WGRAD_MAXG];
-    const float* gdy[AVC_WGRAD_MAXG];
+    int nsplit, tiles, wg_begin;  // filled by avc_wgrad_plan_batch / the launcher
+};
+#define AVC_WGRAD_MAXL 16
+struct WgradBatch {
+    int nlayers;
+    int dbg;   // ablation switches of the micro-benchmarks (0 in the product path)
+    int pad_[2];
+    WgradArgs L[AVC_WGRAD_MAXL];
 };
 
 struct ReduceSeg {

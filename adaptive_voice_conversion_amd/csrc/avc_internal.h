@@ -10,7 +10,10 @@ struct PackArgs {
     int Cout, Cin, KS;       // stacked forward shape
     int dgrad, CK, nchunk, M, Mp;
     float* dst;
+    int rs;       // 1: register-stationary image of conv_rs.hip (nsrc = 1): [slab][q][lane][4] + a zero block
+    int rs_nq, rs_nslab;
 };
+long avc_pack_total(const PackArgs& p);
 
 extern "C" int avc_conv_ck(int KS);
 int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups);
@@ -18,12 +21,24 @@ long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups);
 int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
+// register-stationary conv (conv_rs.hip)
+bool avc_conv_rs_eligible(int mode, int Cred, int KS, int stride, int Tout, int xps);
+long avc_conv_rs_image_floats(int M, int Cred, int KS);
+void avc_pack_rs_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst);
+int avc_launch_pack_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, hipStream_t stream);
+int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream);
+void avc_set_conv_rs(int on);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
 void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit);
+void avc_wgrad_geometry(WgradArgs& a);
+void avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);
+int avc_wgrad_target_wgs();
+int avc_launch_wgrad_batch(const WgradArgs* layers, int n, hipStream_t stream);
 int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
+#define AVC_REDUCE_MAXSEG 32
 int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream);
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
@@ -62,6 +77,7 @@ int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const lo
                                hipStream_t s);
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);
 
+void avc_set_wgrad_batch(int layers, int target_wgs);
 void avc_set_conv_ck5(int ck);
 void avc_set_wgrad_target_wgs(int n);
 void avc_set_in_variant(int v);

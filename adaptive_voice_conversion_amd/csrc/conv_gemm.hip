@@ -28,62 +28,7 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 
-#define AVC_CONV_NJ 6   // source-tile rows of up to 384 positions
-
-struct ConvGeom {
-    int b0, t0, SPT, ncols, SEG, seg_p0, ROWDATA, ROW;
-};
-
-static inline __host__ __device__ ConvGeom conv_geom(int mode, int stride, int Tout, int KS, int BN, int tile) {
-    ConvGeom q;
-    if (Tout >= BN) {
-        int tps = avc_cdiv(Tout, BN);
-        q.b0 = tile / tps;
-        q.t0 = (tile % tps) * BN;
-        q.SPT = 1;
-        q.ncols = BN;
-    } else {
-        q.SPT = BN / Tout;
-        q.b0 = tile * q.SPT;
-        q.t0 = 0;
-        q.ncols = Tout;
-    }
-    if (mode == 0) {
-        q.SEG = (q.ncols - 1) * stride + KS;
-        q.seg_p0 = q.t0 * stride;
-    } else {
-        // main window + both mirror windows of the reflect-padding adjoint (a column
-        // within padR of the end may sit in the last-but-one tile: +(KS-1) slack)
-        q.SEG = q.ncols + 3 * (KS - 1);
-        q.seg_p0 = q.t0;
-    }
-    q.ROWDATA = q.SPT * q.SEG;
-    q.ROW = q.ROWDATA + KS;  // trailing KS zeros: the "null window" of inactive mirror terms / masked columns
-    return q;
-}
-
-static inline __device__ float conv_load_res(const ConvArgs& a, const float* res, int b, int m, int t) {
-    const float* base = res + (long)b * a.rb + (long)m * a.rc;
-    switch (a.res_mode) {
-        case AVC_RES_IDENTITY:
-            return base[(long)t * a.rt];
-        case AVC_RES_AVGPOOL2: {
-            int i0 = 2 * t, i1 = 2 * t + 1;
-            float v0 = base[(long)i0 * a.rt];
-            if (i1 < a.Tres) return (v0 + base[(long)i1 * a.rt]) * 0.5f;
-            return v0;  // clipped window of ceil_mode: divisor 1
-        }
-        case AVC_RES_POOLT: {
-            float gsrc = base[(long)(t >> 1) * a.rt];
-            bool single = (a.Tout & 1) && (t == a.Tout - 1);
-            return single ? gsrc : gsrc * 0.5f;
-        }
-        case AVC_RES_UPT:
-            return base[(long)(2 * t) * a.rt] + base[(long)(2 * t + 1) * a.rt];
-        default:
-            return 0.f;
-    }
-}
+#include "conv_shared.h"
 
 // one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
 // of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR).
@@ -445,32 +390,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         if (!colv[wn]) continue;
-        const int b = colb[wn], t = colt[wn];
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m_tile0 + wave_m * (32 * WM) + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= a.M) continue;
-                float v = acc[wm][wn][r];
-                if (g.bias) v += g.bias[m];
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                long o;
-                if (a.ops == 1)
-                    o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
-                else
-                    o = (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
-                float rr = 0.f;
-                if (a.res_mode != AVC_RES_NONE) rr = conv_load_res(a, g.res, b, m, t);
-                if (a.res_to_primary) v += rr;
-                if (g.out) g.out[o] = v;
-                if (g.out2) {
-                    float v2 = a.res_to_primary ? v : v + rr;
-                    if (g.mask) v2 = (g.mask[o] > 0.f) ? v2 : 0.f;
-                    g.out2[o] = v2;
-                }
-            }
-        }
+        for (int wm = 0; wm < WM; ++wm)
+            conv_store_frag(a, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
     }
 }
 
@@ -498,6 +420,27 @@ __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs
 }
 
 static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride) {
+    if (p.rs) {  // register-stationary image (conv_rs.hip): ks = 4q + u = c2 * KS + j, c = 2 * c2 + (lane >> 5), m = 32 * slab + (lane & 31)
+        const long total = (long)p.rs_nslab * p.rs_nq * 256;
+        const int M = p.dgrad ? p.Cin : p.Cout, Cred = p.dgrad ? p.Cout : p.Cin;
+        const int NKS = p.KS * ((Cred + 1) / 2);
+        const float* w = p.src[0];
+        for (long e = first; e < total + 128; e += stride) {
+            float v = 0.f;   // (the last 128 floats: the zero block the DMA reads structural zeros from)
+            if (e < total) {
+                const int u = (int)(e & 3), lane = (int)((e >> 2) & 63);
+                const long rest = e >> 8;
+                const int q = (int)(rest % p.rs_nq), slab = (int)(rest / p.rs_nq);
+                const int ks = 4 * q + u;
+                const int c2 = ks / p.KS, j = ks - c2 * p.KS;
+                const int c = 2 * c2 + (lane >> 5), m = 32 * slab + (lane & 31);
+                if (ks < NKS && m < M && c < Cred)
+                    v = p.dgrad ? w[((long)c * p.Cin + m) * p.KS + (p.KS - 1 - j)] : w[((long)m * p.Cin + c) * p.KS + j];
+            }
+            p.dst[e] = v;
+        }
+        return;
+    }
     long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
     for (long e = first; e < total; e += stride) {
         int m = (int)(e % p.Mp);
@@ -604,6 +547,7 @@ void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
 
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
+    if (a_in.rs || force_tile == 99) return avc_launch_conv_rs(a_in, stream);
     ConvArgs a = a_in;
     a.dbg = g_conv_ablation;
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
@@ -659,6 +603,10 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     return (int)hipGetLastError();
 }
 
+long avc_pack_total(const PackArgs& p) {
+    return p.rs ? (long)p.rs_nslab * p.rs_nq * 256 + 128 : (long)p.nchunk * p.KS * p.CK * p.Mp;
+}
+
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {
     for (int i = 0; i < n; i += AVC_PACK_BATCH) {
         PackBatch b;
@@ -666,7 +614,7 @@ int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {
         long maxtotal = 1, bytes = 0;
         for (int k = 0; k < m; ++k) {
             b.a[k] = ps[i + k];
-            long t = (long)ps[i + k].nchunk * ps[i + k].KS * ps[i + k].CK * ps[i + k].Mp;
+            long t = avc_pack_total(ps[i + k]);
             maxtotal = t > maxtotal ? t : maxtotal;
             bytes += 8 * t;
         }
@@ -679,7 +627,7 @@ int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {
 }
 
 int avc_launch_pack(const PackArgs& p, hipStream_t stream) {
-    long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
+    long total = avc_pack_total(p);
     int blocks = (int)((total + AVC_THREADS * 4 - 1) / (AVC_THREADS * 4));
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;

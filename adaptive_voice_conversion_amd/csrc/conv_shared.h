@@ -1,0 +1,91 @@
+// Tile geometry and epilogue pieces shared by the conv kernels (conv_gemm.hip, conv_rs.hip).
+#pragma once
+#include "avc_common.h"
+
+#define AVC_CONV_NJ 6   // source-tile rows of up to 384 positions
+
+struct ConvGeom {
+    int b0, t0, SPT, ncols, SEG, seg_p0, ROWDATA, ROW;
+};
+
+static inline __host__ __device__ ConvGeom conv_geom(int mode, int stride, int Tout, int KS, int BN, int tile) {
+    ConvGeom q;
+    if (Tout >= BN) {
+        int tps = avc_cdiv(Tout, BN);
+        q.b0 = tile / tps;
+        q.t0 = (tile % tps) * BN;
+        q.SPT = 1;
+        q.ncols = BN;
+    } else {
+        q.SPT = BN / Tout;
+        q.b0 = tile * q.SPT;
+        q.t0 = 0;
+        q.ncols = Tout;
+    }
+    if (mode == 0) {
+        q.SEG = (q.ncols - 1) * stride + KS;
+        q.seg_p0 = q.t0 * stride;
+    } else {
+        // main window + both mirror windows of the reflect-padding adjoint (a column
+        // within padR of the end may sit in the last-but-one tile: +(KS-1) slack)
+        q.SEG = q.ncols + 3 * (KS - 1);
+        q.seg_p0 = q.t0;
+    }
+    q.ROWDATA = q.SPT * q.SEG;
+    q.ROW = q.ROWDATA + KS;  // trailing KS zeros: the "null window" of inactive mirror terms / masked columns
+    return q;
+}
+
+static inline __device__ float conv_load_res(const ConvArgs& a, const float* res, int b, int m, int t) {
+    const float* base = res + (long)b * a.rb + (long)m * a.rc;
+    switch (a.res_mode) {
+        case AVC_RES_IDENTITY:
+            return base[(long)t * a.rt];
+        case AVC_RES_AVGPOOL2: {
+            int i0 = 2 * t, i1 = 2 * t + 1;
+            float v0 = base[(long)i0 * a.rt];
+            if (i1 < a.Tres) return (v0 + base[(long)i1 * a.rt]) * 0.5f;
+            return v0;  // clipped window of ceil_mode: divisor 1
+        }
+        case AVC_RES_POOLT: {
+            float gsrc = base[(long)(t >> 1) * a.rt];
+            bool single = (a.Tout & 1) && (t == a.Tout - 1);
+            return single ? gsrc : gsrc * 0.5f;
+        }
+        case AVC_RES_UPT:
+            return base[(long)(2 * t) * a.rt] + base[(long)(2 * t + 1) * a.rt];
+        default:
+            return 0.f;
+    }
+}
+
+
+// Epilogue of one 32x32 accumulator fragment (C/D map of the 32x32 MFMAs: column = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): bias, ReLU, pixel-shuffle store index, residual /
+// gradient join, secondary output and ReLU mask of the backward pass.  m_base = first output row of the
+// fragment, (b, t) = the lane's column.
+static __device__ __forceinline__ void conv_store_frag(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, int m_base, int h,
+                                                       int b, int t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.M) continue;
+        float v = acc[r];
+        if (g.bias) v += g.bias[m];
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        long o;
+        if (a.ops == 1)
+            o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
+        else
+            o = (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
+        float rr = 0.f;
+        if (a.res_mode != AVC_RES_NONE) rr = conv_load_res(a, g.res, b, m, t);
+        if (a.res_to_primary) v += rr;
+        if (g.out) g.out[o] = v;
+        if (g.out2) {
+            float v2 = a.res_to_primary ? v : v + rr;
+            if (g.mask) v2 = (g.mask[o] > 0.f) ? v2 : 0.f;
+            g.out2[o] = v2;
+        }
+    }
+}

@@ -9,7 +9,9 @@
 // tile they already hold in LDS.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
+#include <vector>
 
 #include "avc_common.h"
 #include "avc_internal.h"
@@ -33,7 +35,12 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
 // issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
 template <int KS, int NB, int WCO, bool LIN, bool BF>
-__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
+    // which layer of the batch this workgroup works for (wave-uniform scan of <= 16 entries)
+    int layer = 0;
+    for (int i = 1; i < bt.nlayers; ++i) layer = ((int)blockIdx.x >= bt.L[i].wg_begin) ? i : layer;
+    const WgradArgs& a = bt.L[layer];
+    const int dbg = bt.dbg;
     constexpr int WCI = 4 / WCO;            // waves along ci
     constexpr int TCO = 32 * WCO;           // co rows per workgroup
     constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
@@ -46,19 +53,13 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
     const int ptid = tid & 255;   // thread index inside its role group
     const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
     const int ci_tiles = avc_cdiv(a.Cin, TCI);
-    const int co0 = (blockIdx.x / ci_tiles) * TCO, ci0 = (blockIdx.x % ci_tiles) * TCI;
-    const int z = blockIdx.y;
+    const int local = (int)blockIdx.x - a.wg_begin;
+    const int z = local / a.tiles, tile = local - z * a.tiles;   // split index, (co, ci) tile
+    const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
     const float* xptr = a.x.ptr;
     const float* dyptr = a.dy.ptr;
     float* slabp = a.slab;
     float* dbp = a.dbslab;
-    if (a.ngroups > 1) {
-        const int g = blockIdx.z;
-        xptr = a.gx[g];
-        dyptr = a.gdy[g];
-        slabp += (long)g * a.gslab_stride;
-        if (dbp) dbp += (long)g * a.gdb_stride;
-    }
     const int Tc = a.Tc, spc = a.spc;
     const int lgTc = 31 - __builtin_clz(Tc);
     const int XSEG = (Tc - 1) * a.stride + KS;
@@ -235,14 +236,14 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
     if (producer) {
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const int buf = (chunk - c_begin) & 1;
-            const bool more = (chunk + 1 < c_end) && !((a.dbg & 1) && chunk > c_begin);
+            const bool more = (chunk + 1 < c_end) && !((dbg & 1) && chunk > c_begin);
             if (more) issue(chunk + 1, buf ^ 1);
             if (do_db) {
                 const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) dbsum += dr[k];
             }
-            if (!(a.dbg & 4)) __syncthreads();
+            if (!(dbg & 4)) __syncthreads();
         }
         if (do_db) {
 #pragma unroll
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const int buf = (chunk - c_begin) & 1;
-        if (!(a.dbg & 2)) {
+        if (!(dbg & 2)) {
             const float* arow = dyT + buf * DYSP + (wave_m * 32 + li) * WG_DYROW;
             const float* brow = xT + buf * XSP + (wave_n * NB * 32 + li) * XROW;
             // fragments of k-step s+1 are requested before the MFMAs of step s are queued.  LIN (template): whole
@@ -323,14 +324,14 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
                 }
             }
         }
-        if (!(a.dbg & 4)) __syncthreads();
+        if (!(dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: partial tile -> slab[z][tap][co][ci]  (tap-major: the 32 lanes of a half-wave
     // hold 32 consecutive ci of one (tap, co) row -> 128-byte coalesced stores; the reduce kernel
     // restores the [co][ci][tap] parameter layout)
     float* slab = slabp + (long)z * a.slab_stride;
-    if (!(a.dbg & 8))
+    if (!(dbg & 8))
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int ci = ci0 + (wave_n * NB + nb) * 32 + li;
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradArgs 
 
 // out[e] = sum_z slab[z*stride + e]   (fixed order -> deterministic)
 struct ReduceArgs {
-    ReduceSeg seg[16];
+    ReduceSeg seg[AVC_REDUCE_MAXSEG];
     int nseg;
 };
 
@@ -386,91 +387,165 @@ static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
     }
 }
 
+static size_t wgrad_lds_bytes(const WgradArgs& a, int NB, int WCO) {
+    const int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
+    const int XSEG = (a.Tc - 1) * a.stride + a.KS;
+    const int XROW = (a.spc * XSEG) | 1;
+    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 16;
+}
+
+// kernel instance a layer runs on: (KS, NB, WCO, LIN); layers with equal keys can share a launch
+struct WgradKey {
+    int KS, NB, WCO, lin;
+    bool operator==(const WgradKey& o) const { return KS == o.KS && NB == o.NB && WCO == o.WCO && lin == o.lin; }
+};
+static WgradKey wgrad_key(const WgradArgs& a) {
+    WgradKey k;
+    k.KS = a.KS;
+    wgrad_shape(a.Cin, a.Cout, a.KS, &k.NB, &k.WCO);
+    if (k.KS == 1 && k.NB == 4 && wgrad_lds_bytes(a, 4, 4) > 158 * 1024) {  // LDS too small for the wide tile (many short samples)
+        k.NB = 1;
+        k.WCO = 2;
+    }
+    k.lin = (a.Tc == 32 && a.stride == 1) ? 1 : 0;
+    return k;
+}
+
 static int g_wgrad_target_wgs = 256;  // workgroups per launch the split-K aims for (avc_set_tuning)
 void avc_set_wgrad_target_wgs(int n) { g_wgrad_target_wgs = n >= 1 ? n : 256; }
+int avc_wgrad_target_wgs() { return g_wgrad_target_wgs; }
+
+// K-chunk geometry of one layer (32 columns of the (b, t) axis per chunk; short samples are packed)
+void avc_wgrad_geometry(WgradArgs& a) {
+    if (a.Tout >= 32) {
+        a.Tc = 32;
+        a.spc = 1;
+        a.chunks_per_sample = avc_cdiv(a.Tout, 32);
+        a.total_chunks = a.B * a.chunks_per_sample;
+    } else {
+        int p = 1;
+        while (p < a.Tout) p <<= 1;
+        a.Tc = p;
+        a.spc = 32 / p;
+        a.chunks_per_sample = 1;
+        a.total_chunks = avc_cdiv(a.B, a.spc);
+    }
+    const WgradKey k = wgrad_key(a);
+    a.tiles = avc_cdiv(a.Cout, 32 * k.WCO) * avc_cdiv(a.Cin, 32 * k.NB * (4 / k.WCO));
+}
+
+// Split-K factors of a batch.  Layers that share a kernel instance share a launch and get the SAME number
+// of K-chunks per workgroup (every chunk costs the same there, so the launch is balanced); the count is
+// chosen so that the launch has about `target_wgs` workgroups, but at least 4 chunks (128 columns) per
+// workgroup so that the slab write + fixed-order reduce stay a small fraction of the work.
+void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
+    if (target_wgs < 1) target_wgs = g_wgrad_target_wgs;
+    for (int i = 0; i < n; ++i) avc_wgrad_geometry(L[i]);
+    std::vector<char> done((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const WgradKey k = wgrad_key(L[i]);
+        long units = 0;
+        for (int j = i; j < n; ++j)
+            if (!done[j] && wgrad_key(L[j]) == k) units += (long)L[j].tiles * L[j].total_chunks;
+        int cpw = (int)((units + target_wgs - 1) / target_wgs);
+        if (cpw < 4) cpw = 4;
+        for (int j = i; j < n; ++j)
+            if (!done[j] && wgrad_key(L[j]) == k) {
+                int c = cpw < L[j].total_chunks ? cpw : L[j].total_chunks;
+                L[j].chunks_per_wg = c;
+                L[j].nsplit = avc_cdiv(L[j].total_chunks, c);
+                done[j] = 1;
+            }
+    }
+}
 
 void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit) {
-    if (Tout >= 32) {
-        *Tc = 32;
-        *spc = 1;
-        *chunks_per_sample = avc_cdiv(Tout, 32);
-        *total_chunks = B * *chunks_per_sample;
-    } else {
-        int p = 1;
-        while (p < Tout) p <<= 1;
-        *Tc = p;
-        *spc = 32 / p;
-        *chunks_per_sample = 1;
-        *total_chunks = avc_cdiv(B, *spc);
-    }
-    // split-K factor: enough workgroups to cover the 256 CUs, but at least 4 chunks (128 columns)
-    // per workgroup so that the slab write + fixed-order reduce stay a small fraction of the work
-    int NB, WCO;
-    wgrad_shape(Cin, Cout, KS, &NB, &WCO);
-    int tiles = avc_cdiv(Cout, 32 * WCO) * avc_cdiv(Cin, 32 * NB * (4 / WCO));
-    int want = g_wgrad_target_wgs / tiles;
-    if (want < 1) want = 1;
-    int maxsplit = avc_cdiv(*total_chunks, 4);
-    if (want > maxsplit) want = maxsplit;
-    *chunks_per_wg = avc_cdiv(*total_chunks, want);
-    *nsplit = avc_cdiv(*total_chunks, *chunks_per_wg);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tout = Tout; a.KS = KS; a.stride = 1;
+    avc_wgrad_plan_batch(&a, 1, g_wgrad_target_wgs);
+    *Tc = a.Tc; *spc = a.spc; *chunks_per_sample = a.chunks_per_sample; *total_chunks = a.total_chunks;
+    *chunks_per_wg = a.chunks_per_wg; *nsplit = a.nsplit;
 }
 
 template <int KS, int NB, int WCO>
-static int launch_wgrad_t(const WgradArgs& a, int nsplit, hipStream_t stream) {
-    constexpr int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
-    int XSEG = (a.Tc - 1) * a.stride + KS;
-    int XROW = (a.spc * XSEG) | 1;
-    size_t lds = (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 16;
+static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, bool bf, size_t lds, double flops, hipStream_t stream) {
     if (lds > 158 * 1024) return -3;
-    const int ng = a.ngroups > 1 ? a.ngroups : 1;
-    dim3 grid(avc_cdiv(a.Cout, TCO) * avc_cdiv(a.Cin, TCI), nsplit, ng);
-    ProfScope ps(AVC_K_CONV_WGRAD, 2.0 * ng * a.Cout * a.Cin * a.KS * (double)a.B * a.Tout, 0.0, stream);
-    const bool lin = a.Tc == 32 && a.stride == 1;
-    if (a.bf16 == AVC_COMPUTE_BF16) {
-        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, a);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, a);
-    } else if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, a);
+    dim3 grid(total_wgs);
+    ProfScope ps(AVC_K_CONV_WGRAD, flops, 0.0, stream);
+    if (bf) {
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, bt);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, bt);
     return (int)hipGetLastError();
 }
 
 template <int KS>
-static int launch_wgrad_ks(const WgradArgs& a, int nsplit, int WCO, hipStream_t stream) {
-    return WCO == 4 ? launch_wgrad_t<KS, 1, 4>(a, nsplit, stream) : launch_wgrad_t<KS, 1, 2>(a, nsplit, stream);
+static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, bool bf, size_t lds, double flops, hipStream_t stream) {
+    return k.WCO == 4 ? launch_wgrad_t<KS, 1, 4>(bt, total_wgs, k.lin, bf, lds, flops, stream)
+                      : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, lds, flops, stream);
 }
 
 // ablation bits of scripts/wgrad_ablate.py (timing experiments; results are wrong by construction when set)
 static int g_wgrad_ablation = 0;
 void avc_set_wgrad_ablation(int bits) { g_wgrad_ablation = bits; }
 
-int avc_launch_wgrad(const WgradArgs& a_in, int nsplit, hipStream_t stream) {
-    WgradArgs a = a_in;
-    a.dbg = g_wgrad_ablation;
-    if (a.KS < 1 || a.KS > 8 || a.ngroups > AVC_WGRAD_MAXG) return -1;
-    if (a.padL >= a.Tin) return -6;
-    int NB, WCO;
-    wgrad_shape(a.Cin, a.Cout, a.KS, &NB, &WCO);
-    if (a.KS == 1 && NB == 4) {
-        int rc = launch_wgrad_t<1, 4, 4>(a, nsplit, stream);
-        if (rc != -3) return rc;
-        return launch_wgrad_t<1, 1, 2>(a, nsplit, stream);  // LDS too small for the wide tile (many short samples)
+// launches every layer of the batch (planned by avc_wgrad_plan_batch, slabs assigned): one launch per kernel
+// instance present, <= AVC_WGRAD_MAXL layers per launch
+int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream) {
+    std::vector<char> done((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const WgradArgs& a0 = L[i];
+        if (a0.KS < 1 || a0.KS > 8) return -1;
+        const WgradKey k = wgrad_key(a0);
+        WgradBatch bt;
+        memset(&bt, 0, sizeof(bt));
+        bt.dbg = g_wgrad_ablation;
+        int wgs = 0;
+        size_t lds = 0;
+        double flops = 0;
+        for (int j = i; j < n && bt.nlayers < AVC_WGRAD_MAXL; ++j) {
+            if (done[j] || !(wgrad_key(L[j]) == k) || L[j].bf16 != a0.bf16) continue;
+            if (L[j].padL >= L[j].Tin) return -6;
+            WgradArgs& d = bt.L[bt.nlayers++];
+            d = L[j];
+            d.wg_begin = wgs;
+            wgs += d.tiles * d.nsplit;
+            size_t l = wgrad_lds_bytes(d, k.NB, k.WCO);
+            lds = l > lds ? l : lds;
+            flops += 2.0 * d.Cout * d.Cin * d.KS * (double)d.B * d.Tout;
+            done[j] = 1;
+        }
+        const bool bf = a0.bf16 == AVC_COMPUTE_BF16;
+        int rc;
+        if (k.KS == 1 && k.NB == 4) rc = launch_wgrad_t<1, 4, 4>(bt, wgs, k.lin, bf, lds, flops, stream);
+        else switch (k.KS) {
+            case 1: rc = launch_wgrad_ks<1>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 2: rc = launch_wgrad_ks<2>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 3: rc = launch_wgrad_ks<3>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 4: rc = launch_wgrad_ks<4>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 5: rc = launch_wgrad_ks<5>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 6: rc = launch_wgrad_ks<6>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 7: rc = launch_wgrad_ks<7>(bt, wgs, k, bf, lds, flops, stream); break;
+            default: rc = launch_wgrad_ks<8>(bt, wgs, k, bf, lds, flops, stream); break;
+        }
+        if (rc) return rc;
+        // (layers of this key beyond AVC_WGRAD_MAXL stay !done and open their own launch when the outer loop reaches them)
     }
-    switch (a.KS) {
-        case 1: return launch_wgrad_ks<1>(a, nsplit, WCO, stream);
-        case 2: return launch_wgrad_ks<2>(a, nsplit, WCO, stream);
-        case 3: return launch_wgrad_ks<3>(a, nsplit, WCO, stream);
-        case 4: return launch_wgrad_ks<4>(a, nsplit, WCO, stream);
-        case 5: return launch_wgrad_ks<5>(a, nsplit, WCO, stream);
-        case 6: return launch_wgrad_ks<6>(a, nsplit, WCO, stream);
-        case 7: return launch_wgrad_ks<7>(a, nsplit, WCO, stream);
-        default: return launch_wgrad_ks<8>(a, nsplit, WCO, stream);
-    }
+    return 0;
+}
+
+int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
+    (void)nsplit;
+    return avc_launch_wgrad_batch(&a, 1, stream);
 }
 
 int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {
-    if (n < 1 || n > 16) return -1;
+    if (n < 1 || n > AVC_REDUCE_MAXSEG) return -1;
     ReduceArgs r;
     r.nseg = n;
     int maxn = 0;

@@ -55,6 +55,9 @@ struct LayerP {
     long wpf = -1, wpd = -1, bpk = -1;
     int CK = 8, CKd = 8, nchunk_f = 0, nchunk_d = 0, Mp_f = 0, Mp_d = 0, dgM = 0;
     bool need_dgrad = true;
+    // register-stationary kernel (conv_rs.hip) for this layer's forward / input-gradient launch, and its images
+    bool rs_f = false, rs_d = false;
+    long wrs_f = -1, wrs_d = -1;
 };
 
 struct EncNet {
@@ -116,6 +119,8 @@ struct avc_plan {
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
     int flags = 0;            // AVC_PLAN_*
+    int wgrad_batch = 6;      // weight gradients per batched launch (captured at plan creation: the dry run sizes slabs and events with it)
+    int wgrad_target = 512;   // workgroups a batched weight-gradient launch aims for
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
 
@@ -157,7 +162,8 @@ static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool co
 }
 
 // Bn/Tf: batch and output length of the forward launch; Td: output length of the dgrad launch
-static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1) {
+// rs_ps: pixel-(un)shuffle factor of the dy view the dgrad launch reads (0: never the register-stationary kernel)
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, int rs_ps = 1) {
     L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
@@ -168,6 +174,10 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
     L.nchunk_f = avc_cdiv(L.Cin, L.CK);
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
+    L.rs_f = ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(0, L.Cin, L.KS, L.stride, Tf, 1);
+    L.rs_d = need_dgrad && ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(1, L.Cout, L.KS, L.stride, Td, rs_ps);
+    if (L.rs_f) L.wrs_f = p->alloc(avc_conv_rs_image_floats(L.Cout, L.Cin, L.KS));
+    if (L.rs_d) L.wrs_d = p->alloc(avc_conv_rs_image_floats(L.dgM, L.Cout, L.KS));
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
     if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CKd * L.Mp_d);
     if (L.nsrc > 1) L.bpk = p->alloc((long)32 * L.Mp_f);
@@ -213,6 +223,11 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
     }
 }
 
+static int g_wgrad_batch = 6, g_wgrad_batch_target = 512;  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
+void avc_set_wgrad_batch(int layers, int target_wgs) {
+    if (layers >= 1) g_wgrad_batch = layers;
+    if (target_wgs >= 1) g_wgrad_batch_target = target_wgs;
+}
 static void plan_init_streams(avc_plan* p);
 
 extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out) {
@@ -237,6 +252,8 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
     avc_plan* p = new avc_plan();
     p->cfg = *cfg;
     p->flags = flags;
+    p->wgrad_batch = g_wgrad_batch;
+    p->wgrad_target = g_wgrad_batch_target;
     p->B = B;
     p->T = T;
     p->Tc = T_cond;
@@ -313,7 +330,7 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
         finish_layer(p, p->layers[d.in_conv], dg, 0, B, p->Tb, p->Tb);
         for (int l = 0; l < d.n; ++l) {
             finish_layer(p, p->layers[d.c1[l]], dg, 0, B, d.T[l], d.T[l]);
-            finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l]);
+            finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l], 1, dc.upsample[l]);
         }
         finish_layer(p, p->layers[d.affine], dg, 0, 1, B, B);
         finish_layer(p, p->layers[d.out_conv], dg, 0, B, p->Tout, p->Tout);
@@ -633,7 +650,8 @@ static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, 
     a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
     a.M = L.Cout; a.Mp = L.Mp_f;
     a.ngroups = 1;
-    set_group(a.g[0], ws + L.wpf, layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+    set_group(a.g[0], ws + (L.rs_f ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+    a.rs = L.rs_f ? 1 : 0;
     a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.act = act;
@@ -652,7 +670,8 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
     a.ngroups = 1;
-    set_group(a.g[0], ws + L.wpd, nullptr, L.KS, L.CKd, L.nchunk_d);
+    set_group(a.g[0], ws + (L.rs_d ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
+    a.rs = L.rs_d ? 1 : 0;
     a.g[0].out = dx;
     return a;
 }
@@ -668,8 +687,8 @@ struct Reducer {
     hipStream_t s;
     bool dry;
     int flush(hipStream_t st) {
-        for (size_t i = 0; i < segs.size(); i += 16) {
-            int n = (int)std::min<size_t>(16, segs.size() - i);
+        for (size_t i = 0; i < segs.size(); i += AVC_REDUCE_MAXSEG) {
+            int n = (int)std::min<size_t>(AVC_REDUCE_MAXSEG, segs.size() - i);
             if (!dry) {
                 int rc = avc_launch_reduce_segs(&segs[i], n, st);
                 if (rc) return rc;
@@ -692,6 +711,14 @@ struct BwdCtx {
     hipStream_t wstream;   // stream of the weight-gradient kernels of the current branch (== s when not overlapping)
     int nev;
     long dy_used;
+    // weight gradients recorded but not launched yet: they run as batched launches (conv_wgrad.hip) once
+    // p->wgrad_batch layers are pending or a branch ends -- few large, balanced launches with short split-K
+    // instead of one launch per layer
+    struct PendW {
+        WgradArgs a;
+        const LayerP* L;
+    };
+    std::vector<PendW> pend;
     // every gradient tensor a (possibly still running) wgrad kernel reads gets its own buffer
     float* fresh(long n) {
         long off = dy_used;
@@ -712,126 +739,67 @@ static hipStream_t wgrad_edge(BwdCtx& c) {
     return c.wstream;
 }
 
-// Slab reduces of the weight gradients launched so far in this branch: queued on the branch's wgrad
-// stream right behind the kernels that fill the slabs, so they run under the other branches' work
-// instead of as a serial tail in front of the optimizer.
-static int flush_reduces(BwdCtx& c) {
+// Launch the pending weight gradients of this branch as batched launches on the branch's wgrad stream (ordered
+// behind everything queued on c.s so far: their dy operands are final), followed by the fixed-order slab
+// reduces into the flat gradient buffer.  Runs beside the dgrad / InstanceNorm-backward chain.
+static int flush_wgrads(BwdCtx& c) {
+    if (c.pend.empty()) return 0;
     hipStream_t ls = wgrad_edge(c);
+    const int n = (int)c.pend.size();
+    std::vector<WgradArgs> L((size_t)n);
+    for (int i = 0; i < n; ++i) L[i] = c.pend[i].a;
+    avc_wgrad_plan_batch(L.data(), n, c.p->wgrad_target);
+    for (int i = 0; i < n; ++i) {
+        WgradArgs& a = L[i];
+        const long wsz = (long)a.Cout * a.Cin * a.KS;
+        const long need = (long)a.nsplit * (wsz + a.Cout);
+        const long off = c.slab_used;
+        c.slab_used += (need + 63) / 64 * 64;
+        if (c.dry) continue;
+        a.slab = c.ws + c.p->slab + off;
+        a.slab_stride = wsz;
+        a.dbslab = a.slab + (long)a.nsplit * wsz;
+        a.db_stride = a.Cout;
+        const LayerP& Lp = *c.pend[i].L;
+        for (int s = 0; s < Lp.nsrc; ++s) {
+            ReduceSeg w;
+            w.slab = a.slab + (long)s * Lp.rows * Lp.Cin * Lp.KS;
+            w.dst = c.grads + c.p->params[Lp.w[s]].off;
+            w.stride = a.slab_stride;
+            w.n = (int)((long)Lp.rows * Lp.Cin * Lp.KS);
+            w.nsplit = a.nsplit;
+            w.KS = Lp.KS;
+            ReduceSeg b;
+            b.slab = a.dbslab + (long)s * Lp.rows;
+            b.dst = c.grads + c.p->params[Lp.b[s]].off;
+            b.stride = a.db_stride;
+            b.n = Lp.rows;
+            b.nsplit = a.nsplit;
+            b.KS = 1;
+            c.red.segs.push_back(w);
+            c.red.segs.push_back(b);
+        }
+    }
+    c.pend.clear();
+    if (c.dry) return 0;
+    int rc = avc_launch_wgrad_batch(L.data(), n, ls);
+    if (rc) return rc;
     return c.red.flush(ls);
 }
 
-// weight + bias gradient of layer L: x = forward input view, dy = output-gradient view
+// weight + bias gradient of layer L: x = forward input view, dy = output-gradient view (recorded; see flush_wgrads)
 static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, long xsc, int xst, const float* dy, long ysb,
-                       long ysc, int yst, int yps, int Bn, int Tin, int Tout, int row0 = 0, int rows = -1) {
-    // row0/rows: this launch covers forward output channels [row0, row0+rows) of the dy view given
-    WgradArgs a;
+                       long ysc, int yst, int yps, int Bn, int Tin, int Tout) {
+    BwdCtx::PendW pw;
+    WgradArgs& a = pw.a;
     memset(&a, 0, sizeof(a));
-    int Cout = rows < 0 ? L.Cout : rows;
     a.x.ptr = x; a.x.sb = xsb; a.x.sc = xsc; a.x.st = xst; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = ysb; a.dy.sc = ysc; a.dy.st = yst; a.dy.ps = yps;
-    a.B = Bn; a.Cin = L.Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
+    a.B = Bn; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride; a.bf16 = L.bf16;
-    int nsplit;
-    avc_wgrad_plan(Bn, L.Cin, Cout, Tout, L.KS, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
-    long wsz = (long)Cout * L.Cin * L.KS;
-    long need = (long)nsplit * (wsz + Cout);
-    long off = c.slab_used;
-    c.slab_used += (need + 63) / 64 * 64;
-    hipStream_t ls = wgrad_edge(c);  // order after the producer of dy, then run beside the main chain
-    if (c.dry) return 0;
-    a.slab = c.ws + c.p->slab + off;
-    a.slab_stride = wsz;
-    a.dbslab = a.slab + (long)nsplit * wsz;
-    a.db_stride = Cout;
-    int rc = avc_launch_wgrad(a, nsplit, ls);
-    if (rc) return rc;
-    for (int s = 0; s < L.nsrc; ++s) {
-        ReduceSeg w;
-        w.slab = a.slab + (long)s * L.rows * L.Cin * L.KS;
-        w.dst = c.grads + c.p->params[L.w[s]].off;
-        w.stride = a.slab_stride;
-        w.n = (int)((long)L.rows * L.Cin * L.KS);
-        w.nsplit = nsplit;
-        w.KS = L.KS;
-        ReduceSeg b;
-        b.slab = a.dbslab + (long)s * L.rows;
-        b.dst = c.grads + c.p->params[L.b[s]].off;
-        b.stride = a.db_stride;
-        b.n = L.rows;
-        b.nsplit = nsplit;
-        b.KS = 1;
-        c.red.segs.push_back(w);
-        c.red.segs.push_back(b);
-    }
-    return 0;
-}
-
-// Weight gradients of several Linear layers of identical geometry on [C][B] channel-major operands
-// (the speaker encoder's dense stack) as ONE grouped launch: alone each is a 2-workgroup kernel whose
-// ~25 us are launch + pipeline latency.
-static int wgrad_dense_group(BwdCtx& c, const LayerP* const* Ls, const float* const* xs, const float* const* dys, int n, int Bn) {
-    int i = 0;
-    while (i < n) {
-        int m = 1;
-        while (i + m < n && m < AVC_WGRAD_MAXG && Ls[i + m]->Cin == Ls[i]->Cin && Ls[i + m]->Cout == Ls[i]->Cout &&
-               Ls[i + m]->KS == 1 && Ls[i]->KS == 1 && Ls[i + m]->nsrc == 1 && Ls[i]->nsrc == 1)
-            ++m;
-        const LayerP& L = *Ls[i];
-        if (m == 1) {
-            int rc = wgrad_layer(c, L, xs[i], 0, Bn, 1, dys[i], 0, Bn, 1, 1, 1, Bn, Bn);
-            if (rc) return rc;
-            ++i;
-            continue;
-        }
-        WgradArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x.ptr = xs[i]; a.x.sb = 0; a.x.sc = Bn; a.x.st = 1; a.x.ps = 1;
-        a.dy.ptr = dys[i]; a.dy.sb = 0; a.dy.sc = Bn; a.dy.st = 1; a.dy.ps = 1;
-        a.B = 1; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Bn; a.Tout = Bn;
-        a.KS = 1; a.padL = 0; a.stride = 1; a.bf16 = L.bf16;
-        int nsplit;
-        avc_wgrad_plan(1, L.Cin, L.Cout, Bn, 1, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
-        const long wsz = (long)L.Cout * L.Cin;
-        const long per = ((long)nsplit * (wsz + L.Cout) + 63) / 64 * 64;
-        const long off = c.slab_used;
-        c.slab_used += per * m;
-        hipStream_t ls = wgrad_edge(c);
-        if (!c.dry) {
-            a.slab = c.ws + c.p->slab + off;
-            a.slab_stride = wsz;
-            a.dbslab = a.slab + (long)nsplit * wsz;
-            a.db_stride = L.Cout;
-            a.ngroups = m;
-            a.gslab_stride = per;
-            a.gdb_stride = per;
-            for (int g = 0; g < m; ++g) {
-                a.gx[g] = xs[i + g];
-                a.gdy[g] = dys[i + g];
-            }
-            int rc = avc_launch_wgrad(a, nsplit, ls);
-            if (rc) return rc;
-            for (int g = 0; g < m; ++g) {
-                const LayerP& Lg = *Ls[i + g];
-                ReduceSeg w;
-                w.slab = a.slab + (long)g * per;
-                w.dst = c.grads + c.p->params[Lg.w[0]].off;
-                w.stride = wsz;
-                w.n = (int)wsz;
-                w.nsplit = nsplit;
-                w.KS = 1;
-                ReduceSeg b;
-                b.slab = a.dbslab + (long)g * per;
-                b.dst = c.grads + c.p->params[Lg.b[0]].off;
-                b.stride = L.Cout;
-                b.n = L.Cout;
-                b.nsplit = nsplit;
-                b.KS = 1;
-                c.red.segs.push_back(w);
-                c.red.segs.push_back(b);
-            }
-        }
-        i += m;
-    }
+    pw.L = &L;
+    c.pend.push_back(pw);
+    if ((int)c.pend.size() >= c.p->wgrad_batch) return flush_wgrads(c);
     return 0;
 }
 
@@ -843,8 +811,18 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
     a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
     a.dst = ws + L.wpf;
-    out.push_back(a);
-    if (L.need_dgrad) {
+    if (L.rs_f) {   // only the image the launch will read
+        PackArgs r;
+        avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
+        out.push_back(r);
+    } else {
+        out.push_back(a);
+    }
+    if (L.need_dgrad && L.rs_d) {
+        PackArgs r;
+        avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d);
+        out.push_back(r);
+    } else if (L.need_dgrad) {
         a.dgrad = 1; a.CK = L.CKd; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
         a.dst = ws + L.wpd;
         out.push_back(a);
@@ -888,7 +866,7 @@ static int in_bwd(const float* g, const float* y, const float* stats, int Bn, in
 // (conv_gemm.hip): returns true and fills the epilogue fields, or false (caller launches in_fwd).
 static bool fuse_in(ConvArgs& a, const LayerP& L, int Bn, int C, const float* cond, long cond_sb, int cond_off, const float* res,
                     int res_mode, long rb, int Tres, float* out, float* stats, int Bfull, int b0) {
-    if (g_no_in_fusion) return false;
+    if (g_no_in_fusion || a.rs) return false;
     const int T = a.Tout;
     if (!(T == 16 || T == 32 || T == 64) || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
     if (avc_conv_pick_tile(a.Mp, Bn, T, 1) != 11) return false;
@@ -1216,17 +1194,16 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             w.dy.ptr = ws + La.wpf; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
             w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = p->compute;
-            int nsplit;
-            avc_wgrad_plan(1, w.Cin, w.Cout, w.Tout, 1, &w.Tc, &w.spc, &w.chunks_per_sample, &w.total_chunks, &w.chunks_per_wg, &nsplit);
+            avc_wgrad_plan_batch(&w, 1, 256);
             const long wsz = (long)w.Cout * w.Cin;
             const long off = c.slab_used;
-            c.slab_used += ((long)nsplit * wsz + 63) / 64 * 64;
+            c.slab_used += ((long)w.nsplit * wsz + 63) / 64 * 64;
             if (!dry) {
                 w.slab = ws + p->slab + off;
                 w.slab_stride = wsz;
                 w.dbslab = nullptr;
-                RUN(avc_launch_wgrad(w, nsplit, s));
-                RUN(avc_launch_reduce(w.slab, wsz, nsplit, (int)wsz, ws + p->demb, 1, s));  // demb: channel-major [c_cond][B]
+                RUN(avc_launch_wgrad_batch(&w, 1, s));
+                RUN(avc_launch_reduce(w.slab, wsz, w.nsplit, (int)wsz, ws + p->demb, 1, s));  // demb: channel-major [c_cond][B]
                 if (d_emb_up) RUN(avc_launch_add_transposed(ws + p->demb, d_emb_up, B, d.c.c_cond, s));
             }
         }
@@ -1235,7 +1212,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             float lk = lambda_kl / (float)((long)B * Cz * Tb);
             RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Cz, Tb, lk, ws + p->dmuls, s));
         }
-        RUN(flush_reduces(c));  // decoder gradients are complete
+        RUN(flush_wgrads(c));  // decoder gradients are complete
         // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
         // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
         if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
@@ -1293,7 +1270,8 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 gl[ng] = &p->layers[e.dn2[l]]; gx[ng] = ws + e.d1[l]; gdy[ng] = dzl[2 * l + 1]; ++ng;
                 gl[ng] = &p->layers[e.dn1[l]]; gx[ng] = ws + e.hd[l]; gdy[ng] = dzl[2 * l]; ++ng;
             }
-            RUN(wgrad_dense_group(c, gl, gx, gdy, ng, B));
+            // 13 Linear layers on [C][B] channel-major operands: same kernel instance -> ONE batched launch
+            for (int i = 0; i < ng; ++i) RUN(wgrad_layer(c, *gl[i], gx[i], 0, B, 1, gdy[i], 0, B, 1, 1, 1, B, B));
         }
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
@@ -1324,7 +1302,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
-        RUN(flush_reduces(c));
+        RUN(flush_wgrads(c));
         c.s = mainS;
         c.wstream = overlap ? p->wstream[0] : mainS;
     }
@@ -1362,7 +1340,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         dyA = c.fresh((long)B * C * e.T[0]);
         if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
-        RUN(flush_reduces(c));
+        RUN(flush_wgrads(c));
     }
 
     if (!dry) join_side(p, mainS, sideS);

@@ -17,6 +17,14 @@ void avc_set_debug_ablation(int conv_bits, int wgrad_bits) {
     avc_set_conv_ablation(conv_bits);
     avc_set_wgrad_ablation(wgrad_bits);
 }
+// register-stationary weight image of conv_rs.hip (tile code 99 of avc_conv1d_fwd / avc_conv1d_dgrad)
+long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad) {
+    return avc_conv_rs_image_floats(dgrad ? Cin : Cout, dgrad ? Cout : Cin, KS);
+}
+int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream) {
+    return avc_launch_pack_rs(w, Cout, Cin, KS, dgrad, dst, (hipStream_t)stream);
+}
+
 // device-side segment feed: out[b, m, t] = corpus[starts[b] + t, m]   (data_utils.py:10-22,51-54 on the device)
 int avc_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out, void* stream) {
     if (!corpus || !starts || !out) return -1;
@@ -29,6 +37,9 @@ int avc_set_tuning(const char* name, int value) {
     if (!strcmp(name, "conv_ck5")) avc_set_conv_ck5(value);
     else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
     else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
+    else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
+    else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
+    else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);      // workgroups such a launch aims for
     else return -1;
     return 0;
 }
@@ -119,8 +130,6 @@ long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
     avc_wgrad_plan(B, Cin, Cout, Tout, KS, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
     return (long)nsplit * ((long)Cout * Cin * KS + Cout);
 }
-
-// dW[co,ci,j] = sum_{b,t} dy[b,co,t] * reflect_pad(x)[b,ci,t*s+j] ; db[co] = sum dy[b,co,t]
 int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* dy, long syb, long syc, int syt, int yps,
                      int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride, float* dW, float* db, float* ws,
                      void* stream) {
@@ -131,12 +140,12 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = KS; a.padL = KS / 2; a.stride = stride;
-    int nsplit;
-    avc_wgrad_plan(B, Cin, Cout, Tout, KS, &a.Tc, &a.spc, &a.chunks_per_sample, &a.total_chunks, &a.chunks_per_wg, &nsplit);
+    avc_wgrad_plan_batch(&a, 1, avc_wgrad_target_wgs());
+    const int nsplit = a.nsplit;
     long wsz = (long)Cout * Cin * KS;
     a.slab = ws; a.slab_stride = wsz;
     a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;
-    int rc = avc_launch_wgrad(a, nsplit, (hipStream_t)stream);
+    int rc = avc_launch_wgrad_batch(&a, 1, (hipStream_t)stream);
     if (rc) return rc;
     rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, KS, (hipStream_t)stream);
     if (rc || !db) return rc;

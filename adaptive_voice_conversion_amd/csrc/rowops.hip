@@ -307,24 +307,26 @@ copy_rows_kernel(const float* x, long sxb, long sxc, int sxt, int B, int M, int 
 // Device-side data feed (reference: PickleDataset.__getitem__ + CollateFn, data_utils.py:10-22,
 // 51-54): segment b = rows [start[b], start[b]+T) of the HBM-resident corpus [sum_T][M] (mel bins contiguous),
 // emitted as out[b][m][t] with t contiguous -- the layout every first-layer loader reads with unit stride.
-// One workgroup = one sample x 32 frames: coalesced row reads -> LDS tile (odd row pitch) -> coalesced
-// 128-byte time runs per mel bin.
+// One workgroup = one sample x 32 frames x (up to) 128 mel bins: coalesced row reads -> LDS tile (odd row
+// pitch) -> coalesced 128-byte time runs per mel bin.
+#define AVC_GATHER_MB 128
 __global__ void __launch_bounds__(AVC_THREADS)
 gather_segments_kernel(const float* corpus, long n_rows, int M, const long* starts, int T, float* out) {
-    HIP_DYNAMIC_SHARED(float, tile)
-    const int b = blockIdx.y, t0 = blockIdx.x * 32;
-    const int pitch = M | 1;
+    __shared__ float tile[32 * (AVC_GATHER_MB + 1)];
+    const int b = blockIdx.y, t0 = blockIdx.x * 32, m0 = blockIdx.z * AVC_GATHER_MB;
+    const int mb = (M - m0) < AVC_GATHER_MB ? (M - m0) : AVC_GATHER_MB;
+    constexpr int pitch = AVC_GATHER_MB + 1;
     const long r0 = starts[b] + t0;
     const int nt = (T - t0) < 32 ? (T - t0) : 32;
-    for (int e = threadIdx.x; e < 32 * M; e += AVC_THREADS) {
-        const int row = e / M, col = e - row * M;
+    for (int e = threadIdx.x; e < 32 * mb; e += AVC_THREADS) {
+        const int row = e / mb, col = e - row * mb;
         long r = r0 + row;
         r = r < n_rows ? r : n_rows - 1;  // (rows past the segment / corpus end are never stored)
-        tile[row * pitch + col] = (row < nt) ? corpus[r * M + col] : 0.f;
+        tile[row * pitch + col] = (row < nt) ? corpus[r * M + m0 + col] : 0.f;
     }
     __syncthreads();
-    float* ob = out + ((long)b * M) * T + t0;
-    for (int e = threadIdx.x; e < 32 * M; e += AVC_THREADS) {
+    float* ob = out + ((long)b * M + m0) * T + t0;
+    for (int e = threadIdx.x; e < 32 * mb; e += AVC_THREADS) {
         const int m = e >> 5, t = e & 31;
         if (t < nt) ob[(long)m * T + t] = tile[t * pitch + m];
     }
@@ -589,9 +591,9 @@ int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int
 }
 int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out,
                                hipStream_t s) {
-    if (B < 1 || T < 1 || M < 1 || (size_t)32 * (M | 1) * 4 > 64 * 1024) return -1;
+    if (B < 1 || T < 1 || M < 1) return -1;
     ProfScope ps(AVC_K_MISC, 0.0, 8.0 * (double)B * M * T, s);
-    hipLaunchKernelGGL(gather_segments_kernel, dim3(avc_cdiv(T, 32), B), dim3(AVC_THREADS), (size_t)32 * (M | 1) * 4, s, corpus,
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(avc_cdiv(T, 32), B, avc_cdiv(M, AVC_GATHER_MB)), dim3(AVC_THREADS), 0, s, corpus,
                        n_rows, M, starts, T, out);
     return (int)hipGetLastError();
 }

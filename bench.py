@@ -133,12 +133,9 @@ def pmc_traffic(kernel_prefix, grid=None):
     return None, None
 
 
-def cpu_baseline(n_mels, T, budget_s=26.0):
-    """BASELINE.md §2 protocol on the host cores of this box with the oracle's forward (the same ATen CPU
-    ops the reference issues; the reference itself cannot travel to the GPU box -> kind "port"): real
-    in-place ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77,
-    81-97), a thread-count sweep, B in {4, 128, 256}, median of the timed steps, best segments/s reported.
-    Bounded: the sweep stops adding steps when the time budget is spent (>= 3 timed steps per point)."""
+def cpu_baseline_worker(n_mels, T):
+    """Child process of ``cpu_baseline``: prints one JSON line per finished measurement, most valuable first,
+    until the parent's deadline kills it."""
     import statistics
     from oracle import avc_oracle as O
     try:
@@ -147,7 +144,7 @@ def cpu_baseline(n_mels, T, budget_s=26.0):
         cores = os.cpu_count() or 1
     cfg = O.stock_config(n_mels)
     o = cfg["optimizer"]
-    t_start = time.perf_counter()
+    O.use_aten_ops(True)   # the reference's own op choices (F.pad reflect, F.instance_norm, ...): its cost profile
 
     def make(Bc):
         sd = O.make_state_dict(cfg, 0)
@@ -156,7 +153,7 @@ def cpu_baseline(n_mels, T, budget_s=26.0):
                                weight_decay=o["weight_decay"])
         x, eps = O.make_inputs(cfg, Bc, T, 0)
 
-        def step():
+        def step():   # solver.py:81-97 around the oracle's forward
             mu, ls, emb, dec = O.ae_forward(x, eps, params, cfg)
             loss_rec, loss_kl = O.losses(x, mu, ls, dec)
             loss = cfg["lambda"]["lambda_rec"] * loss_rec + 1.0 * loss_kl
@@ -166,41 +163,72 @@ def cpu_baseline(n_mels, T, budget_s=26.0):
             opt.step()
         return step
 
-    def timed(step, n_max, deadline):
+    def measure(Bc, threads, n_timed):
+        torch.set_num_threads(threads)
+        step = make(Bc)
         step()  # warm-up
         ts = []
-        while len(ts) < n_max and (len(ts) < 3 or time.perf_counter() < deadline):
+        for _ in range(n_timed):
             t0 = time.perf_counter()
             step()
             ts.append(time.perf_counter() - t0)
-        return statistics.median(ts), len(ts)
+            print(json.dumps({"B": Bc, "threads": threads, "steps": len(ts), "median_step_s": statistics.median(ts),
+                              "seg_per_s": Bc / statistics.median(ts), "host_cores": cores}), flush=True)
 
-    # 1. thread sweep on a small batch
-    cands = sorted({c for c in (8, 16, 32, cores) if c <= cores} or {cores})
-    thr = {}
-    st = make(32)
-    for c in cands:
-        torch.set_num_threads(c)
-        med, _ = timed(st, 3, 0.0)
-        thr[c] = 32 / med
-    best_threads = max(thr, key=thr.get)
-    torch.set_num_threads(best_threads)
-    # 2. batch sweep at the best thread count
-    per_b = {}
-    for Bc in (4, 128, 256):
-        left = budget_s - (time.perf_counter() - t_start)
-        if Bc == 256 and left < 6.0:
-            break
-        med, n = timed(make(Bc), 5, time.perf_counter() + left * (0.1 if Bc == 4 else 0.45))
-        per_b[Bc] = dict(median_step_s=med, steps=n, seg_per_s=Bc / med)
-    bb = max(per_b, key=lambda k: per_b[k]["seg_per_s"])
-    print(f"[bench] cpu_baseline: threads {thr} -> {best_threads}; batches {per_b}; {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
-    return dict(value=per_b[bb]["seg_per_s"], unit="mel-segments/sec", cores=best_threads, kind="port", host_cores=cores,
-                sample=(f"oracle forward + autograd backward + torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, torch CPU fp32; "
-                        f"thread sweep {sorted(thr)} at B=32 -> {best_threads} threads; B in {sorted(per_b)}: median of "
-                        f"{[per_b[k]['steps'] for k in sorted(per_b)]} timed steps (+1 warm-up each); best at B={bb}"),
-                thread_sweep_seg_per_s={str(k): round(v, 1) for k, v in thr.items()},
-                batch_sweep={str(k): {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per_b.items()})
+    measure(128, cores, 3)
+    best = {cores: None}
+    for c in [c for c in (32, 16, 8) if c < cores]:
+        measure(32, c, 2)
+    measure(32, cores, 2)
+    measure(4, cores, 5)
+    for c in [c for c in (32, 16, 8) if c < cores]:
+        measure(128, c, 3)
+    measure(256, cores, 3)
+
+
+def cpu_baseline(n_mels, T, budget_s=45.0):
+    """BASELINE.md §2 protocol on the host cores of this box with the oracle's forward (the same ATen CPU ops the
+    reference issues; the reference itself cannot travel to the GPU box -> kind "port"): real in-place
+    ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77, 81-97), thread
+    counts {8, 16, 32, all}, B in {4, 32, 128, 256}, one warm-up + median of the timed steps per point, best
+    segments/s reported.  The sweep runs in a child process under a HARD wall-clock budget: whatever points
+    finished by then are used (the line says which)."""
+    import select
+    import subprocess
+    t0 = time.perf_counter()
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--mels", str(n_mels), "--frames", str(T)],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1)
+    pts = {}
+    try:
+        while True:
+            left = budget_s - (time.perf_counter() - t0)
+            if left <= 0:
+                break
+            r, _, _ = select.select([proc.stdout], [], [], left)
+            if not r:
+                break
+            line = proc.stdout.readline()
+            if not line:
+                break
+            try:
+                d = json.loads(line)
+                pts[(d["B"], d["threads"])] = d
+            except Exception:
+                continue
+    finally:
+        proc.kill()
+        proc.wait()
+    if not pts:
+        raise RuntimeError(f"no CPU measurement finished within {budget_s:.0f} s")
+    best = max(pts.values(), key=lambda d: d["seg_per_s"])
+    print(f"[bench] cpu_baseline: {len(pts)} points in {time.perf_counter() - t0:.1f}s, best {best}", file=sys.stderr, flush=True)
+    return dict(value=best["seg_per_s"], unit="mel-segments/sec", cores=best["threads"], kind="port", host_cores=best["host_cores"],
+                sample=(f"oracle forward issuing the reference's ATen ops (F.pad reflect, conv1d, F.instance_norm, avg_pool1d(ceil), interpolate) + autograd backward + in-place torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, "
+                        f"torch CPU fp32; sweep over (batch, threads) under a {budget_s:.0f} s wall-clock budget: "
+                        f"{len(pts)} points finished (1 warm-up + median of the timed steps each); best = B {best['B']}, "
+                        f"{best['threads']} threads, median of {best['steps']} steps"),
+                points=[{"B": d["B"], "threads": d["threads"], "steps": d["steps"], "seg_per_s": round(d["seg_per_s"], 2)}
+                        for d in sorted(pts.values(), key=lambda d: (d["B"], d["threads"]))])
 
 
 def workload_label(a, world):
@@ -263,7 +291,12 @@ def main():
                     help="tracing aid: park the GPU this long before every timed step so that the (tracer-slowed) host has "
                          "the whole step enqueued when it starts; the reported time is then meaningless")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="avc_set_tuning knob applied before the plans are created (A/B measurements), e.g. conv_rs=0, wgrad_batch=1")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        return cpu_baseline_worker(a.mels, a.frames)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_ranks(a)   # does not return
@@ -287,6 +320,10 @@ def main():
     from adaptive_voice_conversion_amd.solver import Solver
     if a.single_stream:
         _lib.load().avc_set_single_stream(1)
+    for kv in a.tune:
+        k, v = kv.split("=")
+        if _lib.load().avc_set_tuning(k.encode(), int(v)) != 0:
+            raise SystemExit(f"unknown tuning knob {k!r}")
     cfg = stock_config(a.mels)
     if a.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
@@ -378,6 +415,7 @@ def main():
             "config": {"workload": workload + (" + device-side segment gather from an HBM-resident corpus inside the timed loop" if feed else ""),
                        "baseline_config_index": cfg_idx, "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
                        "world_size": world, "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
+                       "tuning": a.tune or None,
                        "allreduce": ("decoder range on a communication stream under the encoders' backward, encoders' range after it; "
                                      "RCCL via torch.distributed nccl") if world > 1 else None,
                        "final_losses": meta},

@@ -170,7 +170,9 @@ int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long
 
 /* tuning knobs of the micro-benchmark scripts: "conv_ck5" (8|16|32: chunk depth of k >= 4 convs at the op
  * level), "wgrad_target_wgs" (split-K workgroups per weight-gradient launch, default 256), "in_variant"
- * (InstanceNorm kernel variant).  Returns -1 for an unknown name. */
+ * (InstanceNorm kernel variant), "conv_rs" (0 = never the register-stationary conv kernel), "wgrad_batch" / "wgrad_batch_wgs"
+ * (layers per batched weight-gradient launch / workgroups it aims for; captured by plans created afterwards).
+ * Returns -1 for an unknown name. */
 int avc_set_tuning(const char* name, int value);
 
 /* ---- device-side segment feed (replaces PickleDataset.__getitem__ + CollateFn, data_utils.py:10-22,51-54,
@@ -184,6 +186,10 @@ long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad);
 /* W[Cout][Cin][KS] (nn.Conv1d / nn.Linear state_dict layout; nsrc tensors stacked on Cout) -> LDS-image order */
 int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Cout, int Cin, int KS, int dgrad,
                     float* dst, void* stream);
+/* weight image of the register-stationary conv kernel (csrc/conv_rs.hip; k = 5, 128 reduction channels):
+ * pass it as `wp` / `wpd` together with tile = 99 */
+long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad);
+int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
 /* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b); ops = pixel_shuffle_1d factor of the store
  * (model.py:52-59); res/res_mode: y2 = y + resmap(res) (1 identity, 2 avg_pool1d(2, ceil_mode) model.py:248) */
 int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp,

@@ -208,3 +208,4 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return 0; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)0x2; return 0; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)

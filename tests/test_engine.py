@@ -82,6 +82,7 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
+    ("emu", "tiny128", 3, 40, False),   # 128 hidden channels: the register-stationary conv kernel (conv_rs.hip) in the plan
     pytest.param("gpu", "tiny", 3, 24, True, marks=GPU),
     pytest.param("gpu", "m80", 4, 128, True, marks=GPU),
     pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
@@ -92,7 +93,7 @@ CASES = [
 
 
 def get_cfg(name):
-    return {"tiny": O.tiny_config, "m80": lambda: O.stock_config(80), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -129,7 +130,7 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     # T=24 reaches 3-frame rows at the bottleneck: InstanceNorm over 3 samples is ill-conditioned in
     # fp32 (the oracle's own fp32 vs fp64 gradients differ by 2.1e-4 on decoder.in_conv_layer.weight
     # there, 6e-6 at T=48; measured), so that case gets 5e-3; everything else the stated 1e-4.
-    illc = T <= 24 and cfgname != "tiny"
+    illc = T <= 24 and not cfgname.startswith("tiny")
     worst, med, total = check_grads(plan, grads, grads_m, tol=5e-3 if illc else 1e-4, cfg=cfg, zero_abs=2e-5 if illc else 1e-6)
     assert med < 2e-5
     uw, um, ut = check_grads(plan, grads, grads_ref, tol=None, cfg=cfg, zero_abs=2e-5 if illc else 1e-6)

@@ -287,3 +287,95 @@ def test_conv_bf16_operand_mode(kind, B, Cin, Cout, T, KS, stride):
         assert 1e-5 < err < 1e-2, err
     finally:
         lib.avc_set_op_compute_dtype(0)
+
+
+# ---- register-stationary conv kernel (csrc/conv_rs.hip): tile code 99 + its own weight image
+def pack_rs(lib, dev, w, dgrad):
+    Cout, Cin, KS = w.shape
+    n = lib.avc_packed_weight_floats_rs(Cout, Cin, KS, dgrad)
+    dst = torch.full((n,), float("nan"), device=dev)
+    assert lib.avc_pack_weight_rs(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
+    assert torch.isfinite(dst).all()
+    return dst
+
+
+RS_FWD = [
+    # B, Cout, T, stride
+    (2, 32, 40, 1),      # partial second tile
+    (1, 160, 32, 1),     # two 128-row slab groups, rows >= Cout masked
+    (3, 32, 16, 1),      # two samples per 32-column tile, B odd
+    (2, 32, 21, 2),      # stride 2, odd T
+    (2, 32, 70, 2),      # stride 2: 128-float LDS rows
+    (11, 32, 3, 1),      # bottleneck rows: 10 samples per tile
+    pytest.param(300, 128, 128, 1, marks=GPU),   # > 256 persistent workgroups' worth of tiles
+    pytest.param(256, 256, 64, 1, marks=GPU),
+    pytest.param(64, 128, 128, 2, marks=GPU),
+    pytest.param(200, 128, 16, 1, marks=GPU),
+    pytest.param(3, 128, 1024, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cout,T,stride", RS_FWD)
+def test_conv_rs_fwd_matches_pad_conv(kind, B, Cout, T, stride):
+    if kind == "emu" and B * Cout * T > 12000:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    Cin, KS = 128, 5
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    y = torch.relu(O.pad_conv(x, w, b, stride))
+    Tout = y.shape[2]
+    wp = pack_rs(lib, dev, w.to(dev), 0)
+    out = torch.full((B, Cout, Tout), float("nan"), device=dev)
+    out2 = torch.full_like(out, float("nan"))
+    xd, bd, rd = x.to(dev), b.to(dev), res.to(dev)
+    rmode = 2 if stride == 2 else 1
+    rc = lib.avc_conv1d_fwd(P(xd), xd.stride(0), xd.stride(1), xd.stride(2), B, Cin, T, P(wp), P(bd), Cout, KS, stride, 1, P(out),
+                            out.stride(0), out.stride(1), out.stride(2), 1, P(rd), rmode, rd.stride(0), rd.stride(1), rd.stride(2), T,
+                            P(out2), 99, None)
+    assert rc == 0, rc
+    torch.testing.assert_close(out.cpu(), y, rtol=1e-5, atol=2e-5)
+    rref = O.avg_pool_ceil(res, 2) if stride == 2 else res
+    torch.testing.assert_close(out2.cpu(), y + rref, rtol=1e-5, atol=2e-5)
+
+
+RS_DG = [
+    # B, Cin(out of dgrad), T, stride
+    (2, 32, 40, 1),
+    (1, 32, 70, 1),      # right mirror in the third tile
+    (3, 32, 16, 1),
+    (2, 32, 21, 2),
+    (2, 40, 66, 2),
+    (11, 32, 5, 1),      # short odd rows: 6 samples per tile, partial last tile
+    pytest.param(300, 128, 128, 1, marks=GPU),
+    pytest.param(64, 128, 128, 2, marks=GPU),
+    pytest.param(200, 128, 16, 1, marks=GPU),
+    pytest.param(3, 128, 1024, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,T,stride", RS_DG)
+def test_conv_rs_dgrad_matches_autograd(kind, B, Cin, T, stride):
+    if kind == "emu" and B * Cin * T > 12000:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    Cout, KS = 128, 5
+    g = torch.Generator().manual_seed(B * 7 + T)
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    y = O.pad_conv(x, w, None, stride)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    wpd = pack_rs(lib, dev, w.to(dev), 1)
+    dx = torch.full((B, Cin, T), float("nan"), device=dev)
+    dyd = dy.to(dev)
+    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), dyd.stride(2), 1, B, Cout, dy.shape[2], P(wpd), Cin,
+                              KS, stride, T, P(dx), dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None,
+                              None, 99, None)
+    assert rc == 0, rc
+    torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)

@@ -135,3 +135,25 @@ def test_committed_fixtures_equal_a_fresh_regeneration(golden_dir, tmp_path):
         assert set(a.files) == set(b.files), n
         for k in a.files:
             assert np.array_equal(a[k], b[k]), (n, k)
+
+
+def test_aten_op_mode_of_the_oracle_is_the_same_function(golden_dir):
+    """bench.py's cpu_baseline leg times the oracle with the reference's own ATen op choices
+    (O.use_aten_ops): same values as the explicit restatement and as the reference's golden."""
+    g = np.load(os.path.join(golden_dir, "train_m80_t128_b2.npz"))
+    cfg = O.stock_config(80)
+    sd = O.make_state_dict(cfg, int(g["seed"]))
+    x, eps = O.make_inputs(cfg, int(g["B"]), int(g["T"]), int(g["seed"]))
+    o1, g1 = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    O.use_aten_ops(True)
+    try:
+        o2, g2 = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    finally:
+        O.use_aten_ops(False)
+    np.testing.assert_allclose(o2["dec"].numpy(), g["dec"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(o2["dec"], o1["dec"], rtol=1e-5, atol=1e-5)
+    assert float(o2["loss_rec"]) == pytest.approx(float(g["loss_rec_0"]), rel=1e-5)
+    for k in g1:
+        d = g1[k].norm().item()
+        if d > 1e-6:
+            assert (g1[k] - g2[k]).norm().item() / d < 1e-4, k
