@@ -55,6 +55,16 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
         for (int q = 0; q < NQ; ++q) aw[q] = img[q * 64];
     }
 
+    // this wave's 16 accumulator rows are the same for every tile: bias once
+    const int m_base = blockIdx.y * 128 + wave * 32;
+    float biasv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+        biasv[r] = (g.bias && m < a.M) ? g.bias[m] : 0.f;
+    }
+    const bool has_res = a.res_mode != AVC_RES_NONE, has_mask = g.out2 && g.mask;
+
     const int ntiles = (Tout >= RS_BN) ? a.B * avc_cdiv(Tout, RS_BN) : avc_cdiv(a.B, RS_BN / Tout);
     const ConvGeom q0 = conv_geom(a.mode, a.stride, Tout, KS, RS_BN, 0);
     const int SEG = q0.SEG, ROWDATA = q0.ROWDATA, SPT = q0.SPT;
@@ -150,13 +160,31 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
         bool use_mirror = false;
         if (MIRROR) use_mirror = __any((cbl != ROWDATA) || (cbr != ROWDATA));
 
-        f32x16 acc0, acc1;
+        // residual / mask operands of the epilogue are requested now and land under the MFMA loop (a wave
+        // alone on its SIMD has nobody to hide an epilogue round trip behind)
+        const int bcol = q.b0 + bl;
+        float resv[16], maskv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+            resv[r] = 0.f;
+            maskv[r] = 1.f;
+            if (v && m < a.M) {
+                if (has_res) resv[r] = conv_load_res(a, g.res, bcol, m, t);
+                if (has_mask) maskv[r] = g.mask[(long)bcol * a.ob + (long)m * a.oc + (long)t * a.ot];   // (ops == 1 with a mask)
+            }
+        }
+
+        // four accumulators in rotation: an MFMA never waits on the one issued just before it
+        f32x16 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
         const float* xr = Xb + h * ROWP + cb;
-        const float* xl = Xb + h * ROWP + cbl;
-        const float* xrr = Xb + h * ROWP + cbr;
+        // a column is within pad of at most ONE edge of its sample (Tout >= 6, checked by the launcher): one mirror window
+        const float* xm = Xb + h * ROWP + (cbl != ROWDATA ? cbl : cbr);
         auto body = [&](auto mir_tag) {
             constexpr bool MIR = decltype(mir_tag)::value;
             // B fragments of channel pair c2 + 1 are requested before the MFMAs of pair c2 are queued
@@ -165,7 +193,7 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
                     float x = xr[2 * c2 * ROWP + j];
-                    if (MIR) x = x + xl[2 * c2 * ROWP + j] + xrr[2 * c2 * ROWP + j];
+                    if (MIR) x = x + xm[2 * c2 * ROWP + j];
                     d[j] = x;
                 }
             };
@@ -180,8 +208,7 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
                 for (int j = 0; j < KS; ++j) {
                     const int ks = c2 * KS + j;
                     const float av = aw[ks >> 2][ks & 3];
-                    if (c2 & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[c2 & 1][j], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[c2 & 1][j], acc0, 0, 0, 0);
+                    acc[ks & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[c2 & 1][j], acc[ks & 3], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -189,9 +216,25 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
         if (MIRROR && use_mirror) body(std::true_type{});
         else body(std::false_type{});
 
+        if (v) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
-        if (v) conv_store_frag(a, g, acc0, blockIdx.y * 128 + wave * 32, h, q.b0 + bl, t);
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= a.M) continue;
+                float val = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + biasv[r];
+                if (a.act == 1) val = fmaxf(val, 0.f);
+                long o;
+                if (a.ops == 1) o = (long)bcol * a.ob + (long)m * a.oc + (long)t * a.ot;
+                else o = (long)bcol * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
+                if (a.res_to_primary) val += resv[r];
+                if (g.out) g.out[o] = val;
+                if (g.out2) {
+                    float v2 = a.res_to_primary ? val : val + resv[r];
+                    if (has_mask) v2 = (maskv[r] > 0.f) ? v2 : 0.f;
+                    g.out2[o] = v2;
+                }
+            }
+        }
 
         __builtin_amdgcn_s_waitcnt(0);   // this wave's DMAs of the next tile have landed ...
         __syncthreads();                 // ... and everybody is done reading the current stage
@@ -206,14 +249,19 @@ __global__ void __launch_bounds__(256) conv_rs_kernel(const ConvArgs a) {
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
-static int g_conv_rs = 1;  // avc_set_tuning("conv_rs", 0|1): 0 = always the LDS-tiled kernel (A/B measurements)
+static int g_conv_rs = 0;  // avc_set_tuning("conv_rs", 0|1): plans created while it is 1 use this kernel where eligible.
+                           // Default 0: measured SLOWER than the LDS-tiled kernel on MI355X (profiles/r02_mfma_probe.log)
 void avc_set_conv_rs(int on) { g_conv_rs = on ? 1 : 0; }
 
 // shapes the register-stationary kernel is instantiated for: the k=5, 128-channel convs of the conv blocks
+static bool rs_shape_ok(int mode, int Cred, int KS, int stride, int Tout, int xps);
 bool avc_conv_rs_eligible(int mode, int Cred, int KS, int stride, int Tout, int xps) {
-    if (!g_conv_rs) return false;
+    return g_conv_rs && rs_shape_ok(mode, Cred, KS, stride, Tout, xps);
+}
+static bool rs_shape_ok(int mode, int Cred, int KS, int stride, int Tout, int xps) {
     if (KS != 5 || Cred != 128 || xps != 1) return false;
     if (stride != 1 && stride != 2) return false;
+    if (mode == 1 && Tout < 6) return false;   // (a column could be within pad of both edges: the kernel sums one mirror window)
     const ConvGeom q = conv_geom(mode, stride, Tout, KS, RS_BN, 0);
     return q.ROW <= 128;
 }
@@ -251,7 +299,7 @@ static void launch_rs_rowp(const ConvArgs& a, bool mir, dim3 grid, size_t lds, h
 int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream) {
     if (a.ngroups != 1 || a.in_fuse) return -1;
     const ConvGroup& g = a.g[0];
-    if (!avc_conv_rs_eligible(a.mode, a.Cred, g.KS, a.stride, a.Tout, a.x.ps)) return -2;
+    if (!rs_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout, a.x.ps)) return -2;
     if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;
     const ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, g.KS, RS_BN, 0);
     const int ROWP = q.ROW <= 64 ? 64 : 128;

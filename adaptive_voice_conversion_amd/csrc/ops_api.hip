@@ -56,6 +56,7 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
                     float* dst, void* stream) {
     if (nsrc < 1 || nsrc > 12 || nsrc * rows_per_src != Cout) return -1;
     PackArgs p;
+    memset(&p, 0, sizeof(p));
     for (int i = 0; i < nsrc; ++i) p.src[i] = srcs[i];
     p.nsrc = nsrc;
     p.rows_per_src = rows_per_src;

@@ -350,7 +350,7 @@ RS_DG = [
     (3, 32, 16, 1),
     (2, 32, 21, 2),
     (2, 40, 66, 2),
-    (11, 32, 5, 1),      # short odd rows: 6 samples per tile, partial last tile
+    (11, 32, 6, 1),      # short rows: 5 samples per tile, partial last tile
     pytest.param(300, 128, 128, 1, marks=GPU),
     pytest.param(64, 128, 128, 2, marks=GPU),
     pytest.param(200, 128, 16, 1, marks=GPU),
