@@ -33,7 +33,9 @@
 // one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
 // of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR).
 // A "unit" is 4 k-steps (8 reduction channels of one tap).
-template <int WM, int WN, bool MIRROR>
+// MIR: 0 = no mirror window, 1 = ONE mirror window per column (cbl; a column of a sample of >= 6 frames is within pad
+// of at most one edge), 2 = both windows (very short samples)
+template <int WM, int WN, int MIR>
 static __device__ __forceinline__ void conv_load_unit(float (&av)[4][WM], float (&bv)[4][WN], const float* Arow, const float* Xrow,
                                                       int ROW, const int (&cb)[WN], const int (&cbl)[WN], const int (&cbr)[WN]) {
     constexpr int BM = 64 * WM;
@@ -45,7 +47,8 @@ static __device__ __forceinline__ void conv_load_unit(float (&av)[4][WM], float 
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             float v = xr[cb[wn]];
-            if (MIRROR) v = v + xr[cbl[wn]] + xr[cbr[wn]];
+            if (MIR == 1) v = v + xr[cbl[wn]];
+            if (MIR == 2) v = v + xr[cbl[wn]] + xr[cbr[wn]];
             bv[u][wn] = v;
         }
     }
@@ -76,7 +79,7 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], cons
 // KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
 // block with the fragments of unit u+1 fetched from LDS before the MFMAs of unit u are issued
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, bool BF>
+template <int WM, int WN, int MIR, int KSC, int GRC, bool BF>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
                                                       int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
                                                       const int (&cbr)[WN]) {
@@ -92,12 +95,12 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
         };
         const float *Ar, *Xr;
         unit_ptrs(0, Ar, Xr);
-        conv_load_unit<WM, WN, MIRROR>(av[0], bv[0], Ar, Xr, ROW, cb, cbl, cbr);
+        conv_load_unit<WM, WN, MIR>(av[0], bv[0], Ar, Xr, ROW, cb, cbl, cbr);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u + 1 < U) {
                 unit_ptrs(u + 1, Ar, Xr);
-                conv_load_unit<WM, WN, MIRROR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
+                conv_load_unit<WM, WN, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
             }
             // (pinning this order with sched_barrier(0) was measured: no gain with 4 waves/SIMD, r1 log)
             conv_mma_unit<WM, WN, BF>(acc, av[u & 1], bv[u & 1]);
@@ -109,7 +112,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
             const float* Xrow = Xb + h * ROW + tap;
             for (int g4 = 0; g4 < groups; ++g4) {
                 float av[4][WM], bv[4][WN];
-                conv_load_unit<WM, WN, MIRROR>(av, bv, Arow, Xrow, ROW, cb, cbl, cbr);
+                conv_load_unit<WM, WN, MIR>(av, bv, Arow, Xrow, ROW, cb, cbl, cbr);
                 conv_mma_unit<WM, WN, BF>(acc, av, bv);
                 Arow += 8 * BM;
                 Xrow += 8 * ROW;
@@ -229,10 +232,14 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     // reflect-adjoint windows are needed only by waves that own a column within pad of a sample edge
     bool use_mirror = false;
+    const bool one_window = Tout >= 2 * (padL + padR) + 2;   // left-edge columns [1, padL] and right-edge columns [Tout-1-padR, Tout-2] are disjoint
     if (MIRROR) {
         bool mine = false;
 #pragma unroll
-        for (int wn = 0; wn < WN; ++wn) mine |= (cbl[wn] != q.ROWDATA) || (cbr[wn] != q.ROWDATA);
+        for (int wn = 0; wn < WN; ++wn) {
+            mine |= (cbl[wn] != q.ROWDATA) || (cbr[wn] != q.ROWDATA);
+            if (one_window && cbl[wn] == q.ROWDATA) cbl[wn] = cbr[wn];   // the column's only mirror window
+        }
         use_mirror = __any(mine);
     }
 
@@ -285,10 +292,12 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         const float* Ab = As + (it & 1) * AS;
         const float* Xb = Xs + (it & 1) * XS;
         if ((a.dbg & 2) || chunk >= nchunk) {
-        } else if (MIRROR && use_mirror)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, WN, true, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+        } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
+            conv_chunk_mma<WM, WN, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+        else if (MIRROR && use_mirror)
+            conv_chunk_mma<WM, WN, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else
-            conv_chunk_mma<WM, WN, false, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, WN, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         if (!(a.dbg & 4)) __syncthreads();
     }
 

@@ -450,6 +450,14 @@ void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
             if (!done[j] && wgrad_key(L[j]) == k) units += (long)L[j].tiles * L[j].total_chunks;
         int cpw = (int)((units + target_wgs - 1) / target_wgs);
         if (cpw < 4) cpw = 4;
+        // the launch must FIT the target (one workgroup per CU is resident: a 257th workgroup is a second round
+        // that doubles the launch time): grow the chunk run until the per-layer round-ups fit
+        for (;; ++cpw) {
+            long wgs = 0;
+            for (int j = i; j < n; ++j)
+                if (!done[j] && wgrad_key(L[j]) == k) wgs += (long)L[j].tiles * avc_cdiv(L[j].total_chunks, cpw);
+            if (wgs <= target_wgs || cpw >= (1 << 20)) break;
+        }
         for (int j = i; j < n; ++j)
             if (!done[j] && wgrad_key(L[j]) == k) {
                 int c = cpw < L[j].total_chunks ? cpw : L[j].total_chunks;

@@ -120,7 +120,7 @@ struct avc_plan {
     long dyarena = -1, dyarena_floats = 0;
     int flags = 0;            // AVC_PLAN_*
     int wgrad_batch = 12;      // weight gradients per batched launch (captured at plan creation: the dry run sizes slabs and events with it)
-    int wgrad_target = 512;   // workgroups a batched weight-gradient launch aims for
+    int wgrad_target = 256;   // workgroups a batched weight-gradient launch aims for
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
 
@@ -223,7 +223,7 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
     }
 }
 
-static int g_wgrad_batch = 12, g_wgrad_batch_target = 512;  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
+static int g_wgrad_batch = 12, g_wgrad_batch_target = 256;  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
 void avc_set_wgrad_batch(int layers, int target_wgs) {
     if (layers >= 1) g_wgrad_batch = layers;
     if (target_wgs >= 1) g_wgrad_batch_target = target_wgs;
