@@ -527,7 +527,11 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
 static int g_force_single = 0;
 extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
 static int g_no_in_fusion = 1;  // 1 = InstanceNorm always as its own row kernel (default: the fused epilogue measured slower)
-extern "C" void avc_set_in_fusion(int on) { g_no_in_fusion = on ? 0 : 1; }
+static int g_in_fusion_max_t = 64;  // rows up to this length are fused when fusion is on (16 | 32 | 64)
+extern "C" void avc_set_in_fusion(int on) {
+    g_no_in_fusion = on ? 0 : 1;
+    g_in_fusion_max_t = (on == 16 || on == 32) ? on : 64;   // avc_set_in_fusion(16 | 32): only the latency-bound short rows
+}
 static int g_dec_split_min = 32;  // smallest batch whose decoder forward runs as two half-batch chains
 extern "C" void avc_set_decoder_split_min(int n) { g_dec_split_min = n < 2 ? 2 : n; }
 
@@ -868,7 +872,7 @@ static bool fuse_in(ConvArgs& a, const LayerP& L, int Bn, int C, const float* co
                     int res_mode, long rb, int Tres, float* out, float* stats, int Bfull, int b0) {
     if (g_no_in_fusion || a.rs) return false;
     const int T = a.Tout;
-    if (!(T == 16 || T == 32 || T == 64) || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
+    if (!(T == 16 || T == 32 || T == 64) || T > g_in_fusion_max_t || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
     if (avc_conv_pick_tile(a.Mp, Bn, T, 1) != 11) return false;
     if (res && !(res_mode == AVC_RES_IDENTITY || res_mode == AVC_RES_AVGPOOL2)) return false;
     a.in_fuse = 1;

@@ -9,6 +9,7 @@
 #include "avc_internal.h"
 
 extern "C" {
+void avc_set_in_fusion(int on);
 
 // compute dtype of the op-level conv entry points (the whole-model path takes it from the plan)
 static int g_op_compute = AVC_COMPUTE_F32;
@@ -37,6 +38,7 @@ int avc_set_tuning(const char* name, int value) {
     if (!strcmp(name, "conv_ck5")) avc_set_conv_ck5(value);
     else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
     else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
+    else if (!strcmp(name, "in_fusion")) avc_set_in_fusion(value);
     else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
     else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
     else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);      // workgroups such a launch aims for

@@ -73,19 +73,39 @@ class Inferencer(object):
         wav = self.mel2wav(dec) if self.mel2wav is not None else None
         return wav, dec
 
-    def convert_batch(self, pairs):
-        """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T')
-        share one engine call.  Returns the converted mels ([T'',M] CPU tensors) in input order."""
+    def convert_batch(self, pairs, max_streams=4):
+        """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T') share one engine
+        call (the batch axis of the plan); DIFFERENT shapes are issued on up to ``max_streams`` HIP streams so that
+        the many small, launch-bound passes of real utterance traffic overlap on the device instead of running one
+        after the other (the reference runs batch 1, inference.py:62-70).  Lengths are never padded: reflect padding
+        and the InstanceNorm statistics depend on the true length, so padding would change the result.
+        Returns the converted mels ([T'',M] CPU tensors) in input order."""
         dev = self.model.flat_parameters().device
         buckets = defaultdict(list)
         for i, (s, t) in enumerate(pairs):
             buckets[(s.shape[0], t.shape[0])].append(i)
         out = [None] * len(pairs)
+        cuda = dev.type == "cuda"
+        streams = [torch.cuda.Stream(device=dev) for _ in range(min(max_streams, len(buckets)))] if cuda and len(buckets) > 1 else []
+        main = torch.cuda.current_stream(dev) if cuda else None
+        results = []
         with torch.no_grad():
-            for (_, _), idx in buckets.items():
+            for k, ((_, _), idx) in enumerate(sorted(buckets.items(), key=lambda kv: -kv[0][0] * len(kv[1]))):   # big buckets first
                 xs = torch.stack([pairs[i][0] for i in idx]).to(dev).transpose(1, 2)   # [B, M, T] views, no copy
                 xc = torch.stack([pairs[i][1] for i in idx]).to(dev).transpose(1, 2)
-                dec = self.model.inference(xs, xc).transpose(1, 2).cpu()
+                if streams:
+                    st = streams[k % len(streams)]
+                    st.wait_stream(main)                      # inputs were produced on the caller's stream
+                    with torch.cuda.stream(st):
+                        dec = self.model.inference(xs, xc)    # (one plan + workspace per shape: independent of other buckets)
+                        xs.record_stream(st), xc.record_stream(st)
+                else:
+                    dec = self.model.inference(xs, xc)
+                results.append((idx, dec))
+            for st in streams:
+                main.wait_stream(st)
+            for idx, dec in results:
+                dec = dec.transpose(1, 2).cpu()
                 for k, i in enumerate(idx):
                     out[i] = dec[k]
         return out

@@ -124,7 +124,7 @@ void avc_set_debug_ablation(int conv_bits, int wgrad_bits);
 /* 1 = InstanceNorm / AdaIN / ReLU of rows that fit one conv tile (T_l = 16, 32, 64) run in the producing
  * conv's epilogue; 0 (default) = always as their own row kernels.  Experimental: same results, but the
  * fused epilogue measured 2-4 % slower end to end on MI355X than the stand-alone row kernels. */
-void avc_set_in_fusion(int on);
+void avc_set_in_fusion(int on);   /* 0 off (default), 1 = rows of 16/32/64 frames, 16 | 32 = only rows up to that length */
 
 /* smallest batch whose decoder forward is issued as two half-batch kernel chains on two streams
  * (default 32; tuning / test knob, results are the same function either way) */
