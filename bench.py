@@ -111,26 +111,50 @@ def instnorm_dominant_shape(B, C, T, launches=50):
 PMC_SUMMARIES = ("r02_pmc_fetch_write_summary.json", "r01_pmc_fetch_write_summary.json")
 
 
-def pmc_traffic(kernel_prefix, grid=None):
-    """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (separate
-    --pmc runs of this same command; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md §HBM prescribes, KB
-    units).  Returns (bytes, source file) or (None, None).  It is a replayed profile of the same build,
-    not a counter read of THIS run -- the line says so in "traffic_source"."""
+def _pmc_load():
     for fn in PMC_SUMMARIES:
-        path = os.path.join(ROOT, "profiles", fn)
         try:
-            d = json.load(open(path))
+            return json.load(open(os.path.join(ROOT, "profiles", fn))), f"profiles/{fn}"
         except Exception:
             continue
-        for name, grids in d.items():
-            if not name.startswith(kernel_prefix):
-                continue
-            keys = [str(grid)] if grid is not None else sorted(grids, key=lambda k: -grids[k].get("FETCH_SIZE", {}).get("launches", 0))
-            for k in keys:
-                c = grids.get(k)
-                if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, f"profiles/{fn}"
     return None, None
+
+
+def pmc_traffic(kernel_prefix, grid=None):
+    """HBM bytes per launch of ONE kernel instance (name prefix + grid size) from the rocprofv3 PMC passes committed
+    under profiles/ (separate --pmc runs of this same command; FETCH_SIZE doubled on gfx950 as
+    MI355X_MICROARCH.md §HBM prescribes, KB units).  Returns (bytes, source file) or (None, None).  It is a
+    replayed profile of the same build, not a counter read of THIS run -- the line says so in "traffic_source"."""
+    d, src = _pmc_load()
+    if d is None:
+        return None, None
+    for name, grids in d.items():
+        if name.startswith(kernel_prefix):
+            c = grids.get(str(grid))
+            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, src
+    return None, None
+
+
+def pmc_class_traffic(cls):
+    """Launch-weighted mean HBM bytes per launch over every kernel instance of a kernel CLASS of the profile
+    (the same population bench.py's per-class event brackets average over)."""
+    match = {"conv_wgrad": lambda n: n.startswith("conv_wgrad_kernel"),
+             "conv_fwd": lambda n: n.startswith("conv_gemm_kernel") and ", true, " not in n.split("(")[0][:40],
+             "conv_dgrad": lambda n: n.startswith("conv_gemm_kernel") and ", true, " in n.split("(")[0][:40]}.get(cls)
+    d, src = _pmc_load()
+    if d is None or match is None:
+        return None, None
+    tot = launches = 0.0
+    for name, grids in d.items():
+        if not match(name):
+            continue
+        for c in grids.values():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                n = c["FETCH_SIZE"]["launches"]
+                tot += n * (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+                launches += n
+    return (tot / launches, src) if launches else (None, None)
 
 
 def cpu_baseline_worker(n_mels, T):
@@ -175,22 +199,22 @@ def cpu_baseline_worker(n_mels, T):
             print(json.dumps({"B": Bc, "threads": threads, "steps": len(ts), "median_step_s": statistics.median(ts),
                               "seg_per_s": Bc / statistics.median(ts), "host_cores": cores}), flush=True)
 
-    measure(128, cores, 3)
-    best = {cores: None}
-    for c in [c for c in (32, 16, 8) if c < cores]:
-        measure(32, c, 2)
-    measure(32, cores, 2)
-    measure(4, cores, 5)
-    for c in [c for c in (32, 16, 8) if c < cores]:
+    # most promising points first (MKL / oneDNN stop scaling well before the core count of a GPU host, and 128+
+    # threads are catastrophically slow): B = 128 at 32, 16, 64, 8 threads, then B = 256 and B = 4
+    cands = [c for c in (32, 16, 64, 8) if c <= cores] or [cores]
+    for c in cands:
         measure(128, c, 3)
-    measure(256, cores, 3)
+    for c in cands[:2]:
+        measure(256, c, 3)
+    measure(4, cands[0], 5)
+    measure(32, cands[0], 3)
 
 
 def cpu_baseline(n_mels, T, budget_s=45.0):
     """BASELINE.md §2 protocol on the host cores of this box with the oracle's forward (the same ATen CPU ops the
     reference issues; the reference itself cannot travel to the GPU box -> kind "port"): real in-place
     ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77, 81-97), thread
-    counts {8, 16, 32, all}, B in {4, 32, 128, 256}, one warm-up + median of the timed steps per point, best
+    counts {8, 16, 32, 64}, B in {4, 32, 128, 256}, one warm-up + median of the timed steps per point, best
     segments/s reported.  The sweep runs in a child process under a HARD wall-clock budget: whatever points
     finished by then are used (the line says which)."""
     import select
@@ -425,12 +449,12 @@ def main():
             dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
             d = prof[dom]
             peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-            pmc_prefix = {"conv_wgrad": "conv_wgrad", "conv_fwd": "conv_gemm_kernel", "conv_dgrad": "conv_gemm_kernel"}.get(dom, dom)
-            traffic, tsrc = pmc_traffic(pmc_prefix) if (cfg_idx == 1) else (None, None)
+            traffic, tsrc = pmc_class_traffic(dom) if (cfg_idx == 1) else (None, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
                                "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
-                               "traffic_source": (f"{tsrc}: HBM bytes per launch of the most-launched instance of this kernel class, rocprofv3 --pmc "
-                                                  "passes of this command on the same build (not a counter read of this run)") if tsrc else None,
+                               "traffic_source": (f"{tsrc}: launch-weighted mean HBM bytes per launch over the kernel instances of this class "
+                                                  "(2 x FETCH_SIZE + WRITE_SIZE), separate rocprofv3 --pmc passes of this command on the same "
+                                                  "build (replayed, not a counter read of this run)") if tsrc else None,
                                "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
                                "ms_per_step": d["ms_per_step"],
                                "whole_step": {"algorithmic_tflop_per_step": TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3,
