@@ -78,7 +78,9 @@ int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const lo
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);
 
 void avc_set_wgrad_batch(int layers, int target_wgs);
+void avc_set_wgrad_units(long units);
 void avc_set_conv_ck5(int ck);
+void avc_set_bank_switch(int on);
 void avc_set_wgrad_target_wgs(int n);
 void avc_set_in_variant(int v);
 void avc_set_conv_ablation(int bits);

@@ -296,7 +296,21 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             conv_chunk_mma<WM, WN, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else if (MIRROR && use_mirror)
             conv_chunk_mma<WM, WN, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-        else
+        else if constexpr (KSC < 0) {
+            // grouped launch of layers with different tap counts (the conv bank, k = 1..8): the workgroup's (taps,
+            // chunk depth) pair is uniform, so each pair gets its own straight-line chunk
+            switch (KS * 8 + (CK >> 3)) {
+                case 1 * 8 + 4: conv_chunk_mma<WM, WN, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 2 * 8 + 2: conv_chunk_mma<WM, WN, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 3 * 8 + 2: conv_chunk_mma<WM, WN, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 4 * 8 + 1: conv_chunk_mma<WM, WN, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 5 * 8 + 1: conv_chunk_mma<WM, WN, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 6 * 8 + 1: conv_chunk_mma<WM, WN, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 7 * 8 + 1: conv_chunk_mma<WM, WN, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                case 8 * 8 + 1: conv_chunk_mma<WM, WN, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
+                default: conv_chunk_mma<WM, WN, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            }
+        } else
             conv_chunk_mma<WM, WN, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         if (!(a.dbg & 4)) __syncthreads();
     }
@@ -547,8 +561,13 @@ static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid
     else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
     else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
     else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == -1 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, -1, 0, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 1, 4, KG, BF>), grid, block, lds, stream, a);   // 1x1, 32-channel chunks
     else hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
 }
+
+static int g_bank_switch = 1;   // avc_set_tuning("bank_switch", 0): the grouped bank launch on the generic (run-time taps) chunk loop
+void avc_set_bank_switch(int on) { g_bank_switch = on ? 1 : 0; }
 
 // ablation bits of scripts/conv_ablate.py (timing experiments; results are wrong by construction when set)
 static int g_conv_ablation = 0;
@@ -593,7 +612,9 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     const bool mir = a.mode == 1 && a.mirror;
     // the model's kernel_size (5) with the chunk depths the plan uses gets straight-line chunks
-    const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0))) : 0;
+    const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0)))
+                     : ((a.ngroups > 1 && a.mode == 0 && g_bank_switch) ? -1
+                        : ((a.ngroups == 1 && a.g[0].KS == 1 && a.g[0].CK == 32 && g_bank_switch) ? 14 : 0));
     const bool bf = a.bf16 == AVC_COMPUTE_BF16;
 #define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                             \
     do {                                                                                                           \

@@ -121,6 +121,7 @@ struct avc_plan {
     int flags = 0;            // AVC_PLAN_*
     int wgrad_batch = 12;      // weight gradients per batched launch (captured at plan creation: the dry run sizes slabs and events with it)
     int wgrad_target = 256;   // workgroups a batched weight-gradient launch aims for
+    long wgrad_units = 1L << 40;  // pending (tile x K-chunk) units that trigger a launch before wgrad_batch layers are pending
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
 
@@ -223,7 +224,9 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
     }
 }
 
-static int g_wgrad_batch = 12, g_wgrad_batch_target = 256;  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
+static int g_wgrad_batch = 12, g_wgrad_batch_target = 256;
+static long g_wgrad_units = 1L << 40;
+void avc_set_wgrad_units(long u) { g_wgrad_units = u > 0 ? u : (1L << 40); }  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
 void avc_set_wgrad_batch(int layers, int target_wgs) {
     if (layers >= 1) g_wgrad_batch = layers;
     if (target_wgs >= 1) g_wgrad_batch_target = target_wgs;
@@ -254,6 +257,7 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
     p->flags = flags;
     p->wgrad_batch = g_wgrad_batch;
     p->wgrad_target = g_wgrad_batch_target;
+    p->wgrad_units = g_wgrad_units;
     p->B = B;
     p->T = T;
     p->Tc = T_cond;
@@ -723,6 +727,7 @@ struct BwdCtx {
         const LayerP* L;
     };
     std::vector<PendW> pend;
+    long pend_units = 0;   // (co, ci) tiles x K-chunks of the pending layers
     // every gradient tensor a (possibly still running) wgrad kernel reads gets its own buffer
     float* fresh(long n) {
         long off = dy_used;
@@ -785,6 +790,7 @@ static int flush_wgrads(BwdCtx& c) {
         }
     }
     c.pend.clear();
+    c.pend_units = 0;
     if (c.dry) return 0;
     int rc = avc_launch_wgrad_batch(L.data(), n, ls);
     if (rc) return rc;
@@ -802,8 +808,11 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.B = Bn; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride; a.bf16 = L.bf16;
     pw.L = &L;
+    avc_wgrad_geometry(a);
+    c.pend_units += (long)a.tiles * a.total_chunks;
     c.pend.push_back(pw);
-    if ((int)c.pend.size() >= c.p->wgrad_batch) return flush_wgrads(c);
+    // flush when the batch is worth a launch: enough work to give every CU a long K run, or enough layers
+    if ((int)c.pend.size() >= c.p->wgrad_batch || c.pend_units >= c.p->wgrad_units) return flush_wgrads(c);
     return 0;
 }
 
@@ -1130,7 +1139,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                       long* slab_need) {
     BwdCtx c;
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
-    c.nev = 0; c.dy_used = 0;
+    c.nev = 0; c.dy_used = 0; c.pend_units = 0;
     const bool overlap = !dry && side_ready(p);
     c.wstream = overlap ? p->wstream[0] : s;
     c.red.s = s; c.red.dry = dry;

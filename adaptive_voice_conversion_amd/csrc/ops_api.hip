@@ -39,9 +39,11 @@ int avc_set_tuning(const char* name, int value) {
     else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
     else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
     else if (!strcmp(name, "in_fusion")) avc_set_in_fusion(value);
+    else if (!strcmp(name, "bank_switch")) avc_set_bank_switch(value);             // 0: generic chunk loop for the grouped bank launch
     else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
     else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
-    else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);      // workgroups such a launch aims for
+    else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);
+    else if (!strcmp(name, "wgrad_batch_units")) avc_set_wgrad_units(value);       // pending tile x chunk units that trigger a launch early      // workgroups such a launch aims for
     else return -1;
     return 0;
 }
