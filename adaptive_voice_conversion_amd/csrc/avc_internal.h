@@ -16,7 +16,7 @@ struct PackArgs {
 long avc_pack_total(const PackArgs& p);
 
 extern "C" int avc_conv_ck(int KS);
-int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups);
+int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups, int Kred);   // Kred = reduction channels x taps
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups);
 int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
@@ -81,6 +81,7 @@ void avc_set_wgrad_batch(int layers, int target_wgs);
 void avc_set_wgrad_units(long units);
 void avc_set_conv_ck5(int ck);
 void avc_set_bank_switch(int on);
+void avc_set_conv_heuristic(int which, long v);
 void avc_set_wgrad_target_wgs(int n);
 void avc_set_in_variant(int v);
 void avc_set_conv_ablation(int bits);

@@ -496,16 +496,30 @@ static int g_conv_ck5 = 8;  // chunk depth of the k >= 4 layers at the op level 
 void avc_set_conv_ck5(int ck) { g_conv_ck5 = (ck == 8 || ck == 16 || ck == 32) ? ck : 8; }
 extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? g_conv_ck5 : (KS >= 2 ? 16 : 32); }
 
+// launch-heuristic thresholds (avc_set_tuning "tile_thr11" / "tile_thr21" / "ck16_wgs" / "ck32_wgs" / "kg_wgs"; measured defaults)
+static long g_tile_thr11 = 8192, g_tile_thr21 = 4096, g_ck16_wgs = 256, g_ck32_wgs = 256, g_kg_wgs = 256;   // r2 sweep (profiles/r02_tune_sweeps.log)
+void avc_set_conv_heuristic(int which, long v) {
+    if (which == 0) g_tile_thr11 = v;
+    if (which == 1) g_tile_thr21 = v;
+    if (which == 2) g_ck16_wgs = v;
+    if (which == 3) g_ck32_wgs = v;
+    if (which == 4) g_kg_wgs = v;
+}
 // tile choice shared by the launcher and the plan (which sizes CK from it)
-int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups) {
+int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups, int Kred) {
     // measured on MI355X (profiles/r01_conv_micro_*.log): at equal work the 64x64 tile beats 128x64
     // and 128x128 (more resident waves hide the per-chunk LDS/DMA latency; the fp32 MFMA needs no
     // bigger tile for operand reuse), so take the smallest tile unless the grid gets very large
     auto ntn = [&](int BN) { return Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout); };
     long t11 = (long)(Mp / 64) * ntn(64) * ngroups;
     long t21 = (long)(Mp / 128) * ntn(64) * ngroups;
-    if (t11 <= 2048) return 11;
-    if (t21 <= 4096) return 21;
+    // r2 sweeps (profiles/r02_tune_sweeps.log): launches whose workgroups carry little reduction work -- the grouped bank
+    // (k = 1..8 over 80 mel rows) and 1x1 convs over <= 256 channels -- keep gaining from 64x64 tiles up to ~8k
+    // workgroups (their cost is the epilogue: more, smaller workgroups overlap it better); the k = 5, 128-channel convs
+    // switch to 128x64 beyond ~4k (B = 1024 inference: 7.54 vs 7.66 ms)
+    const long thr11 = (ngroups > 1 || (Kred > 0 && Kred <= 256)) ? g_tile_thr11 : (g_tile_thr11 < 4095 ? g_tile_thr11 : 4095);
+    if (t11 <= thr11) return 11;
+    if (t21 <= g_tile_thr21) return 21;
     return 22;
 }
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
@@ -517,14 +531,14 @@ long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
 // (global -> LDS round trip vs. ~1.3k MFMA cycles), so they take twice the channels per chunk
 int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) {
     int ck = avc_conv_ck(KS);
-    if (KS >= 4 && wgs <= 512) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
+    if (KS >= 4 && wgs <= g_ck16_wgs) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
         int BN = (tile % 10 == 1) ? 64 : 128;
         ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
         if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;
         // at most one workgroup per CU: the forward kernel gains another ~6 % from four chunks of 32
         // (r1 sweep: T_l = 16/32 forward 26.0 -> 24.5 us; the dgrad variant does not move)
         int BM = (tile / 10 == 1) ? 64 : 128;
-        if (KS == 5 && mode == 0 && wgs <= 256 && tile != 11 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
+        if (KS == 5 && mode == 0 && wgs <= g_ck32_wgs && tile != 11 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
     }
     return ck;
 }
@@ -583,7 +597,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
     int tile = force_tile == 12 ? 11 : force_tile;  // (the 64x128 tile measured no better than 64x64 and was dropped)
-    if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups);
+    if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
     int BM = (tile / 10 == 1) ? 64 : 128;
     int BN = (tile % 10 == 1) ? 64 : 128;
     for (int gi = 0; gi < a.ngroups; ++gi) {
@@ -598,7 +612,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
     // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
     int kgroups = 1;
-    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= 256 && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
+    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= g_kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
     if (a.in_fuse) {  // row-statistics exchange area behind the split-K exchange area
         size_t need = ((size_t)kgroups * 4096 + 256) * 4;

@@ -169,9 +169,9 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
     L.Mp_d = avc_cdiv(L.dgM, 128) * 128;
-    int tf = avc_conv_pick_tile(L.Mp_f, Bn, Tf, ngroups);
+    int tf = avc_conv_pick_tile(L.Mp_f, Bn, Tf, ngroups, L.Cin * L.KS);
     L.CK = avc_conv_ck_for(L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
-    int td = avc_conv_pick_tile(L.Mp_d, Bn, Td, 1);
+    int td = avc_conv_pick_tile(L.Mp_d, Bn, Td, 1, L.Cout * L.KS);
     L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
     L.nchunk_f = avc_cdiv(L.Cin, L.CK);
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
@@ -882,7 +882,7 @@ static bool fuse_in(ConvArgs& a, const LayerP& L, int Bn, int C, const float* co
     if (g_no_in_fusion || a.rs) return false;
     const int T = a.Tout;
     if (!(T == 16 || T == 32 || T == 64) || T > g_in_fusion_max_t || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
-    if (avc_conv_pick_tile(a.Mp, Bn, T, 1) != 11) return false;
+    if (avc_conv_pick_tile(a.Mp, Bn, T, 1, a.Cred * a.g[0].KS) != 11) return false;
     if (res && !(res_mode == AVC_RES_IDENTITY || res_mode == AVC_RES_AVGPOOL2)) return false;
     a.in_fuse = 1;
     a.in_cond = cond; a.in_cond_sb = cond_sb; a.in_cond_off = cond_off; a.in_C = C;

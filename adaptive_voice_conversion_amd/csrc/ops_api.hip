@@ -10,6 +10,7 @@
 
 extern "C" {
 void avc_set_in_fusion(int on);
+void avc_set_decoder_split_min(int n);
 
 // compute dtype of the op-level conv entry points (the whole-model path takes it from the plan)
 static int g_op_compute = AVC_COMPUTE_F32;
@@ -39,6 +40,12 @@ int avc_set_tuning(const char* name, int value) {
     else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
     else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
     else if (!strcmp(name, "in_fusion")) avc_set_in_fusion(value);
+    else if (!strcmp(name, "tile_thr11")) avc_set_conv_heuristic(0, value);          // launch heuristics of conv_gemm.hip (new plans)
+    else if (!strcmp(name, "tile_thr21")) avc_set_conv_heuristic(1, value);
+    else if (!strcmp(name, "ck16_wgs")) avc_set_conv_heuristic(2, value);
+    else if (!strcmp(name, "ck32_wgs")) avc_set_conv_heuristic(3, value);
+    else if (!strcmp(name, "kg_wgs")) avc_set_conv_heuristic(4, value);
+    else if (!strcmp(name, "dec_split_min")) avc_set_decoder_split_min(value);
     else if (!strcmp(name, "bank_switch")) avc_set_bank_switch(value);             // 0: generic chunk loop for the grouped bank launch
     else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
     else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
