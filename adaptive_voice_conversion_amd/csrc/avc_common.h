@@ -63,6 +63,8 @@ struct ConvArgs {
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16; // AVC_COMPUTE_*
     int rs;   // 1: g[0].wp is a register-stationary weight image -> conv_rs.hip
+    int par;  // stride-2 dgrad: columns of one parity per wave, each wave multiplies only the taps that meet non-zero
+              // positions of the zero-upsampled dy (set by the launcher)
     // fused InstanceNorm epilogue (64x64 tile, Tout in {16, 32, 64}: every (b, m) row is complete inside the
     // tile): g[0].out <- conv + bias (y, kept for the backward), in_out <- relu(IN(y) * gamma + beta) [+ residual],
     // in_mean / in_rstd <- row statistics (index b * in_C + m)

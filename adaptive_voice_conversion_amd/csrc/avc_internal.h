@@ -28,6 +28,11 @@ void avc_pack_rs_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, in
 int avc_launch_pack_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, hipStream_t stream);
 int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream);
 void avc_set_conv_rs(int on);
+// one-shot short-row conv (conv_small.hip): same packed images as conv_gemm.hip
+bool avc_conv_small_eligible(const ConvArgs& a, bool forced);
+int avc_launch_conv_small(const ConvArgs& a, hipStream_t stream);
+void avc_set_conv_small(int on);
+void avc_set_dgrad_par(int on);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 

@@ -79,17 +79,20 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], cons
 // KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
 // block with the fragments of unit u+1 fetched from LDS before the MFMAs of unit u are issued
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
-template <int WM, int WN, int MIR, int KSC, int GRC, bool BF>
+// TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
+// taps of a column meet the zeros of the zero-upsampled dy)
+template <int WM, int WN, int MIR, int KSC, int GRC, bool BF, int TS = 0>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
                                                       int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
                                                       const int (&cbr)[WN]) {
     constexpr int BM = 64 * WM;
     if constexpr (KSC > 0) {
-        constexpr int U = KSC * GRC;
+        constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
+        constexpr int U = NTAP * GRC;
         constexpr int CKC = 8 * GRC;
         float av[2][4][WM], bv[2][4][WN];
         auto unit_ptrs = [&](int u, const float*& Arow, const float*& Xrow) {
-            const int tap = u / GRC, g4 = u % GRC;
+            const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g4 = u % GRC;
             Arow = Ab + (tap * CKC + 8 * g4 + h) * BM + a_lane;
             Xrow = Xb + (8 * g4 + h) * ROW + tap;
         };
@@ -125,7 +128,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
 // runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
 // summed through LDS in a fixed order at the end (deterministic).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool INF = false>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool INF = false, bool PAR = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -190,7 +193,18 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         int n = wave_n * (32 * WN) + wn * 32 + li;
         int bl, t;
         bool v;
-        if (q.SPT == 1 && Tout >= BN) {
+        if (PAR) {   // (WN == 1) wave_n = parity of the wave's columns, li = slot inside the parity class
+            if (Tout >= BN) {
+                bl = 0;
+                t = q.t0 + 2 * li + wave_n;
+                v = (t < Tout) && (q.b0 < a.B);
+            } else {
+                const int halfT = Tout >> 1;
+                bl = li / halfT;
+                t = 2 * (li - bl * halfT) + wave_n;
+                v = (bl < q.SPT) && (q.b0 + bl < a.B);
+            }
+        } else if (q.SPT == 1 && Tout >= BN) {
             bl = 0;
             t = q.t0 + n;
             v = (t < Tout) && (q.b0 < a.B);
@@ -292,6 +306,16 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         const float* Ab = As + (it & 1) * AS;
         const float* Xb = Xs + (it & 1) * XS;
         if ((a.dbg & 2) || chunk >= nchunk) {
+        } else if constexpr (PAR) {   // even columns: taps 0, 2, 4; odd columns: taps 1, 3 (k = 5, padL = 2)
+            if (wave_n == 0) {
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            } else {
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            }
         } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
             conv_chunk_mma<WM, WN, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
         else if (MIRROR && use_mirror)
@@ -580,6 +604,17 @@ static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid
     else hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
 }
 
+// stride-2 dgrad with one column parity per wave (half the MFMAs of the zero-upsampled correlation)
+template <int KG, bool BF>
+static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, false, true>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, false, true>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, false, true>), grid, block, lds, stream, a);
+}
+static int g_dgrad_par = 1;   // avc_set_tuning("dgrad_par", 0): stride-2 dgrad multiplies all five taps of the zero-upsampled dy
+void avc_set_dgrad_par(int on) { g_dgrad_par = on ? 1 : 0; }
+
 static int g_bank_switch = 1;   // avc_set_tuning("bank_switch", 0): the grouped bank launch on the generic (run-time taps) chunk loop
 void avc_set_bank_switch(int on) { g_bank_switch = on ? 1 : 0; }
 
@@ -590,6 +625,8 @@ void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     if (a_in.rs || force_tile == 99) return avc_launch_conv_rs(a_in, stream);
+    if ((force_tile == 0 || force_tile == 98) && !g_conv_ablation && avc_conv_small_eligible(a_in, force_tile == 98)) return avc_launch_conv_small(a_in, stream);
+    if (force_tile == 98) return -8;
     ConvArgs a = a_in;
     a.dbg = g_conv_ablation;
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
@@ -630,12 +667,17 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
                      : ((a.ngroups > 1 && a.mode == 0 && g_bank_switch) ? -1
                         : ((a.ngroups == 1 && a.g[0].KS == 1 && a.g[0].CK == 32 && g_bank_switch) ? 14 : 0));
     const bool bf = a.bf16 == AVC_COMPUTE_BF16;
+    a.par = g_dgrad_par && a.mode == 1 && a.stride == 2 && tile == 11 && a.ngroups == 1 && (fast == 1 || fast == 2) && !a.in_fuse && !a.dbg &&
+            a.g[0].padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
 #define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                             \
     do {                                                                                                           \
         if (bf) conv_launch_variant<WM_, WN_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
         else conv_launch_variant<WM_, WN_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
     } while (0)
-    if (a.in_fuse) {  // (validated above: 64x64 tile, forward)
+    if (a.par) {
+        if (kgroups == 2) { if (bf) conv_launch_par<2, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<2, false>(a, mir, fast, grid, block, lds, stream); }
+        else { if (bf) conv_launch_par<1, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<1, false>(a, mir, fast, grid, block, lds, stream); }
+    } else if (a.in_fuse) {  // (validated above: 64x64 tile, forward)
         const int f = fast == 4 ? 0 : fast;
         if (kgroups == 2) { if (bf) conv_launch_infuse<2, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<2, false>(a, f, grid, block, lds, stream); }
         else { if (bf) conv_launch_infuse<1, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<1, false>(a, f, grid, block, lds, stream); }

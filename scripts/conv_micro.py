@@ -68,6 +68,24 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
         us = timeit(f); res.append(f"wgrad(+reduce): {us:7.1f}us {flops/us/1e6:6.1f}TF")
     print(f"B={B} {Cin}->{Cout} T={T} k={KS} s={stride}: " + " | ".join(res), flush=True)
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s2":
+    for par in (0, 1):
+        lib.avc_set_tuning(b"dgrad_par", par)
+        print("dgrad_par", par)
+        for T in (128, 64, 32):
+            run(256, 128, 128, T, 5, 2, tiles=(0,), which="d")
+    sys.exit(0)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
+    for ck in (8, 16):
+        lib.avc_set_tuning(b"conv_ck5", ck)
+        print("chunk depth", ck)
+        for B in (256, 128):
+            for T in (32, 16):
+                run(B, 128, 128, T, 5, 1, tiles=(11, 98), which="fd")
+        run(128, 128, 256, 32, 5, 1, tiles=(11, 98), which="f")
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rs":
     B = 256
     for T in (128, 64, 32, 16):

@@ -58,6 +58,8 @@ FWD = [
     (2, 16, 32, 21, 5, 2, 11),    # stride 2, odd T
     (2, 40, 32, 32, 5, 1, 11),    # 5 K-chunks: two split-K wave groups with unequal chunk counts
     (3, 64, 64, 16, 5, 1, 11),    # 8 K-chunks, several short samples per tile, split-K
+    (5, 128, 40, 16, 5, 1, 98),   # tile code 98 = the one-shot short-row kernel (conv_small.hip) or an error: ragged last tile, partial M slab
+    (9, 128, 128, 32, 5, 1, 98),  # 128-column tiles, B not a multiple of the 4 samples per tile
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(8, 128, 256, 64, 5, 1, 0, marks=GPU),
@@ -122,6 +124,13 @@ DG = [
     (5, 16, 32, 3, 5, 1, 11),
     (1, 16, 128, 130, 5, 1, 22),
     (2, 16, 32, 66, 5, 1, 21),
+    (5, 40, 128, 16, 5, 1, 98),   # conv_small.hip, mirror windows of 4 samples per tile
+    (3, 16, 32, 32, 5, 2, 11),    # stride 2 with one column parity per wave (even taps / odd taps): two samples per tile
+    (5, 16, 32, 16, 5, 2, 11),    # ... four samples per tile, ragged last tile
+    (1, 16, 32, 128, 5, 2, 11),   # ... two tiles per sample
+    (1, 16, 32, 101, 5, 2, 11),   # ... odd length, partial last tile
+    (2, 64, 32, 32, 5, 2, 11),    # ... with the two split-K wave groups
+    (3, 128, 128, 32, 5, 1, 98),
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
@@ -150,6 +159,34 @@ def test_conv_dgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride, tile):
                               None, tile, None)
     assert rc == 0
     torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("T", [16, 32])
+def test_conv_small_with_16_channel_chunks(kind, T):
+    """conv_small.hip reads the packed images of conv_gemm.hip at either chunk depth the plan uses for k = 5."""
+    lib, dev = backend(kind)
+    assert lib.avc_set_tuning(b"conv_ck5", 16) == 0
+    try:
+        g = torch.Generator().manual_seed(T)
+        B, C = 5, 128
+        x = torch.randn(B, C, T, generator=g, requires_grad=True)
+        w = torch.randn(C, C, 5, generator=g) / (C * 5) ** 0.5
+        b = torch.randn(C, generator=g)
+        y = O.pad_conv(x, w, b, 1)
+        dy = torch.randn(y.shape, generator=g)
+        (dx_ref,) = torch.autograd.grad(y, x, dy)
+        out, _ = conv_fwd(lib, dev, x.detach().to(dev), w.to(dev), b.to(dev), 1, act=0, tile=98)
+        torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-5, atol=2e-5)
+        wpd = pack(lib, dev, [w.to(dev)], 1)
+        dx = torch.full((B, C, T), float("nan"), device=dev)
+        dyd = dy.to(dev)
+        rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), dyd.stride(2), 1, B, C, T, P(wpd), C, 5, 1, T, P(dx),
+                                  dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None, None, 98, None)
+        assert rc == 0
+        torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
+    finally:
+        lib.avc_set_tuning(b"conv_ck5", 8)
 
 
 @pytest.mark.parametrize("kind", KINDS)
