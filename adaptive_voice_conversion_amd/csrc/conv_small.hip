@@ -143,7 +143,11 @@ __global__ void __launch_bounds__(NT * 256) conv_small_kernel(const ConvArgs a) 
 }
 
 // --------------------------------------------------------------------------
-static int g_conv_small = 0;   // avc_set_tuning("conv_small", 0): short rows on the chunk-pipelined kernel (A/B measurements)
+// avc_set_tuning("conv_small", v): -1 (default) = launches of <= 64 samples (a step of such a batch is bound by the
+// latency of its ~250 dependent launches: 2.31 -> 2.24 ms at B = 4, 3.29 -> 3.24 at B = 64; at B = 256 the kernel is
+// faster alone but its 158 KB of LDS keep the concurrent weight-gradient workgroups off the CU: 6.76 vs 6.74 ms);
+// 0 = never; bit 0 = forward, bit 1 = dgrad launches
+static int g_conv_small = -1;
 void avc_set_conv_small(int on) { g_conv_small = on; }   // bit 0: forward launches, bit 1: dgrad launches
 
 static int small_nt(const ConvArgs& a) { return a.Tout == 32 ? 4 : 2; }   // 4 samples of 32 / 16 frames per workgroup
@@ -155,7 +159,8 @@ static size_t small_lds(const ConvArgs& a) {
 // One workgroup per CU (80 KiB weight slab + the source tile), so only launches that fit the chip in one round:
 // measured (profiles/r02_conv_small.log) two rounds lose to the chunk-pipelined kernel, one round wins by 15-40 %.
 bool avc_conv_small_eligible(const ConvArgs& a, bool forced) {
-    if (!forced && !(g_conv_small & (a.mode == 0 ? 1 : 2))) return false;
+    const int bits = g_conv_small < 0 ? (a.B <= 64 ? 3 : 0) : g_conv_small;
+    if (!forced && !(bits & (a.mode == 0 ? 1 : 2))) return false;
     if (a.ngroups != 1 || a.in_fuse || a.rs || a.dbg) return false;
     const ConvGroup& g = a.g[0];
     if (g.KS != 5 || a.Cred != 128 || a.stride != 1 || g.padL != 2 || g.padR != 2) return false;
