@@ -8,7 +8,7 @@ for what in "$@"; do
   case $what in
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -s -x > $OUT/tests.log 2>&1; tail -4 $OUT/tests.log
-      grep -E "^\[(gpu|emu)" $OUT/tests.log | cut -c1-260 > $OUT/tests_lines.log ;;
+      grep -E "^[.s]*\[(gpu|emu)" $OUT/tests.log | sed -E "s/^[.s]*//" | cut -c1-400 > $OUT/tests_lines.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log ;;
     bench)
