@@ -18,7 +18,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    srcs = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
+    srcs = [f for f in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(f)] + glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
         glob.glob(os.path.join(ROOT, "tests", "emu", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     return any(os.path.getmtime(s) > t for s in srcs if not s.endswith(".so"))
 
@@ -27,7 +27,11 @@ def emu_lib():
     global _lib
     if _lib is None:
         if _stale():
-            subprocess.check_call([os.path.join(CSRC, "build_emu.sh")])
+            import fcntl
+            with open(os.path.join(ROOT, "tests", "emu", ".build.lock"), "w") as lock:   # one builder among concurrent test processes
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _stale():
+                    subprocess.check_call([os.path.join(CSRC, "build_emu.sh")])
         _lib = ctypes.CDLL(SO)
     return _lib
 

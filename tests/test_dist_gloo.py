@@ -50,6 +50,8 @@ def _worker(rank, world, port, out_dir):
 
 def test_two_rank_step_equals_global_batch_step(tmp_path):
     world = 2
+    from tests.emu_util import emu_lib
+    emu_lib()   # (built here once if stale, not by both ranks)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
