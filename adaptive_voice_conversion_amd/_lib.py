@@ -104,6 +104,24 @@ def declare(lib):
                                      c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_instnorm_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int,
                                      c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]
+    # mel <-> waveform DSP
+    lib.avc_dsp_num_frames.argtypes = [c_long, c_int]
+    lib.avc_dsp_basis_floats.argtypes = [c_int, c_int, c_int]
+    lib.avc_dsp_basis_floats.restype = c_long
+    lib.avc_dsp_basis_scratch_floats.argtypes = [c_int, c_int]
+    lib.avc_dsp_basis_scratch_floats.restype = c_long
+    lib.avc_dsp_make_basis.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_stft.argtypes = [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_istft.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_griffin_lim_ws_floats.argtypes = [c_int, c_int, c_int, c_int]
+    lib.avc_dsp_griffin_lim_ws_floats.restype = c_long
+    lib.avc_dsp_griffin_lim.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_magnitude.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.avc_dsp_db_normalize.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
+    lib.avc_dsp_denormalize_amp.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
+    lib.avc_dsp_preemphasis.argtypes = [c_void_p, c_long, c_float, c_void_p, c_void_p]
+    lib.avc_dsp_deemphasis.argtypes = [c_void_p, c_long, c_float, c_void_p, c_void_p]
+    lib.avc_dsp_frame_power.argtypes = [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]
     lib.avc_prof_end.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_prof_class_name.argtypes = [c_int]
     lib.avc_prof_class_name.restype = ctypes.c_char_p

@@ -33,6 +33,17 @@ bool avc_conv_small_eligible(const ConvArgs& a, bool forced);
 int avc_launch_conv_small(const ConvArgs& a, hipStream_t stream);
 void avc_set_conv_small(int on);
 void avc_set_dgrad_par(int on);
+// mel <-> waveform DSP (dsp.hip)
+int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s);
+int avc_launch_dsp_frames(const float* y, long L, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);
+int avc_launch_dsp_ola(const float* tf, int T, int hop, int n_fft, int win, float* y, hipStream_t s);
+int avc_launch_dsp_phase(const float* est, const float* S, int F, int T, float* out, hipStream_t s);
+int avc_launch_dsp_mag(const float* spec, int F, int T, float* mag, hipStream_t s);
+int avc_launch_dsp_db_norm(const float* in, int C, int T, float ref_db, float max_db, float* out, hipStream_t s);
+int avc_launch_dsp_denorm_amp(const float* in, int C, int T, float ref_db, float max_db, float* out, hipStream_t s);
+int avc_launch_dsp_preemph(const float* y, long L, float a, float* out, hipStream_t s);
+int avc_launch_dsp_deemph(const float* x, long L, float a, float* out, hipStream_t s);
+int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop, int n_frames, float* out, hipStream_t s);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 

@@ -1,0 +1,109 @@
+// C-ABI entry points of the mel <-> waveform DSP (declared in include/avc_hip.h; kernels in dsp.hip, the two transforms
+// run as 1x1 "convolutions" on conv_gemm.hip's fp32-MFMA kernel).  Reference: preprocess/tacotron/utils.py:27-155.
+#include <hip/hip_runtime.h>
+
+#include "avc_common.h"
+#include "avc_hip.h"
+#include "avc_internal.h"
+
+extern "C" {
+
+int avc_dsp_num_frames(long L, int hop_length) { return (int)(1 + L / hop_length); }   // librosa.stft, center=True
+
+static bool dsp_geom_ok(int n_fft, int hop, int win) { return n_fft >= 4 && (n_fft & 1) == 0 && win >= 2 && win <= n_fft && hop >= 1 && hop <= win; }
+
+long avc_dsp_basis_floats(int n_fft, int win_length, int inverse) {
+    const int F2 = n_fft + 2;
+    return inverse ? avc_packed_weight_floats(win_length, F2, 1, 0) : avc_packed_weight_floats(F2, win_length, 1, 0);
+}
+long avc_dsp_basis_scratch_floats(int n_fft, int win_length) { return (long)(n_fft + 2) * win_length; }
+
+int avc_dsp_make_basis(int n_fft, int hop_length, int win_length, int inverse, float* dense_scratch, float* packed, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !dense_scratch || !packed) return -1;
+    int rc = avc_launch_dsp_basis(inverse ? 1 : 0, n_fft, win_length, dense_scratch, (hipStream_t)stream);
+    if (rc) return rc;
+    const float* src = dense_scratch;
+    const int F2 = n_fft + 2;
+    return inverse ? avc_pack_weight(&src, 1, win_length, win_length, F2, 1, 0, packed, stream)
+                   : avc_pack_weight(&src, 1, F2, F2, win_length, 1, 0, packed, stream);
+}
+
+// spec[2F][T] = Wf[2F][win] x frames[win][T]
+int avc_dsp_stft(const float* y, long L, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
+                 float* spec, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !y || !basis_fwd || !frames_ws || !spec) return -1;
+    if (L <= n_fft / 2) return -6;   // numpy reflect padding needs pad < len (the reference's librosa call raises there)
+    const int T = avc_dsp_num_frames(L, hop_length), F2 = n_fft + 2;
+    int rc = avc_launch_dsp_frames(y, L, T, hop_length, n_fft, win_length, frames_ws, (hipStream_t)stream);
+    if (rc) return rc;
+    return avc_conv1d_fwd(frames_ws, 0, T, 1, 1, win_length, T, basis_fwd, nullptr, F2, 1, 1, 0, spec, 0, T, 1, 1, nullptr, 0, 0, 0, 0,
+                          0, nullptr, 0, stream);
+}
+
+// y[hop (T-1)] = overlap-add of tf[win][T] = Wi[win][2F] x spec[2F][T], over the window's sum of squares
+int avc_dsp_istft(const float* spec, int T, int n_fft, int hop_length, int win_length, const float* basis_inv, float* tf_ws, float* y,
+                  void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !spec || !basis_inv || !tf_ws || !y || T < 2) return -1;
+    const int F2 = n_fft + 2;
+    int rc = avc_conv1d_fwd(spec, 0, T, 1, 1, F2, T, basis_inv, nullptr, win_length, 1, 1, 0, tf_ws, 0, T, 1, 1, nullptr, 0, 0, 0, 0, 0,
+                            nullptr, 0, stream);
+    if (rc) return rc;
+    return avc_launch_dsp_ola(tf_ws, T, hop_length, n_fft, win_length, y, (hipStream_t)stream);
+}
+
+long avc_dsp_griffin_lim_ws_floats(int T, int n_fft, int hop_length, int win_length) {
+    const long F2 = n_fft + 2;
+    auto up = [](long n) { return (n + 63) / 64 * 64; };
+    return 2 * up(F2 * T) + up((long)win_length * T) + up((long)hop_length * T);
+}
+
+// utils.py:136-147: X = S; repeat n_iter: x = istft(X); est = stft(x); X = S * est / max(1e-8, |est|); return istft(X)
+int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
+                        const float* basis_inv, float* ws, float* y, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !basis_fwd || !basis_inv || !ws || !y || T < 2 || n_iter < 0) return -1;
+    const long Ly = (long)hop_length * (T - 1);
+    if (Ly <= n_fft / 2) return -6;
+    const int F = n_fft / 2 + 1;
+    const long F2 = n_fft + 2;
+    auto up = [](long n) { return (n + 63) / 64 * 64; };
+    float* xbest = ws;
+    float* est = xbest + up(F2 * T);
+    float* fr = est + up(F2 * T);                  // frames of the STFT / time frames of the iSTFT (never live together)
+    float* xt = fr + up((long)win_length * T);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = avc_launch_dsp_phase(nullptr, S, F, T, xbest, s);
+    for (int i = 0; i < n_iter && !rc; ++i) {
+        rc = avc_dsp_istft(xbest, T, n_fft, hop_length, win_length, basis_inv, fr, xt, stream);
+        if (!rc) rc = avc_dsp_stft(xt, Ly, n_fft, hop_length, win_length, basis_fwd, fr, est, stream);   // 1 + Ly / hop == T frames
+        if (!rc) rc = avc_launch_dsp_phase(est, S, F, T, xbest, s);
+    }
+    if (!rc) rc = avc_dsp_istft(xbest, T, n_fft, hop_length, win_length, basis_inv, fr, y, stream);
+    return rc;
+}
+
+int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream) {
+    if (!spec || !mag || T < 1) return -1;
+    return avc_launch_dsp_mag(spec, n_fft / 2 + 1, T, mag, (hipStream_t)stream);
+}
+int avc_dsp_db_normalize(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream) {
+    if (!in || !out || C < 1 || T < 1) return -1;
+    return avc_launch_dsp_db_norm(in, C, T, ref_db, max_db, out, (hipStream_t)stream);
+}
+int avc_dsp_denormalize_amp(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream) {
+    if (!in || !out || C < 1 || T < 1) return -1;
+    return avc_launch_dsp_denorm_amp(in, C, T, ref_db, max_db, out, (hipStream_t)stream);
+}
+int avc_dsp_preemphasis(const float* y, long L, float a, float* out, void* stream) {
+    if (!y || !out || L < 1 || y == out) return -1;
+    return avc_launch_dsp_preemph(y, L, a, out, (hipStream_t)stream);
+}
+int avc_dsp_deemphasis(const float* x, long L, float a, float* out, void* stream) {
+    if (!x || !out || L < 1) return -1;
+    return avc_launch_dsp_deemph(x, L, a, out, (hipStream_t)stream);
+}
+int avc_dsp_frame_power(const float* y, long L, int frame_length, int hop_length, float* out, void* stream) {
+    if (!y || !out || frame_length < 2 || hop_length < 1) return -1;
+    if (L <= frame_length / 2) return -6;
+    return avc_launch_dsp_frame_power(y, L, frame_length, hop_length, avc_dsp_num_frames(L, hop_length), out, (hipStream_t)stream);
+}
+}

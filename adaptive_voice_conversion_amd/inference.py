@@ -7,9 +7,12 @@ Kept from the reference: ``Inferencer(config, args)``, ``load_model`` (``args.mo
 Added: ``convert_batch`` — many (source, target) pairs of arbitrary, unequal lengths in few engine
 calls (pairs are bucketed by shape; the reference only ever runs batch 1).
 
-Out of scope: wav <-> mel DSP (librosa STFT, Griffin-Lim).  If the caller
-supplies ``mel2wav`` it is applied to the denormalised mel exactly where the reference calls
-``melspectrogram2wav``; otherwise the waveform slot of the result is ``None``.
+The audio front and back end (reference: ``get_spectrograms`` / ``melspectrogram2wav`` of
+``preprocess/tacotron/utils.py``, librosa on the CPU there) run on the GPU through ``dsp.MelDSP``:
+``inference_from_path`` (inference.py:86-93) reads two wav files and writes the converted one, ``mel2wav`` defaults to the
+device-side ``melspectrogram2wav`` when the model has as many mel bins as the DSP hyper-parameters produce (the stock
+``config.yaml`` trains on 512-mel features, hyperparams.py:29); a caller-supplied ``mel2wav`` takes precedence, and with
+neither the waveform slot of the result is ``None``.
 """
 import pickle
 from collections import defaultdict
@@ -21,11 +24,12 @@ from .utils import cc, local_device
 
 
 class Inferencer(object):
-    def __init__(self, config, args, mel2wav=None, lib=None):
+    def __init__(self, config, args, mel2wav=None, lib=None, dsp_hp=None):
         self.config = config
         self.args = args
         self.mel2wav = mel2wav
         self._lib = lib
+        self._dsp_hp = dsp_hp   # None: preprocess/tacotron/hyperparams.py's values
         self.build_model()
         if getattr(args, "model", None):
             self.load_model()
@@ -33,6 +37,14 @@ class Inferencer(object):
         if getattr(args, "attr", None):
             with open(args.attr, "rb") as f:
                 self.attr = pickle.load(f)
+        self._dsp = None
+
+    def dsp(self):
+        """The device-side mel <-> waveform DSP (built on first use: its DFT bases take ~30 MB of HBM)."""
+        if self._dsp is None:
+            from .dsp import Hyperparams, MelDSP
+            self._dsp = MelDSP(self._dsp_hp or Hyperparams, device=self.model.flat_parameters().device, lib=self._lib)
+        return self._dsp
 
     def load_model(self):
         dev = self.model.flat_parameters().device
@@ -70,8 +82,31 @@ class Inferencer(object):
             dec = self.model.inference(x, x_cond)
         dec = dec.transpose(1, 2).squeeze(0).detach().cpu().numpy()
         dec = self.denormalize(dec)
-        wav = self.mel2wav(dec) if self.mel2wav is not None else None
+        if self.mel2wav is not None:
+            wav = self.mel2wav(dec)
+        elif getattr(self.args, "source", None) is not None and dec.shape[1] == self.dsp().hp.n_mels:
+            wav = self.dsp().melspectrogram2wav(dec)            # inference.py:69
+        else:
+            wav = None
         return wav, dec
+
+    # ---- inference.py:82-93
+    def write_wav_to_file(self, wav_data, output_path):
+        from scipy.io.wavfile import write
+        write(output_path, rate=int(getattr(self.args, "sample_rate", 24000)), data=wav_data)
+
+    def inference_from_path(self):
+        dsp = self.dsp()
+        if self.model._n_mels != dsp.hp.n_mels:
+            raise ValueError(f"the model works on {self.model._n_mels}-mel features, get_spectrograms produces {dsp.hp.n_mels} "
+                             "(preprocess/tacotron/hyperparams.py:29)")
+        src_mel, _ = dsp.get_spectrograms(self.args.source)
+        tar_mel, _ = dsp.get_spectrograms(self.args.target)
+        src_mel = torch.from_numpy(self.normalize(src_mel)).float()
+        tar_mel = torch.from_numpy(self.normalize(tar_mel)).float()
+        conv_wav, conv_mel = self.inference_one_utterance(src_mel, tar_mel)
+        self.write_wav_to_file(conv_wav, self.args.output)
+        return conv_wav, conv_mel
 
     def convert_batch(self, pairs, max_streams=4):
         """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T') share one engine
@@ -109,3 +144,24 @@ class Inferencer(object):
                 for k, i in enumerate(idx):
                     out[i] = dec[k]
         return out
+
+
+def main(argv=None):
+    """The reference's command line (inference.py:95-109)."""
+    from argparse import ArgumentParser
+    from .config import load_config
+    parser = ArgumentParser()
+    parser.add_argument('-attr', '-a', help='attr file path')
+    parser.add_argument('-config', '-c', help='config file path')
+    parser.add_argument('-model', '-m', help='model path')
+    parser.add_argument('-source', '-s', help='source wav path')
+    parser.add_argument('-target', '-t', help='target wav path')
+    parser.add_argument('-output', '-o', help='output wav path')
+    parser.add_argument('-sample_rate', '-sr', help='sample rate', default=24000, type=int)
+    args = parser.parse_args(argv)
+    inferencer = Inferencer(config=load_config(args.config), args=args)
+    inferencer.inference_from_path()
+
+
+if __name__ == '__main__':
+    main()

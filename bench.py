@@ -27,6 +27,8 @@ import sys
 import time
 import types
 
+import numpy as np
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -255,6 +257,58 @@ def cpu_baseline(n_mels, T, budget_s=45.0):
                         for d in sorted(pts.values(), key=lambda d: (d["B"], d["threads"]))])
 
 
+def dsp_bench(a, dev):
+    """Mel <-> waveform DSP of one utterance (preprocess/tacotron/utils.py:34-87, :89-109 with the stock hyper-parameters:
+    24 kHz, n_fft 2048, hop 300, window 1200, 512 mels, 100 Griffin-Lim iterations).  A "step" = melspectrogram2wav of one
+    utterance, features resident in HBM, the waveform left in HBM (trim's two indices are the only host read)."""
+    from adaptive_voice_conversion_amd.dsp import Hyperparams, MelDSP
+    hp = Hyperparams
+    n = int(a.seconds * hp.sr)
+    t = np.arange(n) / hp.sr
+    ph = 2 * np.pi * np.cumsum(120 + 30 * np.sin(2 * np.pi * 0.7 * t)) / hp.sr
+    y = (0.3 * np.clip(np.sin(2 * np.pi * 1.3 * t), 0, None) ** 2 * sum(np.sin(k * ph) / k for k in range(1, 12))
+         + 0.002 * np.random.RandomState(0).randn(n)).astype(np.float32)
+    dsp = MelDSP(hp, device=dev)
+    yd = torch.from_numpy(y).to(dev)
+    mel, _ = dsp.get_spectrograms_device(yd, do_trim=False)
+    T = mel.shape[0]
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    t_front = timed(lambda: dsp.get_spectrograms_device(yd, do_trim=False), a.steps, a.warmup)
+    t_back = timed(lambda: dsp.melspectrogram2wav(mel, do_trim=False), a.steps, a.warmup)
+    F2, K = hp.n_fft + 2, hp.win_length
+    flops = (2 * hp.n_iter + 1) * 2.0 * F2 * K * T + 2.0 * (hp.n_fft // 2 + 1) * hp.n_mels * T
+    out = {"metric": f"utterances/sec mel -> waveform (melspectrogram2wav, {hp.n_iter} Griffin-Lim iterations, {a.seconds:g} s of {hp.sr} Hz audio = {T} frames)",
+           "value": 1.0 / t_back, "unit": "utterances/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * t_back,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SURVEY §8f row 4 (not a BASELINE.json config): mel <-> waveform DSP of one utterance, stock hyper-parameters",
+                      "frames": T, "front_end_ms (get_spectrograms, no trim)": 1e3 * t_front},
+           "roofline": {"kernel": "conv_gemm 1x1 (the STFT / iSTFT GEMMs against the windowed DFT bases)", "bound": "mfma",
+                        "achieved": flops / t_back / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t_back / 1e12 / 157.3,
+                        "traffic": None,
+                        "note": "algorithmic GEMM flops of the whole call over its wall time (row kernels and launch gaps included)"}}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from oracle import dsp_oracle as D   # the CPU restatement (numpy float64, pocketfft), timed on this host
+        melh = mel.cpu().numpy()
+        t0 = time.perf_counter()
+        ref = D.melspectrogram2wav(melh, D.Hyperparams, do_trim=False)
+        tc = time.perf_counter() - t0
+        wav = dsp.melspectrogram2wav(melh, do_trim=False)
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "utterances/sec", "cores": 1, "kind": "port",
+                               "sample": f"oracle/dsp_oracle.py melspectrogram2wav (numpy rfft / irfft per iteration), the same {T}-frame utterance, one run"}
+        out["config"]["waveform rel-L2 vs the float64 oracle after 100 iterations"] = float(np.linalg.norm(wav - ref) / np.linalg.norm(ref))
+    print(json.dumps(out), flush=True)
+
+
 def workload_label(a, world):
     """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
     prec = "fp32" if a.dtype == "f32" else "bf16 matrix products (fp32 accumulate, fp32 master weights and optimizer state)"
@@ -301,8 +355,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=("train", "infer"), default="train",
-                    help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion")
+    ap.add_argument("--mode", choices=("train", "infer", "dsp"), default="train",
+                    help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion; "
+                         "dsp = the mel <-> waveform back end of a conversion (SURVEY §8f row 4; not a BASELINE.json config)")
+    ap.add_argument("--seconds", type=float, default=5.0, help="--mode dsp: length of the synthetic utterance")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the headline (BASELINE configs[1]); bf16 = configs[2]'s compute mode (bf16 matrix products, "
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
@@ -339,6 +395,9 @@ def main():
         world = dist.get_world_size()   # what the RCCL process group actually has
     if a.gpus != world and rank == 0:
         print(f"warning: --gpus {a.gpus} but the process group has {world} rank(s)", file=sys.stderr)
+
+    if a.mode == "dsp":
+        return dsp_bench(a, dev)
 
     from adaptive_voice_conversion_amd import _lib
     from adaptive_voice_conversion_amd.solver import Solver

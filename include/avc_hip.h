@@ -183,6 +183,37 @@ int avc_set_tuning(const char* name, int value);
 int avc_gather_segments(const float* corpus, long n_rows, int M, const long* starts, int B, int T, float* out,
                         void* stream);
 
+/* ---- mel <-> waveform DSP (replaces preprocess/tacotron/utils.py:27-155, there librosa on the CPU)
+ * A complex spectrogram is [2F][T] fp32 (row 2f = Re, 2f+1 = Im of bin f, F = n_fft/2 + 1, T contiguous); magnitudes /
+ * mels are [C][T]; the normalised features the pickles and the model use are [T][C] (utils.py:84-85).
+ * The transforms are GEMMs against DFT bases that carry the centre-padded periodic Hann window (built once per
+ * (n_fft, win_length) by avc_dsp_make_basis into caller memory of avc_dsp_basis_floats floats; dense_scratch:
+ * avc_dsp_basis_scratch_floats floats, free afterwards).  Nothing here allocates or synchronises. */
+int avc_dsp_num_frames(long L, int hop_length);                      /* librosa.stft(center=True): 1 + L / hop */
+long avc_dsp_basis_floats(int n_fft, int win_length, int inverse);
+long avc_dsp_basis_scratch_floats(int n_fft, int win_length);
+int avc_dsp_make_basis(int n_fft, int hop_length, int win_length, int inverse, float* dense_scratch, float* packed, void* stream);
+/* librosa.stft(y, n_fft, hop_length, win_length) (utils.py:63-66,141): reflect padding of n_fft/2, T = 1 + L/hop frames.
+ * frames_ws: win_length * T floats.  -6 when L <= n_fft/2 (the reference's call raises there). */
+int avc_dsp_stft(const float* y, long L, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
+                 float* spec, void* stream);
+/* librosa.istft(spec, hop_length, win_length, window="hann") (utils.py:150-154): y has hop * (T - 1) samples. */
+int avc_dsp_istft(const float* spec, int T, int n_fft, int hop_length, int win_length, const float* basis_inv, float* tf_ws, float* y,
+                  void* stream);
+/* griffin_lim (utils.py:136-147) on magnitudes S [F][T]: n_iter x (istft, stft, phase projection) + the final istft. */
+long avc_dsp_griffin_lim_ws_floats(int T, int n_fft, int hop_length, int win_length);
+int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
+                        const float* basis_inv, float* ws, float* y, void* stream);
+int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream);                                   /* utils.py:69 */
+/* out[t][c] = clip((20 log10(max(1e-5, in[c][t])) - ref_db + max_db) / max_db, 1e-8, 1)   (utils.py:76-85) */
+int avc_dsp_db_normalize(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream);
+/* out[c][t] = 10 ^ (0.05 (clip(in[t][c], 0, 1) max_db - max_db + ref_db))                 (utils.py:92-98) */
+int avc_dsp_denormalize_amp(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream);
+int avc_dsp_preemphasis(const float* y, long L, float a, float* out, void* stream);        /* utils.py:60 (out != y) */
+int avc_dsp_deemphasis(const float* x, long L, float a, float* out, void* stream);         /* utils.py:104 lfilter([1], [1, -a]) */
+/* mean square of the frames of librosa.effects.trim (utils.py:57,107): out[1 + L/hop] */
+int avc_dsp_frame_power(const float* y, long L, int frame_length, int hop_length, float* out, void* stream);
+
 /* ---- op-level entry points (one per kernel family and direction) -------- */
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad);
 /* W[Cout][Cin][KS] (nn.Conv1d / nn.Linear state_dict layout; nsrc tensors stacked on Cout) -> LDS-image order */

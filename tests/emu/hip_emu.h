@@ -143,6 +143,11 @@ static inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
 }
 }  // namespace emu
 
+// device math that libm lacks (dsp.hip)
+static inline double cospi(double x) { return cos(M_PI * x); }
+static inline float cospif(float x) { return (float)cos(M_PI * (double)x); }
+static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
+
 #define __syncthreads() emu::block_barrier()
 #define __builtin_amdgcn_s_barrier() emu::block_barrier()
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
