@@ -132,8 +132,21 @@ class Solver(object):
         (avc_backward walks decoder -> encoders) -- is reduced on a communication stream under the rest of the
         backward pass; the encoders' range follows on the same stream once the whole backward is done."""
         from . import _lib
+        # compute_dtype bf16 (BASELINE configs[2]: "bf16 compute, fp32 master and optimizer state"): the bucket travels as
+        # bf16 too -- 9.8 MB instead of 19.6 MB per step over xGMI (SURVEY §8e); `allreduce_dtype: fp32` in the config keeps
+        # the wire fp32.  The sum of W bf16-rounded gradients carries a relative error of ~2^-9 per element, the same order as
+        # the bf16 matrix products that produced them.
+        wire_bf16 = self.config.get("allreduce_dtype", "bf16" if str(self.config.get("compute_dtype", "fp32")).lower() in ("bf16", "bfloat16") else "fp32") == "bf16"
+
+        def reduce(seg):
+            if not wire_bf16:
+                d.all_reduce(seg)
+                return
+            wire = seg.to(torch.bfloat16)
+            d.all_reduce(wire)
+            seg.copy_(wire)
         if not grads.is_cuda:
-            d.all_reduce(grads)
+            reduce(grads)
             return
         if self._comm_stream is None or self._comm_stream.device != grads.device:
             self._comm_stream = torch.cuda.Stream(device=grads.device)
@@ -141,10 +154,10 @@ class Solver(object):
         (do, dn), (eo, en) = plan.param_range(_lib.GRADS_DECODER), plan.param_range(_lib.GRADS_ENCODERS)
         plan.stream_wait_grads(_lib.GRADS_DECODER, cs)
         with torch.cuda.stream(cs):
-            d.all_reduce(grads[do:do + dn])
+            reduce(grads[do:do + dn])
         cs.wait_stream(main)                       # the whole backward (avc_backward joins its helper streams into main)
         with torch.cuda.stream(cs):
-            d.all_reduce(grads[eo:eo + en])
+            reduce(grads[eo:eo + en])
         main.wait_stream(cs)
 
     def ae_step(self, data, lambda_kl, eps=None, sync=True):
