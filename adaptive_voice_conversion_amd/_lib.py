@@ -89,6 +89,9 @@ def declare(lib):
     lib.avc_packed_weight_floats_rs.argtypes = [c_int] * 4
     lib.avc_packed_weight_floats_rs.restype = c_long
     lib.avc_pack_weight_rs.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.avc_packed_weight_floats_x3.argtypes = [c_int] * 4
+    lib.avc_packed_weight_floats_x3.restype = c_long
+    lib.avc_pack_weight_x3.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.avc_pack_weight.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.avc_conv1d_fwd.argtypes = [c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_int, c_long, c_long,

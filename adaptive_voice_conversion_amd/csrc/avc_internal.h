@@ -10,7 +10,7 @@ struct PackArgs {
     int Cout, Cin, KS;       // stacked forward shape
     int dgrad, CK, nchunk, M, Mp;
     float* dst;
-    int rs;       // 1: register-stationary image of conv_rs.hip (nsrc = 1): [slab][q][lane][4] + a zero block
+    int rs;       // 1: register-stationary image of conv_rs.hip (nsrc = 1): [slab][q][lane][4] + a zero block; 2: split-bf16 image of conv_x3.hip
     int rs_nq, rs_nslab;
 };
 long avc_pack_total(const PackArgs& p);
@@ -28,6 +28,10 @@ void avc_pack_rs_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, in
 int avc_launch_pack_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, hipStream_t stream);
 int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream);
 void avc_set_conv_rs(int on);
+// split-bf16 conv (conv_x3.hip): ConvArgs.rs == 2, PackArgs.rs == 2
+long avc_conv_x3_image_floats(int M, int Cred);
+void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst);
+int avc_launch_conv_x3(const ConvArgs& a, hipStream_t stream);
 // one-shot short-row conv (conv_small.hip): same packed images as conv_gemm.hip
 bool avc_conv_small_eligible(const ConvArgs& a, bool forced);
 int avc_launch_conv_small(const ConvArgs& a, hipStream_t stream);

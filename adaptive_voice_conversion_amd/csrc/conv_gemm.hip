@@ -29,6 +29,7 @@
 #include "avc_internal.h"
 
 #include "conv_shared.h"
+#include "conv_x3_shared.h"
 
 // one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
 // of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR).
@@ -467,6 +468,10 @@ __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs
 }
 
 static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride) {
+    if (p.rs == 2) {
+        avc_pack_x3_one(p, first, stride);
+        return;
+    }
     if (p.rs) {  // register-stationary image (conv_rs.hip): ks = 4q + u = c2 * KS + j, c = 2 * c2 + (lane >> 5), m = 32 * slab + (lane & 31)
         const long total = (long)p.rs_nslab * p.rs_nq * 256;
         const int M = p.dgrad ? p.Cin : p.Cout, Cred = p.dgrad ? p.Cout : p.Cin;
@@ -624,6 +629,7 @@ void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
 
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
+    if (a_in.rs == 2 || force_tile == 97) return avc_launch_conv_x3(a_in, stream);
     if (a_in.rs || force_tile == 99) return avc_launch_conv_rs(a_in, stream);
     if ((force_tile == 0 || force_tile == 98) && !g_conv_ablation && avc_conv_small_eligible(a_in, force_tile == 98)) return avc_launch_conv_small(a_in, stream);
     if (force_tile == 98) return -8;
@@ -690,6 +696,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
 }
 
 long avc_pack_total(const PackArgs& p) {
+    if (p.rs == 2) return (long)p.nchunk * p.KS * 6 * p.Mp * 4;
     return p.rs ? (long)p.rs_nslab * p.rs_nq * 256 + 128 : (long)p.nchunk * p.KS * p.CK * p.Mp;
 }
 

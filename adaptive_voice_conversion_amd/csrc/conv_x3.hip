@@ -1,0 +1,204 @@
+// fp32-accurate Conv1d on the BF16 matrix core: every operand is the sum of THREE bf16 terms
+//     x = hi + mid + lo            (8 + 8 + 8 mantissa bits; hi / mid by truncation of the exact remainders)
+// and a product keeps the six partial products above 2^-24 of its magnitude,
+//     a b ~= hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid,
+// each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Six of them (6 x 8 passes) cover 16 reduction steps for which
+// the exact-fp32 v_mfma_f32_32x32x2_f32 needs 8 x 16 passes: 2.7x fewer matrix-pipe cycles.  Measured on MI355X
+// (scripts/probe/bf16x3_probe.hip, profiles/r02_bf16x3_probe.log): max error 1.3e-7 of the result's scale (an fp32 fmaf chain
+// of the same products: 1.8e-7) and 185-255 fp32-equivalent TFLOP/s in the inner loop against 100-134 for the fp32 MFMA.
+//
+// Same contraction, geometry, LDS-DMA staging and fused epilogue as conv_gemm.hip (reference: model.py:21-32 pad_layer +
+// nn.Conv1d and its input gradient) for its k = 5 layers: 64x64 tile, 4 waves, 16-channel chunks.  Differences:
+//   * the weights are split ONCE per optimizer step by the pack kernel into a k-contiguous bf16 image
+//     [chunk][tap][term][k-half][m][8 bf16]: a lane's A fragment of a term is one 16-byte LDS read;
+//   * the source tile stays fp32 [channel][position] (DMA'd as before); a lane reads its 8 channels of a tap, adds the
+//     mirror window of the reflect adjoint where needed, and splits the 8 values in registers (~50 VALU per 6 MFMAs).
+// STATUS: op-level only (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad + avc_pack_weight_x3); whole-model plans do not use
+// it.  Parity is green on hardware (error 0.6-2.4x that of an fp32 convolution against fp64), but in THIS kernel structure
+// -- 32x32 per wave, so every B fragment is split for only six MFMAs, and 70 KB of LDS (two workgroups per CU) -- it is not
+// faster than the exact-fp32 kernel: forward 65 vs 68 us at T=128, 33 vs 40 us at T=64, mirrored dgrad SLOWER (85 vs 69 us)
+// (profiles/r02_conv_micro_x3.log).  The probe's 64x32 / 64x64 per-wave tiles (240-255 TF) are the shape the next kernel needs.
+#include <hip/hip_runtime.h>
+
+#include "avc_common.h"
+#include "avc_internal.h"
+#include "conv_shared.h"
+
+#include "conv_x3_shared.h"
+
+template <bool MIRROR>
+__global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) {
+    constexpr int BM = 64, BN = 64, KS = X3_KS, CK = X3_CK;
+    HIP_DYNAMIC_SHARED(float, smem)
+    const ConvGroup g = a.g[0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    const int padL = g.padL, padR = g.padR, nchunk = g.nchunk;
+    const int Tout = a.Tout;
+    const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
+    const int ROW = q.ROW;
+    const int m_tile0 = blockIdx.y * BM;
+    constexpr int AS = X3_AROWS * 256;   // floats per A stage (30 KiB)
+    const int XS = CK * ROW;
+    float* As = smem;
+    float* Xs = smem + 2 * AS;
+
+    // per-lane source descriptors of the X tile (as conv_gemm.hip: position p = 64 j + lane of every row)
+    int xoff[AVC_CONV_NJ];
+#pragma unroll
+    for (int j = 0; j < AVC_CONV_NJ; ++j) {
+        const int p = 64 * j + lane;
+        int sp = -1;
+        if (p < q.ROWDATA) {
+            const int seg = p / q.SEG, qq = p - seg * q.SEG;
+            const int b = q.b0 + seg, pp = q.seg_p0 + qq;
+            if (b < a.B) {
+                if (a.mode == 0) {
+                    const int r = avc_reflect(pp - padL, a.Tsrc);
+                    if (r >= 0 && r < a.Tsrc) sp = (int)(b * a.x.sb + (long)r * a.x.st);
+                } else {
+                    const int v = pp - (KS - 1);
+                    if (v >= 0) {
+                        const int vs = v / a.stride;
+                        if (vs * a.stride == v && vs < a.Tsrc) sp = (int)(b * a.x.sb + (long)vs * a.x.st);
+                    }
+                }
+            }
+        }
+        xoff[j] = sp;
+    }
+    for (int e = tid; e < 2 * XS; e += AVC_THREADS) Xs[e] = 0.f;   // structural zeros are never overwritten afterwards
+
+    // the lane's column (a.par: one column parity per wave -- stride-2 dgrad multiplies only the taps of that parity)
+    const int n = wave_n * 32 + li;
+    int bl, t;
+    bool v;
+    if (a.par) {
+        if (Tout >= BN) { bl = 0; t = q.t0 + 2 * li + wave_n; v = (t < Tout) && (q.b0 < a.B); }
+        else { const int halfT = Tout >> 1; bl = li / halfT; t = 2 * (li - bl * halfT) + wave_n; v = (bl < q.SPT) && (q.b0 + bl < a.B); }
+    } else if (q.SPT == 1 && Tout >= BN) {
+        bl = 0; t = q.t0 + n; v = (t < Tout) && (q.b0 < a.B);
+    } else {
+        bl = n / Tout; t = n - bl * Tout; v = (bl < q.SPT) && (q.b0 + bl < a.B);
+    }
+    int cb = q.ROWDATA, cbm = q.ROWDATA;   // ROWDATA.. = the null window
+    if (v) {
+        if (a.mode == 0) cb = bl * q.SEG + (t - q.t0) * a.stride;
+        else {
+            cb = bl * q.SEG + (t - q.t0) + padL;
+            if (MIRROR) {   // (launcher: Tout >= 2 (padL + padR) + 2 -> at most one mirror window per column)
+                if (t >= 1 && t <= padL) cbm = bl * q.SEG + (padL - t - q.seg_p0);
+                if (t >= Tout - 1 - padR && t <= Tout - 2) cbm = bl * q.SEG + (2 * (Tout - 1) - t + padL - q.seg_p0);
+            }
+        }
+    }
+    const bool use_mirror = MIRROR && __any(cbm != q.ROWDATA);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nj = (ROW + 63) >> 6;
+    __syncthreads();   // zero fill done before the first DMA lands
+
+    auto load_a = [&](int chunk, int buf) {   // 30 rows of 64 m x 16 bytes: the packed image is the LDS image
+        const float* wsrc = g.wp + ((long)chunk * X3_AROWS * a.Mp + m_tile0) * 4;
+        float* Ad = As + buf * AS;
+        for (int row = wave; row < X3_AROWS; row += 4) avc_glds16(wsrc + (long)row * a.Mp * 4 + lane * 4, Ad + row * 256);
+    };
+    auto load_x = [&](int chunk, int buf) {
+        float* Xd = Xs + buf * XS;
+        for (int r = wave; r < CK; r += 4) {
+            const int c = chunk * CK + r;
+            const long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
+            const float* src = a.x.ptr + coff;
+#pragma unroll
+            for (int j = 0; j < AVC_CONV_NJ; ++j)
+                if (j < nj && xoff[j] >= 0) avc_glds4(src + xoff[j], Xd + r * ROW + 64 * j);
+        }
+    };
+    load_a(0, 0);
+    load_x(0, 0);
+    __syncthreads();
+
+    const int a_lane = wave_m * 32 + li;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (chunk + 1 < nchunk) {
+            load_a(chunk + 1, (chunk + 1) & 1);
+            load_x(chunk + 1, (chunk + 1) & 1);
+        }
+        const avc_u32x4* Ab = (const avc_u32x4*)(As + (chunk & 1) * AS);
+        const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;
+#pragma unroll
+        for (int tap = 0; tap < KS; ++tap) {
+            if (a.par && ((tap & 1) != wave_n)) continue;   // (wave-uniform)
+            unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float x = Xb[k * ROW + cb + tap];
+                if (use_mirror) x += Xb[k * ROW + cbm + tap];
+                x3_split(x, hi[k], mid[k], lo[k]);
+            }
+            avc_u32x4 bt[3], at[3];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                bt[0][qd] = x3_pair(hi[2 * qd], hi[2 * qd + 1]);
+                bt[1][qd] = x3_pair(mid[2 * qd], mid[2 * qd + 1]);
+                bt[2][qd] = x3_pair(lo[2 * qd], lo[2 * qd + 1]);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * 64 + a_lane];
+            // small terms first
+            acc = avc_mfma_bf16x8(at[2], bt[0], acc);
+            acc = avc_mfma_bf16x8(at[0], bt[2], acc);
+            acc = avc_mfma_bf16x8(at[1], bt[1], acc);
+            acc = avc_mfma_bf16x8(at[1], bt[0], acc);
+            acc = avc_mfma_bf16x8(at[0], bt[1], acc);
+            acc = avc_mfma_bf16x8(at[0], bt[0], acc);
+        }
+        __syncthreads();
+    }
+    if (v) conv_store_frag(a, g, acc, m_tile0 + wave_m * 32, h, q.b0 + bl, t);
+}
+
+// --------------------------------------------------------------------------
+static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
+    if (KS != X3_KS || Cred < X3_CK || Cred % X3_CK != 0) return false;
+    if (stride != 1 && stride != 2) return false;
+    if (mode == 1 && Tout < 10) return false;   // one mirror window per column
+    const ConvGeom q = conv_geom(mode, stride, Tout, KS, 64, 0);
+    return q.ROW <= 64 * AVC_CONV_NJ;
+}
+long avc_conv_x3_image_floats(int M, int Cred) { return (long)(Cred / X3_CK) * X3_AROWS * (avc_cdiv(M, 128) * 128) * 4; }
+
+void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst) {
+    memset(&p, 0, sizeof(p));
+    const int M = dgrad ? Cin : Cout, Cred = dgrad ? Cout : Cin;
+    p.src[0] = w;
+    p.nsrc = 1; p.rows_per_src = Cout;
+    p.Cout = Cout; p.Cin = Cin; p.KS = KS; p.dgrad = dgrad;
+    p.CK = X3_CK; p.nchunk = Cred / X3_CK;
+    p.M = M; p.Mp = avc_cdiv(M, 128) * 128;
+    p.dst = dst;
+    p.rs = 2;
+}
+
+int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
+    if (a.ngroups != 1 || a.in_fuse || a.bf16 != AVC_COMPUTE_F32) return -1;
+    const ConvGroup& g = a.g[0];
+    if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != X3_CK || g.nchunk * X3_CK != a.Cred || a.Mp % 128 != 0) return -2;
+    if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;
+    const ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, g.KS, 64, 0);
+    const size_t lds = (size_t)(2 * X3_AROWS * 256 + 2 * X3_CK * q.ROW) * 4 + 16;
+    if (lds > 160 * 1024) return -5;
+    const int ntn = a.Tout >= 64 ? a.B * avc_cdiv(a.Tout, 64) : avc_cdiv(a.B, 64 / a.Tout);
+    a.par = a.mode == 1 && a.stride == 2 && g.padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
+    dim3 grid(ntn, a.Mp / 64);
+    const double flops = 2.0 * a.M * a.Cred * g.KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
+    ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
+    if (a.mode == 1 && a.mirror) hipLaunchKernelGGL((conv_x3_kernel<true>), grid, dim3(AVC_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((conv_x3_kernel<false>), grid, dim3(AVC_THREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}

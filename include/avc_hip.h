@@ -222,6 +222,11 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
 /* weight image of the register-stationary conv kernel (csrc/conv_rs.hip; k = 5, 128 reduction channels):
  * pass it as `wp` / `wpd` together with tile = 99 */
 long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad);
+/* weight image of the split-bf16 conv kernel (csrc/conv_x3.hip; k = 5, reduction channels a multiple of 16: every operand as
+ * three bf16 terms, six bf16 MFMAs per product block, fp32-level accuracy): pass it as `wp` / `wpd` together with tile = 97.
+ * Op-level only: whole-model plans multiply in exact fp32 (measured no faster in this form, see the file header). */
+long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad);
+int avc_pack_weight_x3(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
 int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
 /* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b); ops = pixel_shuffle_1d factor of the store
  * (model.py:52-59); res/res_mode: y2 = y + resmap(res) (1 identity, 2 avg_pool1d(2, ceil_mode) model.py:248) */

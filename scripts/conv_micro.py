@@ -15,6 +15,12 @@ def pack(w, dgrad):
     assert lib.avc_pack_weight(arr, 1, Cout, Cout, Cin, KS, dgrad, P(dst), None) == 0
     return dst
 
+def pack_x3(w, dgrad):
+    Cout, Cin, KS = w.shape
+    dst = torch.zeros(lib.avc_packed_weight_floats_x3(Cout, Cin, KS, dgrad), device=dev)
+    assert lib.avc_pack_weight_x3(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
+    return dst
+
 def pack_rs(w, dgrad):
     Cout, Cin, KS = w.shape
     dst = torch.zeros(lib.avc_packed_weight_floats_rs(Cout, Cin, KS, dgrad), device=dev)
@@ -42,20 +48,22 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
     wp, wpd = pack(w, 0), pack(w, 1)
     rs_ok = KS == 5 and Cin == 128
     wrs, wrsd = (pack_rs(w, 0), pack_rs(w, 1)) if rs_ok else (None, None)
+    x3_ok = KS == 5 and Cin % 16 == 0 and Cout % 16 == 0 and 97 in tiles
+    wx3, wx3d = (pack_x3(w, 0), pack_x3(w, 1)) if x3_ok else (None, None)
     flops = 2.0 * Cout * Cin * KS * B * To
     res = []
     for tile in tiles:
         if tile == 99 and not rs_ok:
             continue
         if "f" in which:
-            f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wrs if tile == 99 else wp), P(b), Cout, KS, stride, 1, P(out),
+            f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wrs if tile == 99 else (wx3 if tile == 97 else wp)), P(b), Cout, KS, stride, 1, P(out),
                                            out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, tile, None)
             assert f() == 0
             us = timeit(f); res.append(f"fwd t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
         if "d" in which:
             if tile == 99 and Cout != 128:
                 continue
-            f = lambda: lib.avc_conv1d_dgrad(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, To, P(wrsd if tile == 99 else wpd), Cin, KS, stride, T, P(dx),
+            f = lambda: lib.avc_conv1d_dgrad(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, To, P(wrsd if tile == 99 else (wx3d if tile == 97 else wpd)), Cin, KS, stride, T, P(dx),
                                              dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, tile, None)
             assert f() == 0
             us = timeit(f); res.append(f"dgr t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
@@ -67,6 +75,15 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
         assert f() == 0
         us = timeit(f); res.append(f"wgrad(+reduce): {us:7.1f}us {flops/us/1e6:6.1f}TF")
     print(f"B={B} {Cin}->{Cout} T={T} k={KS} s={stride}: " + " | ".join(res), flush=True)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "x3":
+    for B in (256, 1024):
+        for T in (128, 64, 32, 16):
+            run(B, 128, 128, T, 5, 1, tiles=(0, 97), which="fd")
+        run(B, 128, 128, 128, 5, 2, tiles=(0, 97), which="fd")
+        run(B, 128, 256, 64, 5, 1, tiles=(0, 97), which="f")
+    run(64, 128, 128, 1024, 5, 1, tiles=(0, 97), which="fd")
+    sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s2":
     for par in (0, 1):

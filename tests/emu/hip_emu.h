@@ -125,6 +125,33 @@ static inline f32x16_t mfma_32x32x8_bf16(s16x4_t a, s16x4_t b, f32x16_t c) {
     wave_sync();
     return c;
 }
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][col=l&31], j = 0..7 in the lane's eight bf16 slots
+// (slot j = half j&1 of dword j>>1, low half first); C/D as the fp32 32x32 shape (checked on hardware by
+// scripts/probe/bf16x3_probe.hip's accuracy test)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+static inline f32x16_t mfma_32x32x16_bf16(u32x4_t a, u32x4_t b, f32x16_t c) {
+    // two rounds through the 16-byte wave slots: A fragments, then B fragments
+    u32x4_t* buf = (u32x4_t*)wave_buf();
+    int l = lane();
+    u32x4_t afr[64], bfr[64];
+    buf[l] = a;
+    wave_sync();
+    for (int i = 0; i < 64; ++i) afr[i] = buf[i];
+    wave_sync();
+    buf[l] = b;
+    wave_sync();
+    for (int i = 0; i < 64; ++i) bfr[i] = buf[i];
+    wave_sync();
+    auto el = [](const u32x4_t& v, int j) { unsigned d = v[j >> 1]; return bf16_to_f32((short)((j & 1) ? (d >> 16) : (d & 0xffffu))); };
+    int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(el(afr[row + 32 * (k >> 3)], k & 7), el(bfr[col + 32 * (k >> 3)], k & 7), acc);
+        c[r] = acc;
+    }
+    return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C: col=l&15,row=4*(l>>4)+r
 static inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
     float2* buf = (float2*)wave_buf();

@@ -416,3 +416,74 @@ def test_conv_rs_dgrad_matches_autograd(kind, B, Cin, T, stride):
                               None, 99, None)
     assert rc == 0, rc
     torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
+
+
+# ---- split-bf16 conv kernel (csrc/conv_x3.hip): tile code 97 + its own weight image.  Every operand as three bf16 terms,
+# six bf16 MFMAs per product block: the result must be as close to exact arithmetic as an fp32 convolution is.
+def pack_x3(lib, dev, w, dgrad):
+    Cout, Cin, KS = w.shape
+    n = lib.avc_packed_weight_floats_x3(Cout, Cin, KS, dgrad)
+    assert n > 0
+    dst = torch.zeros(n, device=dev)
+    assert lib.avc_pack_weight_x3(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
+    return dst
+
+
+X3 = [
+    # B, Cin, Cout, T, stride
+    (2, 16, 32, 40, 1),       # one chunk, partial second tile
+    (3, 32, 48, 16, 1),       # two chunks, several samples per tile, rows >= Cout masked
+    (2, 32, 32, 21, 2),       # stride 2, odd T (dgrad: all taps)
+    (2, 16, 32, 32, 2),       # stride 2 (dgrad: one column parity per wave)
+    (1, 32, 144, 70, 1),      # three row tiles
+    pytest.param(64, 128, 128, 128, 1, marks=GPU),
+    pytest.param(64, 128, 128, 64, 2, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,stride", X3)
+def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
+    if kind == "emu" and B * Cin * Cout * T > 3e6:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 31 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, generator=g) / (Cin * 5) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xd64 = x.double().requires_grad_(True)
+    y64 = O.pad_conv(xd64, w.double(), b.double(), stride)
+    y32 = O.pad_conv(x, w, b, stride)
+    wp = pack_x3(lib, dev, w.to(dev), 0)
+    out = torch.full(y32.shape, float("nan"), device=dev)
+    xd = x.to(dev)
+    rc = lib.avc_conv1d_fwd(P(xd), xd.stride(0), xd.stride(1), 1, B, Cin, T, P(wp), P(b.to(dev)), Cout, 5, stride, 0, P(out),
+                            out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, 97, None)
+    assert rc == 0, rc
+    e_x3 = (out.cpu().double() - y64.detach()).abs().max().item()
+    e_32 = (y32.double() - y64.detach()).abs().max().item()
+    print(f"[{kind} x3 fwd B={B} {Cin}->{Cout} T={T} s={stride}] max |err| vs fp64: split-bf16 {e_x3:.2e}, fp32 conv {e_32:.2e}")
+    # the hardware sums the 16 products of an instruction before it rounds into the accumulator; the CPU simulator rounds after
+    # every product (6 x more roundings than an fp32 convolution), so its bar is wider
+    bar = 3.0 if kind == "gpu" else 10.0
+    assert e_x3 <= bar * e_32 + 1e-7, (e_x3, e_32)
+    torch.testing.assert_close(out.cpu(), y32, rtol=1e-5, atol=2e-5)
+    # input gradient
+    dy = torch.randn(y32.shape, generator=g)
+    (dx64,) = torch.autograd.grad(y64, xd64, dy.double())
+    xg = x.clone().requires_grad_(True)
+    (dx32,) = torch.autograd.grad(O.pad_conv(xg, w, None, stride), xg, dy)
+    wpd = pack_x3(lib, dev, w.to(dev), 1)
+    dx = torch.full((B, Cin, T), float("nan"), device=dev)
+    dyd = dy.to(dev)
+    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cout, dy.shape[2], P(wpd), Cin, 5, stride, T, P(dx),
+                              dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, 97, None)
+    if T < 10:
+        assert rc != 0
+        return
+    assert rc == 0, rc
+    e_x3 = (dx.cpu().double() - dx64).abs().max().item()
+    e_32 = (dx32.double() - dx64).abs().max().item()
+    print(f"[{kind} x3 dgrad] max |err| vs fp64: split-bf16 {e_x3:.2e}, fp32 conv {e_32:.2e}")
+    assert e_x3 <= bar * e_32 + 1e-7, (e_x3, e_32)
+    torch.testing.assert_close(dx.cpu(), dx32, rtol=1e-5, atol=2e-5)
