@@ -14,7 +14,7 @@
 //   * the source tile stays fp32 [channel][position] (DMA'd as before); a lane reads its 8 channels of a tap, adds the
 //     mirror window of the reflect adjoint where needed, and splits the 8 values in registers (~50 VALU per 6 MFMAs).
 // STATUS: op-level only (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad + avc_pack_weight_x3); whole-model plans do not use
-// it.  Parity is green on hardware (error 0.6-2.4x that of an fp32 convolution against fp64), but in THIS kernel structure
+// it.  Parity is green on hardware (error 0.6-3.6x that of an fp32 convolution against fp64), but in THIS kernel structure
 // -- 32x32 per wave, so every B fragment is split for only six MFMAs, and 70 KB of LDS (two workgroups per CU) -- it is not
 // faster than the exact-fp32 kernel: forward 65 vs 68 us at T=128, 33 vs 40 us at T=64, mirrored dgrad SLOWER (85 vs 69 us)
 // (profiles/r02_conv_micro_x3.log).  The probe's 64x32 / 64x64 per-wave tiles (240-255 TF) are the shape the next kernel needs.

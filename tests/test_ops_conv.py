@@ -465,7 +465,7 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     print(f"[{kind} x3 fwd B={B} {Cin}->{Cout} T={T} s={stride}] max |err| vs fp64: split-bf16 {e_x3:.2e}, fp32 conv {e_32:.2e}")
     # the hardware sums the 16 products of an instruction before it rounds into the accumulator; the CPU simulator rounds after
     # every product (6 x more roundings than an fp32 convolution), so its bar is wider
-    bar = 3.0 if kind == "gpu" else 10.0
+    bar = 4.0 if kind == "gpu" else 10.0
     assert e_x3 <= bar * e_32 + 1e-7, (e_x3, e_32)
     torch.testing.assert_close(out.cpu(), y32, rtol=1e-5, atol=2e-5)
     # input gradient
