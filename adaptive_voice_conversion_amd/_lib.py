@@ -119,6 +119,9 @@ def declare(lib):
     lib.avc_dsp_griffin_lim_ws_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.avc_dsp_griffin_lim_ws_floats.restype = c_long
     lib.avc_dsp_griffin_lim.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_stft_batch.argtypes = [c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_istft_batch.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_griffin_lim_batch.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_dsp_magnitude.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.avc_dsp_db_normalize.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     lib.avc_dsp_denormalize_amp.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]

@@ -39,8 +39,8 @@ void avc_set_conv_small(int on);
 void avc_set_dgrad_par(int on);
 // mel <-> waveform DSP (dsp.hip)
 int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s);
-int avc_launch_dsp_frames(const float* y, long L, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);
-int avc_launch_dsp_ola(const float* tf, int T, int hop, int n_fft, int win, float* y, hipStream_t s);
+int avc_launch_dsp_frames(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);
+int avc_launch_dsp_ola(const float* tf, int B, int T, int hop, int n_fft, int win, float* y, hipStream_t s);
 int avc_launch_dsp_phase(const float* est, const float* S, int F, int T, float* out, hipStream_t s);
 int avc_launch_dsp_mag(const float* spec, int F, int T, float* mag, hipStream_t s);
 int avc_launch_dsp_db_norm(const float* in, int C, int T, float ref_db, float max_db, float* out, hipStream_t s);

@@ -55,19 +55,25 @@ __global__ void __launch_bounds__(AVC_THREADS) dsp_basis_kernel(int which, int n
     }
 }
 
-__global__ void __launch_bounds__(AVC_THREADS) dsp_frames_kernel(const float* y, long L, int T, int hop, int n_fft, int win, float* frames) {
+// B signals of L samples each (y[b * L + i]) -> frames[k][b * T + t]: the utterances of a batch are columns of ONE GEMM
+__global__ void __launch_bounds__(AVC_THREADS) dsp_frames_kernel(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames) {
     const int n0 = (n_fft - win) / 2;
-    const long total = (long)win * T;
+    const long BT = (long)B * T, total = (long)win * BT;
     for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < total; e += (long)gridDim.x * AVC_THREADS) {
-        const int k = (int)(e / T), t = (int)(e - (long)k * T);
-        frames[e] = y[dsp_reflect((long)t * hop + n0 + k - n_fft / 2, L)];
+        const int k = (int)(e / BT);
+        const long c = e - (long)k * BT;
+        const int b = (int)(c / T), t = (int)(c - (long)b * T);
+        frames[e] = y[(long)b * L + dsp_reflect((long)t * hop + n0 + k - n_fft / 2, L)];
     }
 }
 
 // y[s] = sum_t tf[q - t*hop - n0, t] / sum_t w^2[q - t*hop - n0],  q = s + n_fft/2   (tf already carries the window)
-__global__ void __launch_bounds__(AVC_THREADS) dsp_ola_kernel(const float* tf, int T, int hop, int n_fft, int win, float* y, long Ly) {
+__global__ void __launch_bounds__(AVC_THREADS) dsp_ola_kernel(const float* tf, int B, int T, int hop, int n_fft, int win, float* y, long Ly) {
     const int n0 = (n_fft - win) / 2;
-    for (long s = (long)blockIdx.x * AVC_THREADS + threadIdx.x; s < Ly; s += (long)gridDim.x * AVC_THREADS) {
+    const long BT = (long)B * T;
+    for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < (long)B * Ly; e += (long)gridDim.x * AVC_THREADS) {
+        const int b = (int)(e / Ly);
+        const long s = e - (long)b * Ly;
         const long q = s + n_fft / 2 - n0;          // k = q - t*hop must lie in [0, win)
         long t1 = q / hop;
         long t0 = (q - win + hop) / hop;            // ceil((q - win + 1) / hop) for q - win + 1 > 0
@@ -77,10 +83,10 @@ __global__ void __launch_bounds__(AVC_THREADS) dsp_ola_kernel(const float* tf, i
         for (long t = t0; t <= t1; ++t) {
             const int k = (int)(q - t * hop);
             const float w = 0.5f - 0.5f * cospif(2.0f * (float)k / (float)win);
-            acc += tf[(long)k * T + t];
+            acc += tf[(long)k * BT + (long)b * T + t];
             wss += w * w;
         }
-        y[s] = wss > 1.17549435e-38f ? acc / wss : acc;
+        y[e] = wss > 1.17549435e-38f ? acc / wss : acc;
     }
 }
 
@@ -191,16 +197,16 @@ int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s)
     hipLaunchKernelGGL(dsp_basis_kernel, dim3(dsp_blocks((long)(n_fft + 2) * win)), dim3(AVC_THREADS), 0, s, which, n_fft, win, W);
     return (int)hipGetLastError();
 }
-int avc_launch_dsp_frames(const float* y, long L, int T, int hop, int n_fft, int win, float* frames, hipStream_t s) {
-    ProfScope ps(AVC_K_MISC, 0.0, 8.0 * (double)win * T, s);
-    hipLaunchKernelGGL(dsp_frames_kernel, dim3(dsp_blocks((long)win * T)), dim3(AVC_THREADS), 0, s, y, L, T, hop, n_fft, win, frames);
+int avc_launch_dsp_frames(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames, hipStream_t s) {
+    ProfScope ps(AVC_K_MISC, 0.0, 8.0 * (double)win * B * T, s);
+    hipLaunchKernelGGL(dsp_frames_kernel, dim3(dsp_blocks((long)win * B * T)), dim3(AVC_THREADS), 0, s, y, L, B, T, hop, n_fft, win, frames);
     return (int)hipGetLastError();
 }
-int avc_launch_dsp_ola(const float* tf, int T, int hop, int n_fft, int win, float* y, hipStream_t s) {
+int avc_launch_dsp_ola(const float* tf, int B, int T, int hop, int n_fft, int win, float* y, hipStream_t s) {
     const long Ly = (long)hop * (T - 1);
     if (Ly < 1) return -1;
-    ProfScope ps(AVC_K_MISC, 0.0, 4.0 * ((double)win * T + Ly), s);
-    hipLaunchKernelGGL(dsp_ola_kernel, dim3(dsp_blocks(Ly)), dim3(AVC_THREADS), 0, s, tf, T, hop, n_fft, win, y, Ly);
+    ProfScope ps(AVC_K_MISC, 0.0, 4.0 * B * ((double)win * T + Ly), s);
+    hipLaunchKernelGGL(dsp_ola_kernel, dim3(dsp_blocks((long)B * Ly)), dim3(AVC_THREADS), 0, s, tf, B, T, hop, n_fft, win, y, Ly);
     return (int)hipGetLastError();
 }
 int avc_launch_dsp_phase(const float* est, const float* S, int F, int T, float* out, hipStream_t s) {

@@ -28,57 +28,75 @@ int avc_dsp_make_basis(int n_fft, int hop_length, int win_length, int inverse, f
                    : avc_pack_weight(&src, 1, F2, F2, win_length, 1, 0, packed, stream);
 }
 
-// spec[2F][T] = Wf[2F][win] x frames[win][T]
-int avc_dsp_stft(const float* y, long L, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
-                 float* spec, void* stream) {
-    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !y || !basis_fwd || !frames_ws || !spec) return -1;
+// spec[2F][B T] = Wf[2F][win] x frames[win][B T]   (B signals of L samples: their frames are columns of one GEMM)
+int avc_dsp_stft_batch(const float* y, long L, int B, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
+                       float* spec, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !y || !basis_fwd || !frames_ws || !spec || B < 1) return -1;
     if (L <= n_fft / 2) return -6;   // numpy reflect padding needs pad < len (the reference's librosa call raises there)
     const int T = avc_dsp_num_frames(L, hop_length), F2 = n_fft + 2;
-    int rc = avc_launch_dsp_frames(y, L, T, hop_length, n_fft, win_length, frames_ws, (hipStream_t)stream);
+    const long BT = (long)B * T;
+    if (BT > 0x7fffffffL) return -1;
+    int rc = avc_launch_dsp_frames(y, L, B, T, hop_length, n_fft, win_length, frames_ws, (hipStream_t)stream);
     if (rc) return rc;
-    return avc_conv1d_fwd(frames_ws, 0, T, 1, 1, win_length, T, basis_fwd, nullptr, F2, 1, 1, 0, spec, 0, T, 1, 1, nullptr, 0, 0, 0, 0,
-                          0, nullptr, 0, stream);
+    return avc_conv1d_fwd(frames_ws, 0, BT, 1, 1, win_length, (int)BT, basis_fwd, nullptr, F2, 1, 1, 0, spec, 0, BT, 1, 1, nullptr, 0, 0, 0,
+                          0, 0, nullptr, 0, stream);
+}
+int avc_dsp_stft(const float* y, long L, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
+                 float* spec, void* stream) {
+    return avc_dsp_stft_batch(y, L, 1, n_fft, hop_length, win_length, basis_fwd, frames_ws, spec, stream);
 }
 
 // y[hop (T-1)] = overlap-add of tf[win][T] = Wi[win][2F] x spec[2F][T], over the window's sum of squares
+int avc_dsp_istft_batch(const float* spec, int B, int T, int n_fft, int hop_length, int win_length, const float* basis_inv, float* tf_ws,
+                        float* y, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !spec || !basis_inv || !tf_ws || !y || T < 2 || B < 1) return -1;
+    const int F2 = n_fft + 2;
+    const long BT = (long)B * T;
+    if (BT > 0x7fffffffL) return -1;
+    int rc = avc_conv1d_fwd(spec, 0, BT, 1, 1, F2, (int)BT, basis_inv, nullptr, win_length, 1, 1, 0, tf_ws, 0, BT, 1, 1, nullptr, 0, 0, 0, 0,
+                            0, nullptr, 0, stream);
+    if (rc) return rc;
+    return avc_launch_dsp_ola(tf_ws, B, T, hop_length, n_fft, win_length, y, (hipStream_t)stream);
+}
 int avc_dsp_istft(const float* spec, int T, int n_fft, int hop_length, int win_length, const float* basis_inv, float* tf_ws, float* y,
                   void* stream) {
-    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !spec || !basis_inv || !tf_ws || !y || T < 2) return -1;
-    const int F2 = n_fft + 2;
-    int rc = avc_conv1d_fwd(spec, 0, T, 1, 1, F2, T, basis_inv, nullptr, win_length, 1, 1, 0, tf_ws, 0, T, 1, 1, nullptr, 0, 0, 0, 0, 0,
-                            nullptr, 0, stream);
-    if (rc) return rc;
-    return avc_launch_dsp_ola(tf_ws, T, hop_length, n_fft, win_length, y, (hipStream_t)stream);
+    return avc_dsp_istft_batch(spec, 1, T, n_fft, hop_length, win_length, basis_inv, tf_ws, y, stream);
 }
 
-long avc_dsp_griffin_lim_ws_floats(int T, int n_fft, int hop_length, int win_length) {
+long avc_dsp_griffin_lim_ws_floats(int T, int n_fft, int hop_length, int win_length) {   // T = frames of ALL utterances of a batch
     const long F2 = n_fft + 2;
     auto up = [](long n) { return (n + 63) / 64 * 64; };
     return 2 * up(F2 * T) + up((long)win_length * T) + up((long)hop_length * T);
 }
 
 // utils.py:136-147: X = S; repeat n_iter: x = istft(X); est = stft(x); X = S * est / max(1e-8, |est|); return istft(X)
-int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
-                        const float* basis_inv, float* ws, float* y, void* stream) {
-    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !basis_fwd || !basis_inv || !ws || !y || T < 2 || n_iter < 0) return -1;
-    const long Ly = (long)hop_length * (T - 1);
+// B utterances of T frames each: S is [F][B T] (utterance b in columns b T .. b T + T - 1), y is [B][hop (T - 1)]
+int avc_dsp_griffin_lim_batch(const float* S, int B, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
+                              const float* basis_inv, float* ws, float* y, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !basis_fwd || !basis_inv || !ws || !y || T < 2 || B < 1 || n_iter < 0) return -1;
+    const long Ly = (long)hop_length * (T - 1), BT = (long)B * T;
     if (Ly <= n_fft / 2) return -6;
+    if (BT > 0x7fffffffL) return -1;
     const int F = n_fft / 2 + 1;
     const long F2 = n_fft + 2;
     auto up = [](long n) { return (n + 63) / 64 * 64; };
     float* xbest = ws;
-    float* est = xbest + up(F2 * T);
-    float* fr = est + up(F2 * T);                  // frames of the STFT / time frames of the iSTFT (never live together)
-    float* xt = fr + up((long)win_length * T);
+    float* est = xbest + up(F2 * BT);
+    float* fr = est + up(F2 * BT);                 // frames of the STFT / time frames of the iSTFT (never live together)
+    float* xt = fr + up((long)win_length * BT);
     hipStream_t s = (hipStream_t)stream;
-    int rc = avc_launch_dsp_phase(nullptr, S, F, T, xbest, s);
+    int rc = avc_launch_dsp_phase(nullptr, S, F, (int)BT, xbest, s);
     for (int i = 0; i < n_iter && !rc; ++i) {
-        rc = avc_dsp_istft(xbest, T, n_fft, hop_length, win_length, basis_inv, fr, xt, stream);
-        if (!rc) rc = avc_dsp_stft(xt, Ly, n_fft, hop_length, win_length, basis_fwd, fr, est, stream);   // 1 + Ly / hop == T frames
-        if (!rc) rc = avc_launch_dsp_phase(est, S, F, T, xbest, s);
+        rc = avc_dsp_istft_batch(xbest, B, T, n_fft, hop_length, win_length, basis_inv, fr, xt, stream);
+        if (!rc) rc = avc_dsp_stft_batch(xt, Ly, B, n_fft, hop_length, win_length, basis_fwd, fr, est, stream);   // 1 + Ly / hop == T frames
+        if (!rc) rc = avc_launch_dsp_phase(est, S, F, (int)BT, xbest, s);
     }
-    if (!rc) rc = avc_dsp_istft(xbest, T, n_fft, hop_length, win_length, basis_inv, fr, y, stream);
+    if (!rc) rc = avc_dsp_istft_batch(xbest, B, T, n_fft, hop_length, win_length, basis_inv, fr, y, stream);
     return rc;
+}
+int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
+                        const float* basis_inv, float* ws, float* y, void* stream) {
+    return avc_dsp_griffin_lim_batch(S, 1, T, n_fft, hop_length, win_length, n_iter, basis_fwd, basis_inv, ws, y, stream);
 }
 
 int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream) {

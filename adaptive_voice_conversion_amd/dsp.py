@@ -204,6 +204,37 @@ class MelDSP:
                                                   _P(self.basis_fwd), _P(self.basis_inv), _P(ws), _P(y), self._stream()))
         return y
 
+    def griffin_lim_batch(self, spectrograms, n_iter=None):
+        """B equally long utterances in ONE set of launches: spectrograms [B, F, T] (or a list of [F, T]).  Returns [B, hop (T-1)]
+        device waveforms.  A lone 400-frame utterance fills half the chip; eight of them are one efficient GEMM per transform."""
+        hp = self.hp
+        S = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in spectrograms]) if not torch.is_tensor(spectrograms) else spectrograms
+        S = S.to(self.device).float()
+        B, F, T = S.shape
+        Scat = S.permute(1, 0, 2).reshape(F, B * T).contiguous()          # [F][B T]: utterance b in columns b T ..
+        return self._griffin_lim_cat(Scat, B, T, n_iter)
+
+    def _griffin_lim_cat(self, Scat, B, T, n_iter):
+        hp = self.hp
+        ws = torch.empty(self.lib.avc_dsp_griffin_lim_ws_floats(B * T, hp.n_fft, hp.hop_length, hp.win_length), device=self.device)
+        y = torch.empty(B, hp.hop_length * (T - 1), device=self.device)
+        with self._dev():
+            self._ok(self.lib.avc_dsp_griffin_lim_batch(_P(Scat), B, T, hp.n_fft, hp.hop_length, hp.win_length,
+                                                        hp.n_iter if n_iter is None else n_iter, _P(self.basis_fwd), _P(self.basis_inv),
+                                                        _P(ws), _P(y), self._stream()))
+        return y
+
+    def melspectrogram2wav_batch(self, mels, do_trim=True, n_iter=None):
+        """utils.py:89-109 for B utterances of EQUAL length ([B, T, n_mels] or a list of [T, n_mels]): one launch set.
+        Returns a list of float32 numpy waveforms (trim makes their lengths differ)."""
+        mels = [torch.as_tensor(m, dtype=torch.float32) for m in mels]
+        B, T = len(mels), mels[0].shape[0]
+        if any(m.shape != mels[0].shape for m in mels):
+            raise ValueError("melspectrogram2wav_batch needs equally long utterances (group them by length)")
+        amp = self._amplitudes(torch.cat(mels, dim=0))                       # [C][B T]
+        y = self._griffin_lim_cat(self._matmul(self.mel_inv_w, amp), B, T, n_iter)
+        return [self._finish(y[b], do_trim) for b in range(B)]
+
     def _finish(self, wav, do_trim):
         hp = self.hp
         out = torch.empty_like(wav)

@@ -284,13 +284,18 @@ def dsp_bench(a, dev):
         return (time.perf_counter() - t0) / steps
     t_front = timed(lambda: dsp.get_spectrograms_device(yd, do_trim=False), a.steps, a.warmup)
     t_back = timed(lambda: dsp.melspectrogram2wav(mel, do_trim=False), a.steps, a.warmup)
+    nb = a.batch if a.batch != 256 else 8      # (--batch defaults to the train step's 256)
+    mels = [mel] * nb
+    t_batch = timed(lambda: dsp.melspectrogram2wav_batch(mels, do_trim=False), max(1, a.steps // 2), 1)
     F2, K = hp.n_fft + 2, hp.win_length
     flops = (2 * hp.n_iter + 1) * 2.0 * F2 * K * T + 2.0 * (hp.n_fft // 2 + 1) * hp.n_mels * T
     out = {"metric": f"utterances/sec mel -> waveform (melspectrogram2wav, {hp.n_iter} Griffin-Lim iterations, {a.seconds:g} s of {hp.sr} Hz audio = {T} frames)",
            "value": 1.0 / t_back, "unit": "utterances/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * t_back,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "SURVEY §8f row 4 (not a BASELINE.json config): mel <-> waveform DSP of one utterance, stock hyper-parameters",
-                      "frames": T, "front_end_ms (get_spectrograms, no trim)": 1e3 * t_front},
+                      "frames": T, "front_end_ms (get_spectrograms, no trim)": 1e3 * t_front,
+                      f"batched: {nb} equally long utterances per call (melspectrogram2wav_batch)": {
+                          "ms_per_call": 1e3 * t_batch, "utterances_per_sec": nb / t_batch, "gemm_tflops": nb * flops / t_batch / 1e12}},
            "roofline": {"kernel": "conv_gemm 1x1 (the STFT / iSTFT GEMMs against the windowed DFT bases)", "bound": "mfma",
                         "achieved": flops / t_back / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t_back / 1e12 / 157.3,
                         "traffic": None,

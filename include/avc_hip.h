@@ -204,6 +204,15 @@ int avc_dsp_istft(const float* spec, int T, int n_fft, int hop_length, int win_l
 long avc_dsp_griffin_lim_ws_floats(int T, int n_fft, int hop_length, int win_length);
 int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
                         const float* basis_inv, float* ws, float* y, void* stream);
+/* B equally long utterances at once: their frames are the columns of ONE GEMM per transform (a lone 400-frame utterance is
+ * 133-238 workgroups).  y: [B][L] signals -> spec [2F][B T] with utterance b in columns b T .. b T + T - 1; S likewise [F][B T];
+ * waveforms [B][hop (T - 1)].  Workspaces: the single-utterance sizes with T replaced by B T. */
+int avc_dsp_stft_batch(const float* y, long L, int B, int n_fft, int hop_length, int win_length, const float* basis_fwd, float* frames_ws,
+                       float* spec, void* stream);
+int avc_dsp_istft_batch(const float* spec, int B, int T, int n_fft, int hop_length, int win_length, const float* basis_inv, float* tf_ws,
+                        float* y, void* stream);
+int avc_dsp_griffin_lim_batch(const float* S, int B, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
+                              const float* basis_inv, float* ws, float* y, void* stream);
 int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream);                                   /* utils.py:69 */
 /* out[t][c] = clip((20 log10(max(1e-5, in[c][t])) - ref_db + max_db) / max_db, 1e-8, 1)   (utils.py:76-85) */
 int avc_dsp_db_normalize(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream);

@@ -174,6 +174,22 @@ def test_griffin_lim_and_melspectrogram2wav_match_oracle(kind):
     np.testing.assert_allclose(wav2, D.spectrogram2wav(mag, hp, do_trim=False, n_iter=2), atol=5e-4 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_batched_griffin_lim_equals_one_utterance_at_a_time(kind):
+    """avc_dsp_griffin_lim_batch: the frames of B utterances are columns of one GEMM per transform; every column's dot
+    products are the ones of the single-utterance call, so the waveforms must agree to the last bit."""
+    dsp, hp, dev = make(kind)
+    n = 12000 if kind == "gpu" else 1500
+    mels = [D.get_spectrograms(speechlike(n, hp.sr, 20 + i), hp, do_trim=False)[0] for i in range(3)]
+    one = [dsp.melspectrogram2wav(m, do_trim=False, n_iter=2) for m in mels]
+    many = dsp.melspectrogram2wav_batch(mels, do_trim=False, n_iter=2)
+    assert len(many) == 3
+    for a, b in zip(one, many):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    with pytest.raises(ValueError, match="equally long"):
+        dsp.melspectrogram2wav_batch([mels[0], mels[1][:-3]])
+
+
 @GPU
 def test_gpu_hundred_griffin_lim_iterations_converge_like_the_oracle():
     """utils.py's n_iter = 100: compare what the iteration is FOR -- the spectral convergence
