@@ -8,16 +8,18 @@
 // of the same products: 1.8e-7) and 185-255 fp32-equivalent TFLOP/s in the inner loop against 100-134 for the fp32 MFMA.
 //
 // Same contraction, geometry, LDS-DMA staging and fused epilogue as conv_gemm.hip (reference: model.py:21-32 pad_layer +
-// nn.Conv1d and its input gradient) for its k = 5 layers: 64x64 tile, 4 waves, 16-channel chunks.  Differences:
+// nn.Conv1d and its input gradient) for its k = 5 layers, 16-channel chunks; the workgroup tile is 64 rows x 128 columns with
+// the four waves side by side (64 x 32 each), so that one operand split feeds twelve MFMAs.  Differences:
 //   * the weights are split ONCE per optimizer step by the pack kernel into a k-contiguous bf16 image
 //     [chunk][tap][term][k-half][m][8 bf16]: a lane's A fragment of a term is one 16-byte LDS read;
 //   * the source tile stays fp32 [channel][position] (DMA'd as before); a lane reads its 8 channels of a tap, adds the
 //     mirror window of the reflect adjoint where needed, and splits the 8 values in registers (~50 VALU per 6 MFMAs).
 // STATUS: op-level only (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad + avc_pack_weight_x3); whole-model plans do not use
-// it.  Parity is green on hardware (error 0.6-3.6x that of an fp32 convolution against fp64), but in THIS kernel structure
-// -- 32x32 per wave, so every B fragment is split for only six MFMAs, and 70 KB of LDS (two workgroups per CU) -- it is not
-// faster than the exact-fp32 kernel: forward 65 vs 68 us at T=128, 33 vs 40 us at T=64, mirrored dgrad SLOWER (85 vs 69 us)
-// (profiles/r02_conv_micro_x3.log).  The probe's 64x32 / 64x64 per-wave tiles (240-255 TF) are the shape the next kernel needs.
+// it.  Parity is green on hardware (error 0.6-3.6x that of an fp32 convolution against fp64).  Measured against the exact-fp32
+// kernel (profiles/r02_conv_micro_x3.log): forward 53.6 vs 68.5 us at B=256, T=128 (100 vs 78 TFLOP/s), 185 vs 228 us at B=1024
+// (116 vs 94); mirrored dgrad 63.8 vs 69.1 us; layers with <= 256 workgroups of 64x128 (T_l <= 64 at B=256) are slower.  A
+// first version with 32x32 per wave (one split per six MFMAs) was no faster at all; what still separates this one from the probe's
+// 240 TFLOP/s is everything around the MFMA loop (30 KB of weight image per chunk through LDS, the barriers, 2 workgroups per CU).
 #include <hip/hip_runtime.h>
 
 #include "avc_common.h"
@@ -28,12 +30,12 @@
 
 template <bool MIRROR>
 __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) {
-    constexpr int BM = 64, BN = 64, KS = X3_KS, CK = X3_CK;
+    constexpr int BM = 64, BN = 128, KS = X3_KS, CK = X3_CK;   // 4 waves side by side, each 64 rows x 32 columns: ONE split feeds 12 MFMAs
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[0];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int wave_n = wave;
     const int li = lane & 31, h = lane >> 5;
     const int padL = g.padL, padR = g.padR, nchunk = g.nchunk;
     const int Tout = a.Tout;
@@ -71,13 +73,15 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     }
     for (int e = tid; e < 2 * XS; e += AVC_THREADS) Xs[e] = 0.f;   // structural zeros are never overwritten afterwards
 
-    // the lane's column (a.par: one column parity per wave -- stride-2 dgrad multiplies only the taps of that parity)
+    // the lane's column (a.par: one column parity per wave -- stride-2 dgrad multiplies only the taps of that parity:
+    // waves 0, 2 the even columns, waves 1, 3 the odd ones)
     const int n = wave_n * 32 + li;
+    const int par = wave_n & 1, pi = (wave_n >> 1) * 32 + li;   // parity class and slot inside it (64 slots per tile)
     int bl, t;
     bool v;
     if (a.par) {
-        if (Tout >= BN) { bl = 0; t = q.t0 + 2 * li + wave_n; v = (t < Tout) && (q.b0 < a.B); }
-        else { const int halfT = Tout >> 1; bl = li / halfT; t = 2 * (li - bl * halfT) + wave_n; v = (bl < q.SPT) && (q.b0 + bl < a.B); }
+        if (Tout >= BN) { bl = 0; t = q.t0 + 2 * pi + par; v = (t < Tout) && (q.b0 < a.B); }
+        else { const int halfT = Tout >> 1; bl = pi / halfT; t = 2 * (pi - bl * halfT) + par; v = (bl < q.SPT) && (q.b0 + bl < a.B); }
     } else if (q.SPT == 1 && Tout >= BN) {
         bl = 0; t = q.t0 + n; v = (t < Tout) && (q.b0 < a.B);
     } else {
@@ -96,9 +100,9 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     }
     const bool use_mirror = MIRROR && __any(cbm != q.ROWDATA);
 
-    f32x16 acc;
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
     const int nj = (ROW + 63) >> 6;
     __syncthreads();   // zero fill done before the first DMA lands
 
@@ -122,7 +126,6 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     load_x(0, 0);
     __syncthreads();
 
-    const int a_lane = wave_m * 32 + li;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk + 1 < nchunk) {
             load_a(chunk + 1, (chunk + 1) & 1);
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;
 #pragma unroll
         for (int tap = 0; tap < KS; ++tap) {
-            if (a.par && ((tap & 1) != wave_n)) continue;   // (wave-uniform)
+            if (a.par && ((tap & 1) != par)) continue;   // (wave-uniform)
             unsigned hi[8], mid[8], lo[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
                 if (use_mirror) x += Xb[k * ROW + cbm + tap];
                 x3_split(x, hi[k], mid[k], lo[k]);
             }
-            avc_u32x4 bt[3], at[3];
+            avc_u32x4 bt[3];
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 bt[0][qd] = x3_pair(hi[2 * qd], hi[2 * qd + 1]);
@@ -148,18 +151,25 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
                 bt[2][qd] = x3_pair(lo[2 * qd], lo[2 * qd + 1]);
             }
 #pragma unroll
-            for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * 64 + a_lane];
-            // small terms first
-            acc = avc_mfma_bf16x8(at[2], bt[0], acc);
-            acc = avc_mfma_bf16x8(at[0], bt[2], acc);
-            acc = avc_mfma_bf16x8(at[1], bt[1], acc);
-            acc = avc_mfma_bf16x8(at[1], bt[0], acc);
-            acc = avc_mfma_bf16x8(at[0], bt[1], acc);
-            acc = avc_mfma_bf16x8(at[0], bt[0], acc);
+            for (int wm = 0; wm < 2; ++wm) {
+                avc_u32x4 at[3];
+#pragma unroll
+                for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * 64 + wm * 32 + li];
+                // small terms first
+                acc[wm] = avc_mfma_bf16x8(at[2], bt[0], acc[wm]);
+                acc[wm] = avc_mfma_bf16x8(at[0], bt[2], acc[wm]);
+                acc[wm] = avc_mfma_bf16x8(at[1], bt[1], acc[wm]);
+                acc[wm] = avc_mfma_bf16x8(at[1], bt[0], acc[wm]);
+                acc[wm] = avc_mfma_bf16x8(at[0], bt[1], acc[wm]);
+                acc[wm] = avc_mfma_bf16x8(at[0], bt[0], acc[wm]);
+            }
         }
         __syncthreads();
     }
-    if (v) conv_store_frag(a, g, acc, m_tile0 + wave_m * 32, h, q.b0 + bl, t);
+    if (v) {
+        conv_store_frag(a, g, acc[0], m_tile0, h, q.b0 + bl, t);
+        conv_store_frag(a, g, acc[1], m_tile0 + 32, h, q.b0 + bl, t);
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -167,7 +177,7 @@ static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
     if (KS != X3_KS || Cred < X3_CK || Cred % X3_CK != 0) return false;
     if (stride != 1 && stride != 2) return false;
     if (mode == 1 && Tout < 10) return false;   // one mirror window per column
-    const ConvGeom q = conv_geom(mode, stride, Tout, KS, 64, 0);
+    const ConvGeom q = conv_geom(mode, stride, Tout, KS, 128, 0);
     return q.ROW <= 64 * AVC_CONV_NJ;
 }
 long avc_conv_x3_image_floats(int M, int Cred) { return (long)(Cred / X3_CK) * X3_AROWS * (avc_cdiv(M, 128) * 128) * 4; }
@@ -190,11 +200,11 @@ int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
     const ConvGroup& g = a.g[0];
     if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != X3_CK || g.nchunk * X3_CK != a.Cred || a.Mp % 128 != 0) return -2;
     if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;
-    const ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, g.KS, 64, 0);
+    const ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, g.KS, 128, 0);
     const size_t lds = (size_t)(2 * X3_AROWS * 256 + 2 * X3_CK * q.ROW) * 4 + 16;
     if (lds > 160 * 1024) return -5;
-    const int ntn = a.Tout >= 64 ? a.B * avc_cdiv(a.Tout, 64) : avc_cdiv(a.B, 64 / a.Tout);
-    a.par = a.mode == 1 && a.stride == 2 && g.padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
+    const int ntn = a.Tout >= 128 ? a.B * avc_cdiv(a.Tout, 128) : avc_cdiv(a.B, 128 / a.Tout);
+    a.par = a.mode == 1 && a.stride == 2 && g.padL == 2 && (a.Tout >= 128 || (a.Tout % 2 == 0 && 128 % a.Tout == 0));
     dim3 grid(ntn, a.Mp / 64);
     const double flops = 2.0 * a.M * a.Cred * g.KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);

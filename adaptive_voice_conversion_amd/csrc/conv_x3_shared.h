@@ -24,7 +24,11 @@ static __device__ __forceinline__ void x3_split(float x, unsigned& hi, unsigned&
     mid = x3_bits(r) & 0xffff0000u;
     lo = (x3_bits(r - x3_float(mid)) + 0x8000u) & 0xffff0000u;
 }
-static __device__ __forceinline__ unsigned x3_pair(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }   // (bf16 a, bf16 b)
+#ifndef AVC_EMU
+static __device__ __forceinline__ unsigned x3_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (bf16 a, bf16 b): one v_perm_b32
+#else
+static inline unsigned x3_pair(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
+#endif
 
 #define X3_KS 5
 #define X3_CK 16
