@@ -242,6 +242,12 @@ def test_inference_from_path_wav_to_wav(kind, tmp_path):
     dec = O.ae_inference(torch.from_numpy(pad(smel)).t()[None].float(), torch.from_numpy(pad(tmel)).t()[None].float(), sd, cfg)[0].t().numpy()
     dec = dec * attr["std"] + attr["mean"]
     np.testing.assert_allclose(mel, dec, rtol=1e-3, atol=2e-4)
+    # the batched front: three pairs, two of them equally long -> one batched Griffin-Lim for those two
+    pairs = [(torch.from_numpy(smel).float(), torch.from_numpy(tmel).float())] * 2 + [(torch.from_numpy(smel[:-8]).float(), torch.from_numpy(tmel).float())]
+    wavs, mels = inf.convert_batch_to_wav(pairs)
+    assert len(wavs) == 3 and np.array_equal(wavs[0], wavs[1]) and wavs[2].shape != wavs[0].shape
+    np.testing.assert_allclose(mels[0], mel, rtol=1e-4, atol=1e-4)
+    assert wavs[0].shape == wav.shape and np.allclose(wavs[0], wav, atol=1e-5 * np.abs(wav).max())
     ref = D.melspectrogram2wav(dec, hp)
     assert abs(len(wav) - len(ref)) <= 512                # (trim picks whole 512-sample hops: a borderline frame may flip)
     n = min(len(wav), len(ref))
