@@ -37,6 +37,7 @@ bool avc_conv_small_eligible(const ConvArgs& a, bool forced);
 int avc_launch_conv_small(const ConvArgs& a, hipStream_t stream);
 void avc_set_conv_small(int on);
 void avc_set_dgrad_par(int on);
+int avc_conv_ablation_bits();
 // mel <-> waveform DSP (dsp.hip)
 int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s);
 int avc_launch_dsp_frames(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);

@@ -626,6 +626,7 @@ void avc_set_bank_switch(int on) { g_bank_switch = on ? 1 : 0; }
 // ablation bits of scripts/conv_ablate.py (timing experiments; results are wrong by construction when set)
 static int g_conv_ablation = 0;
 void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
+int avc_conv_ablation_bits() { return g_conv_ablation; }
 
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {

@@ -31,6 +31,8 @@
 template <bool MIRROR>
 __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) {
     constexpr int BM = 64, BN = 128, KS = X3_KS, CK = X3_CK;   // 4 waves side by side, each 64 rows x 32 columns: ONE split feeds 12 MFMAs
+    // (BM = 128 -- one split per 24 MFMAs, one workgroup per CU -- measured no better: 55.2 vs 53.6 us at T=128)
+    constexpr int WM = BM / 32;
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[0];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
     const int ROW = q.ROW;
     const int m_tile0 = blockIdx.y * BM;
-    constexpr int AS = X3_AROWS * 256;   // floats per A stage (30 KiB)
+    constexpr int AS = X3_AROWS * BM * 4;   // floats per A stage (30 KiB)
     const int XS = CK * ROW;
     float* As = smem;
     float* Xs = smem + 2 * AS;
@@ -100,16 +102,21 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     }
     const bool use_mirror = MIRROR && __any(cbm != q.ROWDATA);
 
-    f32x16 acc[2];
+    f32x16 acc[WM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][r] = 0.f;
     const int nj = (ROW + 63) >> 6;
     __syncthreads();   // zero fill done before the first DMA lands
 
-    auto load_a = [&](int chunk, int buf) {   // 30 rows of 64 m x 16 bytes: the packed image is the LDS image
+    auto load_a = [&](int chunk, int buf) {   // 30 rows of BM m x 16 bytes: the packed image is the LDS image
         const float* wsrc = g.wp + ((long)chunk * X3_AROWS * a.Mp + m_tile0) * 4;
         float* Ad = As + buf * AS;
-        for (int row = wave; row < X3_AROWS; row += 4) avc_glds16(wsrc + (long)row * a.Mp * 4 + lane * 4, Ad + row * 256);
+        for (int piece = wave; piece < X3_AROWS * (BM / 64); piece += 4) {
+            const int row = piece / (BM / 64), half = piece % (BM / 64);
+            avc_glds16(wsrc + ((long)row * a.Mp + half * 64 + lane) * 4, Ad + (row * BM + half * 64) * 4);
+        }
     };
     auto load_x = [&](int chunk, int buf) {
         float* Xd = Xs + buf * XS;
@@ -127,7 +134,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        if (chunk + 1 < nchunk) {
+        if (chunk + 1 < nchunk && !(a.dbg & 1)) {   // (dbg: ablation switches of scripts/conv_ablate.py, timing only)
             load_a(chunk + 1, (chunk + 1) & 1);
             load_x(chunk + 1, (chunk + 1) & 1);
         }
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;
 #pragma unroll
         for (int tap = 0; tap < KS; ++tap) {
-            if (a.par && ((tap & 1) != par)) continue;   // (wave-uniform)
+            if ((a.par && ((tap & 1) != par)) || (a.dbg & 2)) continue;   // (wave-uniform)
             unsigned hi[8], mid[8], lo[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -151,10 +158,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
                 bt[2][qd] = x3_pair(lo[2 * qd], lo[2 * qd + 1]);
             }
 #pragma unroll
-            for (int wm = 0; wm < 2; ++wm) {
+            for (int wm = 0; wm < WM; ++wm) {
                 avc_u32x4 at[3];
 #pragma unroll
-                for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * 64 + wm * 32 + li];
+                for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * BM + wm * 32 + li];
                 // small terms first
                 acc[wm] = avc_mfma_bf16x8(at[2], bt[0], acc[wm]);
                 acc[wm] = avc_mfma_bf16x8(at[0], bt[2], acc[wm]);
@@ -167,8 +174,8 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         __syncthreads();
     }
     if (v) {
-        conv_store_frag(a, g, acc[0], m_tile0, h, q.b0 + bl, t);
-        conv_store_frag(a, g, acc[1], m_tile0 + 32, h, q.b0 + bl, t);
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) conv_store_frag(a, g, acc[wm], m_tile0 + 32 * wm, h, q.b0 + bl, t);
     }
 }
 
@@ -196,6 +203,7 @@ void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, in
 
 int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
+    a.dbg = avc_conv_ablation_bits();
     if (a.ngroups != 1 || a.in_fuse || a.bf16 != AVC_COMPUTE_F32) return -1;
     const ConvGroup& g = a.g[0];
     if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != X3_CK || g.nchunk * X3_CK != a.Cred || a.Mp % 128 != 0) return -2;

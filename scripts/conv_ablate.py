@@ -34,6 +34,30 @@ def run(B, Cin, Cout, T, KS, tiles, mode="f"):
         lib.avc_set_debug_ablation(0, 0)
         print(f"{mode} B={B} {Cin}->{Cout} T={T} k={KS} t{tile} (ideal {flops/157.3e6:5.1f}us): " + " | ".join(res), flush=True)
 
+def run_x3(B, Cin, Cout, T):
+    from conv_micro import pack_x3
+    x = torch.randn(B, Cin, T, device=dev)
+    w = torch.randn(Cout, Cin, 5, device=dev) / (Cin * 5) ** 0.5
+    b = torch.randn(Cout, device=dev)
+    out = torch.zeros(B, Cout, T, device=dev)
+    wp = pack_x3(w, 0)
+    res = []
+    for dbg, name in ((0, "full"), (1, "noDMA"), (2, "noMFMA/split"), (3, "neither")):
+        lib.avc_set_debug_ablation(dbg, 0)
+        f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wp), P(b), Cout, 5, 1, 1, P(out), out.stride(0), out.stride(1), 1, 1,
+                                       None, 0, 0, 0, 0, 0, None, 97, None)
+        assert f() == 0
+        res.append(f"{name}: {timeit(f):6.1f}us")
+    lib.avc_set_debug_ablation(0, 0)
+    print(f"x3 fwd B={B} {Cin}->{Cout} T={T}: " + " | ".join(res), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "x3":
+    run_x3(256, 128, 128, 128)
+    run_x3(1024, 128, 128, 128)
+    run_x3(256, 128, 128, 64)
+    sys.exit(0)
+
 if __name__ == "__main__":
     B = 256
     run(B, 128, 128, 128, 5, (11,))
