@@ -14,8 +14,9 @@
 //     [chunk][tap][term][k-half][m][8 bf16]: a lane's A fragment of a term is one 16-byte LDS read;
 //   * the source tile stays fp32 [channel][position] (DMA'd as before); a lane reads its 8 channels of a tap, adds the
 //     mirror window of the reflect adjoint where needed, and splits the 8 values in registers (~50 VALU per 6 MFMAs).
-// STATUS: op-level only (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad + avc_pack_weight_x3); whole-model plans do not use
-// it.  Parity is green on hardware (error 0.6-3.6x that of an fp32 convolution against fp64).  Measured against the exact-fp32
+// STATUS: opt-in.  Op level: tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad + avc_pack_weight_x3; whole-model plans created
+// after avc_set_tuning("conv_x3", 1) run their k = 5 layers that fill the chip on it (the default engine multiplies in exact fp32).
+//  Parity is green on hardware (error 0.6-3.6x that of an fp32 convolution against fp64).  Measured against the exact-fp32
 // kernel (profiles/r02_conv_micro_x3.log): forward 53.6 vs 68.5 us at B=256, T=128 (100 vs 78 TFLOP/s), 185 vs 228 us at B=1024
 // (116 vs 94); mirrored dgrad 63.8 vs 69.1 us; layers with <= 256 workgroups of 64x128 (T_l <= 64 at B=256) are slower.  A
 // first version with 32x32 per wave (one split per six MFMAs) was no faster at all; what still separates this one from the probe's
@@ -140,16 +141,20 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         }
         const avc_u32x4* Ab = (const avc_u32x4*)(As + (chunk & 1) * AS);
         const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;
-#pragma unroll
-        for (int tap = 0; tap < KS; ++tap) {
-            if ((a.par && ((tap & 1) != par)) || (a.dbg & 2)) continue;   // (wave-uniform)
-            unsigned hi[8], mid[8], lo[8];
+        // Straight-line taps, software-pipelined by hand: the eight B values of tap j+1 are requested from LDS before the
+        // twelve MFMAs of tap j are issued, so the LDS round trip and the split (~50 VALU) of a tap overlap the matrix
+        // pipe working on the previous one (a tap loop with its parity branches compiled to read -> wait -> split -> MFMA).
+        auto fetch = [&](int tap, float (&x)[8]) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float x = Xb[k * ROW + cb + tap];
-                if (use_mirror) x += Xb[k * ROW + cbm + tap];
-                x3_split(x, hi[k], mid[k], lo[k]);
+                x[k] = Xb[k * ROW + cb + tap];
+                if (use_mirror) x[k] += Xb[k * ROW + cbm + tap];
             }
+        };
+        auto mma = [&](int tap, const float (&x)[8]) {
+            unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x3_split(x[k], hi[k], mid[k], lo[k]);
             avc_u32x4 bt[3];
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -157,19 +162,43 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
                 bt[1][qd] = x3_pair(mid[2 * qd], mid[2 * qd + 1]);
                 bt[2][qd] = x3_pair(lo[2 * qd], lo[2 * qd + 1]);
             }
+            avc_u32x4 at[WM][3];
 #pragma unroll
-            for (int wm = 0; wm < WM; ++wm) {
-                avc_u32x4 at[3];
+            for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int term = 0; term < 3; ++term) at[term] = Ab[((tap * 3 + term) * 2 + h) * BM + wm * 32 + li];
-                // small terms first
-                acc[wm] = avc_mfma_bf16x8(at[2], bt[0], acc[wm]);
-                acc[wm] = avc_mfma_bf16x8(at[0], bt[2], acc[wm]);
-                acc[wm] = avc_mfma_bf16x8(at[1], bt[1], acc[wm]);
-                acc[wm] = avc_mfma_bf16x8(at[1], bt[0], acc[wm]);
-                acc[wm] = avc_mfma_bf16x8(at[0], bt[1], acc[wm]);
-                acc[wm] = avc_mfma_bf16x8(at[0], bt[0], acc[wm]);
-            }
+                for (int term = 0; term < 3; ++term) at[wm][term] = Ab[((tap * 3 + term) * 2 + h) * BM + wm * 32 + li];
+            // small terms first; the WM accumulators alternate so that consecutive MFMAs are independent
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][2], bt[0], acc[wm]);
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][0], bt[2], acc[wm]);
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][1], bt[1], acc[wm]);
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][1], bt[0], acc[wm]);
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][0], bt[1], acc[wm]);
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][0], bt[0], acc[wm]);
+        };
+        float xa[8], xb[8];
+        if (a.dbg & 2) {
+        } else if (!a.par) {
+            fetch(0, xa);
+            fetch(1, xb); mma(0, xa);
+            fetch(2, xa); mma(1, xb);
+            fetch(3, xb); mma(2, xa);
+            fetch(4, xa); mma(3, xb);
+            mma(4, xa);
+        } else if (par == 0) {   // even columns of a stride-2 dgrad: taps 0, 2, 4
+            fetch(0, xa);
+            fetch(2, xb); mma(0, xa);
+            fetch(4, xa); mma(2, xb);
+            mma(4, xa);
+        } else {                 // odd columns: taps 1, 3
+            fetch(1, xa);
+            fetch(3, xb); mma(1, xa);
+            mma(3, xb);
         }
         __syncthreads();
     }
@@ -180,12 +209,23 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
 }
 
 // --------------------------------------------------------------------------
+static int g_conv_x3 = 0;   // avc_set_tuning("conv_x3", 1): plans created while it is 1 run their big k = 5 layers on this kernel
+void avc_set_conv_x3(int on) { g_conv_x3 = on; }   // 2: every layer of an eligible shape, whatever its size (tests)
+
 static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
     if (KS != X3_KS || Cred < X3_CK || Cred % X3_CK != 0) return false;
     if (stride != 1 && stride != 2) return false;
     if (mode == 1 && Tout < 10) return false;   // one mirror window per column
     const ConvGeom q = conv_geom(mode, stride, Tout, KS, 128, 0);
     return q.ROW <= 64 * AVC_CONV_NJ;
+}
+// a plan layer takes this kernel when the launch fills the chip with 64 x 128 tiles (measured: 256 workgroups still win,
+// 128 lose to the exact-fp32 kernel, profiles/r02_conv_micro_x3.log)
+bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int B, int M) {
+    if (!g_conv_x3 || !x3_shape_ok(mode, Cred, KS, stride, Tout)) return false;
+    const long ntn = Tout >= 128 ? (long)B * avc_cdiv(Tout, 128) : avc_cdiv(B, 128 / Tout);
+    // (the input-gradient launches carry the mask / residual-join epilogue: in the engine they win only from 512 workgroups on)
+    return g_conv_x3 >= 2 || ntn * (avc_cdiv(M, 128) * 2) >= (mode == 1 ? 512 : 256);
 }
 long avc_conv_x3_image_floats(int M, int Cred) { return (long)(Cred / X3_CK) * X3_AROWS * (avc_cdiv(M, 128) * 128) * 4; }
 
@@ -204,7 +244,7 @@ void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, in
 int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
     a.dbg = avc_conv_ablation_bits();
-    if (a.ngroups != 1 || a.in_fuse || a.bf16 != AVC_COMPUTE_F32) return -1;
+    if (a.ngroups != 1 || a.in_fuse) return -1;
     const ConvGroup& g = a.g[0];
     if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != X3_CK || g.nchunk * X3_CK != a.Cred || a.Mp % 128 != 0) return -2;
     if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;

@@ -57,6 +57,7 @@ struct LayerP {
     bool need_dgrad = true;
     // register-stationary kernel (conv_rs.hip) for this layer's forward / input-gradient launch, and its images
     bool rs_f = false, rs_d = false;
+    bool x3_f = false, x3_d = false;   // split-bf16 kernel (conv_x3.hip): image at wrs_f / wrs_d, 16-channel chunks
     long wrs_f = -1, wrs_d = -1;
 };
 
@@ -177,8 +178,14 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
     L.rs_f = ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(0, L.Cin, L.KS, L.stride, Tf, 1);
     L.rs_d = need_dgrad && ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(1, L.Cout, L.KS, L.stride, Td, rs_ps);
+    L.x3_f = !L.rs_f && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
+    L.x3_d = !L.rs_d && need_dgrad && ngroups == 1 && L.nsrc == 1 && L.dgM == L.Cin && avc_conv_x3_eligible(1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
+    if (L.x3_f) { L.CK = 16; L.nchunk_f = L.Cin / 16; }
+    if (L.x3_d) { L.CKd = 16; L.nchunk_d = L.Cout / 16; }
     if (L.rs_f) L.wrs_f = p->alloc(avc_conv_rs_image_floats(L.Cout, L.Cin, L.KS));
     if (L.rs_d) L.wrs_d = p->alloc(avc_conv_rs_image_floats(L.dgM, L.Cout, L.KS));
+    if (L.x3_f) L.wrs_f = p->alloc(avc_conv_x3_image_floats(L.Cout, L.Cin));
+    if (L.x3_d) L.wrs_d = p->alloc(avc_conv_x3_image_floats(L.dgM, L.Cout));
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
     if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CKd * L.Mp_d);
     if (L.nsrc > 1) L.bpk = p->alloc((long)32 * L.Mp_f);
@@ -658,8 +665,8 @@ static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, 
     a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
     a.M = L.Cout; a.Mp = L.Mp_f;
     a.ngroups = 1;
-    set_group(a.g[0], ws + (L.rs_f ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
-    a.rs = L.rs_f ? 1 : 0;
+    set_group(a.g[0], ws + ((L.rs_f || L.x3_f) ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+    a.rs = L.x3_f ? 2 : (L.rs_f ? 1 : 0);
     a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.act = act;
@@ -678,8 +685,8 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
     a.ngroups = 1;
-    set_group(a.g[0], ws + (L.rs_d ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
-    a.rs = L.rs_d ? 1 : 0;
+    set_group(a.g[0], ws + ((L.rs_d || L.x3_d) ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
+    a.rs = L.x3_d ? 2 : (L.rs_d ? 1 : 0);
     a.g[0].out = dx;
     return a;
 }
@@ -824,14 +831,22 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
     a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
     a.dst = ws + L.wpf;
-    if (L.rs_f) {   // only the image the launch will read
+    if (L.x3_f) {   // only the image the launch will read
+        PackArgs r;
+        avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
+        out.push_back(r);
+    } else if (L.rs_f) {
         PackArgs r;
         avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
         out.push_back(r);
     } else {
         out.push_back(a);
     }
-    if (L.need_dgrad && L.rs_d) {
+    if (L.need_dgrad && L.x3_d) {
+        PackArgs r;
+        avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d);
+        out.push_back(r);
+    } else if (L.need_dgrad && L.rs_d) {
         PackArgs r;
         avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d);
         out.push_back(r);

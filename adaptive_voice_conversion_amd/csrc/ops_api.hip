@@ -60,6 +60,7 @@ int avc_set_tuning(const char* name, int value) {
     else if (!strcmp(name, "bank_switch")) avc_set_bank_switch(value);             // 0: generic chunk loop for the grouped bank launch
     else if (!strcmp(name, "dgrad_par")) avc_set_dgrad_par(value);                 // 0: stride-2 dgrad on all five taps of the zero-upsampled dy
     else if (!strcmp(name, "conv_small")) avc_set_conv_small(value);               // 0: short rows (T = 16 / 32) on the chunk-pipelined kernel
+    else if (!strcmp(name, "conv_x3")) avc_set_conv_x3(value);                     // 1: split-bf16 conv kernel for the big k = 5 layers of new plans
     else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
     else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
     else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);

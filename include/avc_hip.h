@@ -170,7 +170,8 @@ int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long
 
 /* tuning knobs of the micro-benchmark scripts: "conv_ck5" (8|16|32: chunk depth of k >= 4 convs at the op
  * level), "wgrad_target_wgs" (split-K workgroups per weight-gradient launch, default 256), "in_variant"
- * (InstanceNorm kernel variant), "conv_rs" (0 = never the register-stationary conv kernel), "conv_small" (one-shot kernel
+ * (InstanceNorm kernel variant), "conv_rs" (0 = never the register-stationary conv kernel), "conv_x3" (1 = split-bf16 conv
+ * kernel for the big k = 5 layers of new plans, 2 = for every eligible layer; csrc/conv_x3.hip), "conv_small" (one-shot kernel
  * of the T_l = 16 / 32 layers, csrc/conv_small.hip, tile code 98 at the op level: -1 = launches of <= 64 samples (default),
  * 0 = never, bit 0 = forward, bit 1 = dgrad), "dgrad_par" (0 = stride-2 dgrad multiplies all taps of the zero-upsampled dy),
  * "wgrad_batch" / "wgrad_batch_wgs" (layers per batched weight-gradient launch / workgroups it aims for; captured by plans
@@ -233,7 +234,8 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
 long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad);
 /* weight image of the split-bf16 conv kernel (csrc/conv_x3.hip; k = 5, reduction channels a multiple of 16: every operand as
  * three bf16 terms, six bf16 MFMAs per product block, fp32-level accuracy): pass it as `wp` / `wpd` together with tile = 97.
- * Op-level only: whole-model plans multiply in exact fp32 (measured no faster in this form, see the file header). */
+ * Whole-model plans created after avc_set_tuning("conv_x3", 1) use it for their k = 5 layers that fill the chip (opt-in; the
+ * default engine multiplies in exact fp32). */
 long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad);
 int avc_pack_weight_x3(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
 int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);

@@ -83,7 +83,10 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
     ("emu", "tiny128", 3, 40, False),   # 128 hidden channels + avc_set_tuning("conv_rs", 1): the register-stationary conv kernel in the plan
+    ("emu", "tiny128x3", 3, 40, False), # ... + avc_set_tuning("conv_x3", 2): the split-bf16 conv kernel in every eligible layer of the plan
     pytest.param("gpu", "m80rs", 8, 128, False, marks=GPU),   # the same opt-in kernel on the stock config
+    pytest.param("gpu", "m80x3", 8, 128, False, marks=GPU),   # split-bf16 kernel, every eligible layer
+    pytest.param("gpu", "m80x3", 3, 40, False, marks=GPU),    # ... odd lengths
     pytest.param("gpu", "tiny", 3, 24, True, marks=GPU),
     pytest.param("gpu", "m80", 4, 128, True, marks=GPU),
     pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
@@ -94,7 +97,7 @@ CASES = [
 
 
 def get_cfg(name):
-    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80rs": lambda: O.stock_config(80), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80rs": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -107,13 +110,19 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     if transposed:
         xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
     rs = cfgname in ("tiny128", "m80rs")   # opt-in register-stationary conv kernel: captured by plans created while the knob is on
+    x3 = cfgname.endswith("x3")            # opt-in split-bf16 conv kernel (2 = every layer of an eligible shape, whatever its size)
     if rs:
         assert lib.avc_set_tuning(b"conv_rs", 1) == 0
+    if x3:
+        assert lib.avc_set_tuning(b"conv_x3", 2) == 0
     try:
         plan = Plan(cfg, B, T, lib=lib)
     finally:
         lib.avc_set_tuning(b"conv_rs", 0)
+        lib.avc_set_tuning(b"conv_x3", 0)
     assert plan.num_params == len(sd)
+    if rs or x3:   # the opt-in kernels bring their own weight images: the plan really switched
+        assert plan.workspace_floats > Plan(cfg, B, T, lib=lib).workspace_floats
     params = flat_params(plan, sd, dev)
     ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
     plan.forward(params, xd, None, eps.to(dev), ws)
