@@ -16,6 +16,8 @@ typedef short avc_s16x4 __attribute__((ext_vector_type(4)));
 enum {
     AVC_COMPUTE_F32 = 0,   // v_mfma_f32_32x32x2_f32: bit-exact fp32 (reference precision)
     AVC_COMPUTE_BF16 = 1,  // operands rounded to bf16 (RNE) at fragment time, fp32 accumulate: v_mfma_f32_32x32x8_bf16
+    AVC_COMPUTE_F32X3 = 2, // (weight-gradient launches) every operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product
+                           // block: fp32-level accuracy (conv_x3_shared.h); instances it is not built for run AVC_COMPUTE_F32
 };
 
 // ---- residual / gradient-join modes used by conv epilogues and row kernels

@@ -32,6 +32,8 @@ void avc_set_conv_rs(int on);
 bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int B, int M);
 long avc_conv_x3_image_floats(int M, int Cred);
 void avc_set_conv_x3(int on);
+void avc_set_wgrad_x3(int on);
+int avc_wgrad_x3();
 void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst);
 int avc_launch_conv_x3(const ConvArgs& a, hipStream_t stream);
 // one-shot short-row conv (conv_small.hip): same packed images as conv_gemm.hip

@@ -15,6 +15,7 @@
 
 #include "avc_common.h"
 #include "avc_internal.h"
+#include "conv_x3_shared.h"
 
 #define WG_DYROW 33
 #define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue)
@@ -34,7 +35,13 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // k-loop is matrix-pipe idle time (measured: 62 % MFMA duty even with DMA and barriers removed).
 // So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
 // issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
-template <int KS, int NB, int WCO, bool LIN, bool BF>
+//
+// X3 (LIN layers -- whole 32-column chunks of a stride-1 conv -- with up to 6 accumulators; opt-in, avc_set_tuning("wgrad_x3", 1)): the consumers form the products from three bf16 terms per
+// operand on v_mfma_f32_32x32x16_bf16 (conv_x3_shared.h: fp32-level accuracy in 2.7x fewer matrix-pipe cycles).  Both operands are
+// activations here, so both are split in registers: per 16 columns a lane reads its 8 dy values and the 12 x values that its
+// KS shifted windows cover, splits each ONCE, and assembles the KS B fragments by pairing registers (v_perm) -- 20 splits and
+// 30 MFMAs per block where the fp32 path issues 40 MFMAs of twice the length.  Producers, tiles, slabs: unchanged.
+template <int KS, int NB, int WCO, bool LIN, bool BF, bool X3 = false>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
     // which layer of the batch this workgroup works for (wave-uniform scan of <= 16 entries)
     int layer = 0;
@@ -288,7 +295,61 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
 #pragma unroll
                         for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
                 };
-                if constexpr (BF) {
+                if constexpr (X3 && LIN && !BF) {
+                    // two blocks of 16 columns: lane-half h owns columns 16 kb + 8 h .. + 7 of the chunk
+                    constexpr int NX = 8 + KS - 1;   // x values under the KS shifted windows of 8 columns
+                    auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {
+                        const float* ap = arow + 16 * kb + 8 * h;
+                        const float* bp = brow + 16 * kb + 8 * h;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) av[i] = ap[i];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) xv[nb][i] = bp[nb * 32 * XROW + i];
+                    };
+                    auto block = [&](const float (&av)[8], const float (&xv)[NB][NX]) {
+                        unsigned ah[8], am[8], al[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x3_split(av[i], ah[i], am[i], al[i]);
+                        avc_u32x4 at[3];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            at[0][q4] = x3_pair(ah[2 * q4], ah[2 * q4 + 1]);
+                            at[1][q4] = x3_pair(am[2 * q4], am[2 * q4 + 1]);
+                            at[2][q4] = x3_pair(al[2 * q4], al[2 * q4 + 1]);
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            unsigned xh[NX], xm[NX], xl[NX];
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) x3_split(xv[nb][i], xh[i], xm[i], xl[i]);
+#pragma unroll
+                            for (int j = 0; j < KS; ++j) {
+                                avc_u32x4 b0, b1, b2;
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    b0[q4] = x3_pair(xh[j + 2 * q4], xh[j + 2 * q4 + 1]);
+                                    b1[q4] = x3_pair(xm[j + 2 * q4], xm[j + 2 * q4 + 1]);
+                                    b2[q4] = x3_pair(xl[j + 2 * q4], xl[j + 2 * q4 + 1]);
+                                }
+                                f32x16& c = acc[nb * KS + j];
+                                // small terms first
+                                c = avc_mfma_bf16x8(at[2], b0, c);
+                                c = avc_mfma_bf16x8(at[0], b2, c);
+                                c = avc_mfma_bf16x8(at[1], b1, c);
+                                c = avc_mfma_bf16x8(at[1], b0, c);
+                                c = avc_mfma_bf16x8(at[0], b1, c);
+                                c = avc_mfma_bf16x8(at[0], b0, c);
+                            }
+                        }
+                    };
+                    float a0[8], x0[NB][NX], a1[8], x1[NB][NX];
+                    fetch(0, a0, x0);
+                    fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
+                    block(a0, x0);
+                    block(a1, x1);
+                } else if constexpr (BF) {
                     // four k-steps (8 columns) per v_mfma_f32_32x32x8_bf16: slot j of lane-half h carries
                     // column 2(4g + j) + h of the chunk in both operands; operands are rounded to bf16 here
                     float av4[2][4], bv4[2][4][NACC];
@@ -478,23 +539,31 @@ void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* sp
     *chunks_per_wg = a.chunks_per_wg; *nsplit = a.nsplit;
 }
 
+
 template <int KS, int NB, int WCO>
-static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, bool bf, size_t lds, double flops, hipStream_t stream) {
+static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, bool bf, bool x3, size_t lds, double flops, hipStream_t stream) {
     if (lds > 158 * 1024) return -3;
     dim3 grid(total_wgs);
     ProfScope ps(AVC_K_CONV_WGRAD, flops, 0.0, stream);
     if (bf) {
         if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, bt);
         else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
-    } else if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, bt);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else if (lin) {
+        if constexpr (KS * NB <= 6) {   // (k = 7, 8: 112-128 accumulator registers + the split terms do not fit without spills)
+            if (x3) {
+                hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+                return (int)hipGetLastError();
+            }
+        }
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, bt);
     return (int)hipGetLastError();
 }
 
 template <int KS>
-static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, bool bf, size_t lds, double flops, hipStream_t stream) {
-    return k.WCO == 4 ? launch_wgrad_t<KS, 1, 4>(bt, total_wgs, k.lin, bf, lds, flops, stream)
-                      : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, lds, flops, stream);
+static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, bool bf, bool x3, size_t lds, double flops, hipStream_t stream) {
+    return k.WCO == 4 ? launch_wgrad_t<KS, 1, 4>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream)
+                      : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream);
 }
 
 // ablation bits of scripts/wgrad_ablate.py (timing experiments; results are wrong by construction when set)
@@ -528,18 +597,18 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream) {
             flops += 2.0 * d.Cout * d.Cin * d.KS * (double)d.B * d.Tout;
             done[j] = 1;
         }
-        const bool bf = a0.bf16 == AVC_COMPUTE_BF16;
+        const bool bf = a0.bf16 == AVC_COMPUTE_BF16, x3 = a0.bf16 == AVC_COMPUTE_F32X3;
         int rc;
-        if (k.KS == 1 && k.NB == 4) rc = launch_wgrad_t<1, 4, 4>(bt, wgs, k.lin, bf, lds, flops, stream);
+        if (k.KS == 1 && k.NB == 4) rc = launch_wgrad_t<1, 4, 4>(bt, wgs, k.lin, bf, x3, lds, flops, stream);
         else switch (k.KS) {
-            case 1: rc = launch_wgrad_ks<1>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 2: rc = launch_wgrad_ks<2>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 3: rc = launch_wgrad_ks<3>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 4: rc = launch_wgrad_ks<4>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 5: rc = launch_wgrad_ks<5>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 6: rc = launch_wgrad_ks<6>(bt, wgs, k, bf, lds, flops, stream); break;
-            case 7: rc = launch_wgrad_ks<7>(bt, wgs, k, bf, lds, flops, stream); break;
-            default: rc = launch_wgrad_ks<8>(bt, wgs, k, bf, lds, flops, stream); break;
+            case 1: rc = launch_wgrad_ks<1>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 2: rc = launch_wgrad_ks<2>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 3: rc = launch_wgrad_ks<3>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 4: rc = launch_wgrad_ks<4>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 5: rc = launch_wgrad_ks<5>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 6: rc = launch_wgrad_ks<6>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            case 7: rc = launch_wgrad_ks<7>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+            default: rc = launch_wgrad_ks<8>(bt, wgs, k, bf, x3, lds, flops, stream); break;
         }
         if (rc) return rc;
         // (layers of this key beyond AVC_WGRAD_MAXL stay !done and open their own launch when the outer loop reaches them)

@@ -122,6 +122,7 @@ struct avc_plan {
     int flags = 0;            // AVC_PLAN_*
     int wgrad_batch = 12;      // weight gradients per batched launch (captured at plan creation: the dry run sizes slabs and events with it)
     int wgrad_target = 256;   // workgroups a batched weight-gradient launch aims for
+    int wgrad_x3 = 0;         // split-bf16 products in the weight-gradient launches (avc_set_tuning("wgrad_x3", 1) at plan creation)
     long wgrad_units = 1L << 40;  // pending (tile x K-chunk) units that trigger a launch before wgrad_batch layers are pending
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
@@ -232,6 +233,9 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
 }
 
 static int g_wgrad_batch = 12, g_wgrad_batch_target = 256;
+static int g_wgrad_x3 = 0;
+void avc_set_wgrad_x3(int on) { g_wgrad_x3 = on ? 1 : 0; }
+int avc_wgrad_x3() { return g_wgrad_x3; }
 static long g_wgrad_units = 1L << 40;
 void avc_set_wgrad_units(long u) { g_wgrad_units = u > 0 ? u : (1L << 40); }  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
 void avc_set_wgrad_batch(int layers, int target_wgs) {
@@ -264,6 +268,7 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
     p->flags = flags;
     p->wgrad_batch = g_wgrad_batch;
     p->wgrad_target = g_wgrad_batch_target;
+    p->wgrad_x3 = g_wgrad_x3;
     p->wgrad_units = g_wgrad_units;
     p->B = B;
     p->T = T;
@@ -813,7 +818,8 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.x.ptr = x; a.x.sb = xsb; a.x.sc = xsc; a.x.st = xst; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = ysb; a.dy.sc = ysc; a.dy.st = yst; a.dy.ps = yps;
     a.B = Bn; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Tin; a.Tout = Tout;
-    a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride; a.bf16 = L.bf16;
+    a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
+    a.bf16 = (L.bf16 == AVC_COMPUTE_F32 && c.p->wgrad_x3) ? AVC_COMPUTE_F32X3 : L.bf16;
     pw.L = &L;
     avc_wgrad_geometry(a);
     c.pend_units += (long)a.tiles * a.total_chunks;

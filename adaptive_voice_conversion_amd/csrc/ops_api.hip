@@ -60,6 +60,7 @@ int avc_set_tuning(const char* name, int value) {
     else if (!strcmp(name, "bank_switch")) avc_set_bank_switch(value);             // 0: generic chunk loop for the grouped bank launch
     else if (!strcmp(name, "dgrad_par")) avc_set_dgrad_par(value);                 // 0: stride-2 dgrad on all five taps of the zero-upsampled dy
     else if (!strcmp(name, "conv_small")) avc_set_conv_small(value);               // 0: short rows (T = 16 / 32) on the chunk-pipelined kernel
+    else if (!strcmp(name, "wgrad_x3")) avc_set_wgrad_x3(value);                   // 1: split-bf16 products in the whole-chunk weight-gradient launches (new plans, op level)
     else if (!strcmp(name, "conv_x3")) avc_set_conv_x3(value);                     // 1: split-bf16 conv kernel for the big k = 5 layers of new plans
     else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
     else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
@@ -163,7 +164,7 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
                      void* stream) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = g_op_compute;
+    a.bf16 = (g_op_compute == AVC_COMPUTE_F32 && avc_wgrad_x3()) ? AVC_COMPUTE_F32X3 : g_op_compute;
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;

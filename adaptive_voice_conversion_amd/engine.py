@@ -63,11 +63,13 @@ class Plan:
     """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
     tests may inject the CPU lane-level simulation build instead."""
 
-    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1}
+    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp32x3": 0, "f32x3": 0}
 
     def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None):
         """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
-        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3).
+        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3); "fp32x3" = fp32-accurate
+        products from three bf16 terms per operand on the bf16 matrix core for the big k = 5 convs and the whole-chunk weight
+        gradients (opt-in; csrc/conv_x3.hip), exact fp32 everywhere else.
         mode: "train" (forward + loss + backward), "inference" (forward only: the workspace holds no gradient,
         slab or dy buffers) or "speaker" (only the speaker encoder runs, AE.get_speaker_embeddings).
         device: the plan's helper streams are created on it (default: the current device)."""
@@ -78,15 +80,24 @@ class Plan:
         flags = {"train": 0, "inference": _lib.PLAN_INFERENCE, "speaker": _lib.PLAN_INFERENCE | _lib.PLAN_SPEAKER_ONLY}[mode]
         h = ctypes.c_void_p()
         dev = torch.device(device) if device is not None else None
-        with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
-            rc = self.lib.avc_plan_create_ex(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(h))
-        if rc != 0:
-            raise RuntimeError(self.lib.avc_last_error().decode())
-        self.h = h
         key = str(compute_dtype).lower()
         if key not in self.COMPUTE:
             raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE)}, got {compute_dtype!r}")
-        self.compute_dtype = "bf16" if self.COMPUTE[key] else "fp32"
+        x3 = key in ("fp32x3", "f32x3")
+        if x3:   # captured by the plan at creation (process-wide knobs: one host call at a time, include/avc_hip.h)
+            self.lib.avc_set_tuning(b"conv_x3", 1)
+            self.lib.avc_set_tuning(b"wgrad_x3", 1)
+        try:
+            with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
+                rc = self.lib.avc_plan_create_ex(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(h))
+        finally:
+            if x3:
+                self.lib.avc_set_tuning(b"conv_x3", 0)
+                self.lib.avc_set_tuning(b"wgrad_x3", 0)
+        if rc != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
+        self.h = h
+        self.compute_dtype = "fp32x3" if x3 else ("bf16" if self.COMPUTE[key] else "fp32")
         if self.lib.avc_plan_set_compute_dtype(h, self.COMPUTE[key]) != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.num_params = self.lib.avc_plan_num_params(h)

@@ -316,7 +316,9 @@ def dsp_bench(a, dev):
 
 def workload_label(a, world):
     """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
-    prec = "fp32" if a.dtype == "f32" else "bf16 matrix products (fp32 accumulate, fp32 master weights and optimizer state)"
+    prec = {"f32": "fp32", "bf16": "bf16 matrix products (fp32 accumulate, fp32 master weights and optimizer state)",
+            "f32x3": "fp32 storage and results; the big conv / weight-gradient products from three bf16 terms per operand on the bf16 matrix core "
+                     "(fp32-level accuracy, opt-in; DESIGN 3.5) -- NOT the headline precision path"}[a.dtype]
     if a.mode == "infer":
         idx = 3 if (a.mels == 80 and a.frames == 128 and a.batch == 1024) else None
         what = f"AE.inference one-shot conversion, {a.mels}-mel x {a.frames}-frame source and target, batch {a.batch}/GPU, {prec}"
@@ -324,7 +326,7 @@ def workload_label(a, world):
     else:
         idx = None
         if a.mels == 80 and a.frames == 128 and a.batch == 256:
-            idx = 1 if a.dtype == "f32" else 2
+            idx = {"f32": 1, "bf16": 2}.get(a.dtype)
         elif a.mels == 80 and a.frames == 1024 and a.batch == 64 and a.dtype == "f32":
             idx = 4
         what = (f"recon+KL train step (fwd, loss, bwd, {'RCCL all-reduce, ' if world > 1 else ''}clip, Adam-amsgrad), "
@@ -364,7 +366,7 @@ def main():
                     help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion; "
                          "dsp = the mel <-> waveform back end of a conversion (SURVEY §8f row 4; not a BASELINE.json config)")
     ap.add_argument("--seconds", type=float, default=5.0, help="--mode dsp: length of the synthetic utterance")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32",
                     help="f32 = the headline (BASELINE configs[1]); bf16 = configs[2]'s compute mode (bf16 matrix products, "
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -415,6 +417,8 @@ def main():
     cfg = stock_config(a.mels)
     if a.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
+    if a.dtype == "f32x3":   # opt-in: fp32-accurate products from three bf16 terms on the bf16 matrix core
+        cfg["compute_dtype"] = "fp32x3"
     torch.manual_seed(0)
     args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log")
     solver = Solver(cfg, args)
@@ -517,7 +521,8 @@ def main():
             prof = profile_classes(solver, x, eps, steps=3)
             dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
             d = prof[dom]
-            peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            # f32x3: six 8-pass bf16 MFMAs per 16 reduction steps -> the matrix pipe's ceiling for these products is the bf16 peak / 6
+            peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
             traffic, tsrc = pmc_class_traffic(dom) if (cfg_idx == 1) else (None, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
                                "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,

@@ -171,7 +171,8 @@ int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long
 /* tuning knobs of the micro-benchmark scripts: "conv_ck5" (8|16|32: chunk depth of k >= 4 convs at the op
  * level), "wgrad_target_wgs" (split-K workgroups per weight-gradient launch, default 256), "in_variant"
  * (InstanceNorm kernel variant), "conv_rs" (0 = never the register-stationary conv kernel), "conv_x3" (1 = split-bf16 conv
- * kernel for the big k = 5 layers of new plans, 2 = for every eligible layer; csrc/conv_x3.hip), "conv_small" (one-shot kernel
+ * kernel for the big k = 5 layers of new plans, 2 = for every eligible layer; csrc/conv_x3.hip), "wgrad_x3" (1 = split-bf16
+ * products in the whole-chunk weight-gradient launches of new plans and of avc_conv1d_wgrad), "conv_small" (one-shot kernel
  * of the T_l = 16 / 32 layers, csrc/conv_small.hip, tile code 98 at the op level: -1 = launches of <= 64 samples (default),
  * 0 = never, bit 0 = forward, bit 1 = dgrad), "dgrad_par" (0 = stride-2 dgrad multiplies all taps of the zero-upsampled dy),
  * "wgrad_batch" / "wgrad_batch_wgs" (layers per batched weight-gradient launch / workgroups it aims for; captured by plans

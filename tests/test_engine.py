@@ -110,16 +110,17 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     if transposed:
         xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
     rs = cfgname in ("tiny128", "m80rs")   # opt-in register-stationary conv kernel: captured by plans created while the knob is on
-    x3 = cfgname.endswith("x3")            # opt-in split-bf16 conv kernel (2 = every layer of an eligible shape, whatever its size)
+    x3 = cfgname.endswith("x3")            # opt-in split-bf16 products: conv kernel (2 = every layer of an eligible shape, whatever its size) + weight gradients
     if rs:
         assert lib.avc_set_tuning(b"conv_rs", 1) == 0
     if x3:
-        assert lib.avc_set_tuning(b"conv_x3", 2) == 0
+        assert lib.avc_set_tuning(b"conv_x3", 2) == 0 and lib.avc_set_tuning(b"wgrad_x3", 1) == 0
     try:
         plan = Plan(cfg, B, T, lib=lib)
     finally:
         lib.avc_set_tuning(b"conv_rs", 0)
         lib.avc_set_tuning(b"conv_x3", 0)
+        lib.avc_set_tuning(b"wgrad_x3", 0)
     assert plan.num_params == len(sd)
     if rs or x3:   # the opt-in kernels bring their own weight images: the plan really switched
         assert plan.workspace_floats > Plan(cfg, B, T, lib=lib).workspace_floats

@@ -27,12 +27,15 @@ from tests.test_engine import flat_params, get_cfg
 GPU = pytest.mark.gpu
 
 
+_COMPUTE = ["fp32"]   # (test_fp32x3_mode_... reruns the headline-shape test with the opt-in split-bf16 products)
+
+
 def _fwd_bwd(kind, cfgname, B, T, seed=0):
     lib, dev = backend(kind)
     cfg = get_cfg(cfgname)
     sd = O.make_state_dict(cfg, seed)
     x, eps = O.make_inputs(cfg, B, T, seed)
-    plan = Plan(cfg, B, T, lib=lib)
+    plan = Plan(cfg, B, T, lib=lib, compute_dtype=_COMPUTE[0])
     params = flat_params(plan, sd, dev)
     ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
     xd, ed = x.to(dev), eps.to(dev)
@@ -103,6 +106,18 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
     print(f"[{kind}/{cfgname} B={B} T={T}] {label}: per-tensor gradient rel-L2 vs the fp64 oracle on the engine's ReLU branch: "
           f"engine worst {worst_e:.2e} / median {errs[len(errs) // 2]:.2e}; fp32 oracle worst {worst_r:.2e}; worst engine/oracle ratio {worst_ratio:.2f}")
     assert errs[len(errs) // 2] < 1e-4
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU), pytest.param("gpu", "m80", 4, 1024, marks=GPU)])
+def test_fp32x3_mode_meets_the_same_bars(kind, cfgname, B, T):
+    """compute_dtype "fp32x3" (opt-in: the big conv and weight-gradient products from three bf16 terms per operand on the bf16
+    matrix core): the SAME forward / loss / gradient bars as the exact-fp32 engine at the graded shapes -- per tensor at
+    least as close to the fp64 oracle as twice the fp32 oracle's own distance."""
+    _COMPUTE[0] = "fp32x3"
+    try:
+        test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, f"fp32x3 mode at B={B}, T={T}")
+    finally:
+        _COMPUTE[0] = "fp32"
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 32, 128, marks=GPU)])

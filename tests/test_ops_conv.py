@@ -273,6 +273,45 @@ def test_conv_wgrad_many_short_samples_per_chunk(kind, B, Cin, Cout, T, KS, stri
     test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride)
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS", [(2, 16, 32, 32, 5), (3, 64, 64, 64, 5), (2, 80, 32, 96, 5), (1, 16, 130, 200, 3), (2, 130, 40, 40, 1),
+                                             (2, 80, 32, 33, 4), (2, 16, 32, 70, 6), (2, 16, 32, 64, 2),
+                                             pytest.param(64, 128, 128, 128, 5, marks=GPU), pytest.param(256, 128, 128, 32, 5, marks=GPU),
+                                             pytest.param(16, 1104, 128, 128, 1, marks=GPU), pytest.param(32, 80, 128, 128, 6, marks=GPU)])
+def test_conv_wgrad_x3_split_bf16_products(kind, B, Cin, Cout, T, KS):
+    """avc_set_tuning("wgrad_x3", 1): the whole-chunk k = 5 weight-gradient launches form their products from three bf16 terms
+    per operand (both operands are activations: both are split in registers).  Same bar as the exact-fp32 kernel, plus the
+    distance from an fp64 reference next to the fp32 autograd result's own."""
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    assert lib.avc_set_tuning(b"wgrad_x3", 1) == 0
+    try:
+        test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, 1)
+        g = torch.Generator().manual_seed(B + T)
+        x = torch.randn(B, Cin, T, generator=g)
+        w = (torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5)
+        w64 = w.double().requires_grad_(True)
+        y64 = O.pad_conv(x.double(), w64, None, 1)
+        dy = torch.randn(y64.shape, generator=g)
+        (dw64,) = torch.autograd.grad(y64, [w64], dy.double())
+        w32 = w.clone().requires_grad_(True)
+        (dw32,) = torch.autograd.grad(O.pad_conv(x, w32, None, 1), [w32], dy)
+        To = y64.shape[2]
+        ws = torch.zeros(lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, To, KS), device=dev)
+        dW = torch.zeros(Cout, Cin, KS, device=dev)
+        db = torch.zeros(Cout, device=dev)
+        xd, dyd = x.to(dev), dy.to(dev)
+        assert lib.avc_conv1d_wgrad(P(xd), xd.stride(0), xd.stride(1), 1, P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cin, Cout, T, To, KS, 1,
+                                    P(dW), P(db), P(ws), None) == 0
+        e_x3 = (dW.cpu().double() - dw64).abs().max().item()
+        e_32 = (dw32.double() - dw64).abs().max().item()
+        print(f"[{kind} wgrad x3 B={B} {Cin}->{Cout} T={T} k={KS}] max |err| vs fp64: split-bf16 {e_x3:.2e}, fp32 autograd {e_32:.2e}")
+        assert e_x3 <= (4.0 if kind == "gpu" else 12.0) * e_32 + 1e-6 * dw64.abs().max().item()
+    finally:
+        lib.avc_set_tuning(b"wgrad_x3", 0)
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
