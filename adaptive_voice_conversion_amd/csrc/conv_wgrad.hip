@@ -36,7 +36,7 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
 // issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
 //
-// X3 (LIN layers -- whole 32-column chunks of a stride-1 conv -- with up to 6 accumulators; opt-in, avc_set_tuning("wgrad_x3", 1)): the consumers form the products from three bf16 terms per
+// X3 (LIN layers -- whole 32-column chunks of a stride-1 conv, k = 1..8; opt-in, avc_set_tuning("wgrad_x3", 1)): the consumers form the products from three bf16 terms per
 // operand on v_mfma_f32_32x32x16_bf16 (conv_x3_shared.h: fp32-level accuracy in 2.7x fewer matrix-pipe cycles).  Both operands are
 // activations here, so both are split in registers: per 16 columns a lane reads its 8 dy values and the 12 x values that its
 // KS shifted windows cover, splits each ONCE, and assembles the KS B fragments by pairing registers (v_perm) -- 20 splits and
@@ -549,7 +549,7 @@ static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, bool bf
         if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, bt);
         else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
     } else if (lin) {
-        if constexpr (KS * NB <= 6) {   // (k = 7, 8: 112-128 accumulator registers + the split terms do not fit without spills)
+        if constexpr (KS * NB <= 8) {
             if (x3) {
                 hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
                 return (int)hipGetLastError();

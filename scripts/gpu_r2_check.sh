@@ -32,8 +32,9 @@ for what in "$@"; do
       timeout 600 python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > $OUT/train_bf16_b256.json 2>$OUT/train_bf16.err; cut -c1-300 $OUT/train_bf16_b256.json
       timeout 600 python bench.py --feed --steps 20 --warmup 5 --no-cpu-baseline --no-profile > $OUT/train_feed_b256.json 2>$OUT/train_feed.err; cut -c1-300 $OUT/train_feed_b256.json
       timeout 600 python bench.py --batch 4 --steps 50 --warmup 10 --no-cpu-baseline --no-profile > $OUT/train_b4.json 2>$OUT/train_b4.err; cut -c1-300 $OUT/train_b4.json
-      timeout 600 python bench.py --tune conv_x3=1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/train_x3_b256.json 2>$OUT/train_x3.err; cut -c1-300 $OUT/train_x3_b256.json
-      timeout 600 python bench.py --tune conv_x3=1 --mode infer --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/infer_x3_b1024.json 2>$OUT/infer_x3.err; cut -c1-300 $OUT/infer_x3_b1024.json
+      timeout 600 python bench.py --dtype f32x3 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/train_f32x3_b256.json 2>$OUT/train_f32x3.err; cut -c1-300 $OUT/train_f32x3_b256.json
+      timeout 600 python bench.py --dtype f32x3 --mode infer --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/infer_f32x3_b1024.json 2>$OUT/infer_f32x3.err; cut -c1-300 $OUT/infer_f32x3_b1024.json
+      timeout 600 python bench.py --dtype f32x3 --frames 1024 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $OUT/train_f32x3_t1024_b64.json 2>/dev/null; cut -c1-300 $OUT/train_f32x3_t1024_b64.json
       timeout 600 python bench.py --mode dsp --steps 5 --warmup 2 > $OUT/dsp.json 2>$OUT/dsp.err; cut -c1-300 $OUT/dsp.json ;;
   esac
 done

@@ -275,9 +275,10 @@ def test_conv_wgrad_many_short_samples_per_chunk(kind, B, Cin, Cout, T, KS, stri
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("B,Cin,Cout,T,KS", [(2, 16, 32, 32, 5), (3, 64, 64, 64, 5), (2, 80, 32, 96, 5), (1, 16, 130, 200, 3), (2, 130, 40, 40, 1),
-                                             (2, 80, 32, 33, 4), (2, 16, 32, 70, 6), (2, 16, 32, 64, 2),
+                                             (2, 80, 32, 33, 4), (2, 16, 32, 70, 6), (2, 16, 32, 64, 2), (2, 16, 32, 64, 7), (2, 8, 32, 19, 8),
                                              pytest.param(64, 128, 128, 128, 5, marks=GPU), pytest.param(256, 128, 128, 32, 5, marks=GPU),
-                                             pytest.param(16, 1104, 128, 128, 1, marks=GPU), pytest.param(32, 80, 128, 128, 6, marks=GPU)])
+                                             pytest.param(16, 1104, 128, 128, 1, marks=GPU), pytest.param(32, 80, 128, 128, 6, marks=GPU),
+                                             pytest.param(32, 80, 128, 128, 8, marks=GPU)])
 def test_conv_wgrad_x3_split_bf16_products(kind, B, Cin, Cout, T, KS):
     """avc_set_tuning("wgrad_x3", 1): the whole-chunk k = 5 weight-gradient launches form their products from three bf16 terms
     per operand (both operands are activations: both are split in registers).  Same bar as the exact-fp32 kernel, plus the
