@@ -82,8 +82,8 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
-    ("emu", "tiny128", 3, 40, False),   # 128 hidden channels + avc_set_tuning("conv_rs", 1): the register-stationary conv kernel in the plan
-    ("emu", "tiny128x3", 3, 40, False), # ... + avc_set_tuning("conv_x3", 2): the split-bf16 conv kernel in every eligible layer of the plan
+    ("emu", "tiny128", 2, 40, False),   # 128 hidden channels + avc_set_tuning("conv_rs", 1): the register-stationary conv kernel in the plan
+    ("emu", "tiny128x3", 2, 40, False), # ... + avc_set_tuning("conv_x3", 2): the split-bf16 conv kernel in every eligible layer of the plan
     pytest.param("gpu", "m80rs", 8, 128, False, marks=GPU),   # the same opt-in kernel on the stock config
     pytest.param("gpu", "m80x3", 8, 128, False, marks=GPU),   # split-bf16 kernel, every eligible layer
     pytest.param("gpu", "m80x3", 3, 40, False, marks=GPU),    # ... odd lengths
