@@ -30,11 +30,11 @@ int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream);
 void avc_set_conv_rs(int on);
 // split-bf16 conv (conv_x3.hip): ConvArgs.rs == 2, PackArgs.rs == 2
 bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int B, int M);
-long avc_conv_x3_image_floats(int M, int Cred);
+long avc_conv_x3_image_floats(int M, int Cred, int KS);
 void avc_set_conv_x3(int on);
 void avc_set_wgrad_x3(int on);
 int avc_wgrad_x3();
-void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst);
+void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, int M_rows = 0);
 int avc_launch_conv_x3(const ConvArgs& a, hipStream_t stream);
 // one-shot short-row conv (conv_small.hip): same packed images as conv_gemm.hip
 bool avc_conv_small_eligible(const ConvArgs& a, bool forced);

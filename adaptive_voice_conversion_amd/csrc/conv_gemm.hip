@@ -697,7 +697,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
 }
 
 long avc_pack_total(const PackArgs& p) {
-    if (p.rs == 2) return (long)p.nchunk * p.KS * 6 * p.Mp * 4;
+    if (p.rs == 2) return (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
     return p.rs ? (long)p.rs_nslab * p.rs_nq * 256 + 128 : (long)p.nchunk * p.KS * p.CK * p.Mp;
 }
 

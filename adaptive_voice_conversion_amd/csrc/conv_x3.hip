@@ -8,7 +8,8 @@
 // of the same products: 1.8e-7) and 185-255 fp32-equivalent TFLOP/s in the inner loop against 100-134 for the fp32 MFMA.
 //
 // Same contraction, geometry, LDS-DMA staging and fused epilogue as conv_gemm.hip (reference: model.py:21-32 pad_layer +
-// nn.Conv1d and its input gradient) for its k = 5 layers, 16-channel chunks; the workgroup tile is 64 rows x 128 columns with
+// nn.Conv1d and its input gradient) for its k = 5 layers (16-channel chunks) and its 1x1 convs (32-channel chunks, the last one
+// zero-padded by the image: the 1104 -> 128 in_conv takes 100 instead of 136 us); the workgroup tile is 64 rows x 128 columns with
 // the four waves side by side (64 x 32 each), so that one operand split feeds twelve MFMAs.  Differences:
 //   * the weights are split ONCE per optimizer step by the pack kernel into a k-contiguous bf16 image
 //     [chunk][tap][term][k-half][m][8 bf16]: a lane's A fragment of a term is one 16-byte LDS read;
@@ -29,9 +30,9 @@
 
 #include "conv_x3_shared.h"
 
-template <bool MIRROR>
+template <bool MIRROR, int KS, int KB>
 __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) {
-    constexpr int BM = 64, BN = 128, KS = X3_KS, CK = X3_CK;   // 4 waves side by side, each 64 rows x 32 columns: ONE split feeds 12 MFMAs
+    constexpr int BM = 64, BN = 128, CK = 16 * KB, AROWS = KS * KB * 6;   // 4 waves side by side, each 64 rows x 32 columns: ONE split feeds 12 MFMAs
     // (BM = 128 -- one split per 24 MFMAs, one workgroup per CU -- measured no better: 55.2 vs 53.6 us at T=128)
     constexpr int WM = BM / 32;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
     const int ROW = q.ROW;
     const int m_tile0 = blockIdx.y * BM;
-    constexpr int AS = X3_AROWS * BM * 4;   // floats per A stage (30 KiB)
+    constexpr int AS = AROWS * BM * 4;   // floats per A stage (k = 5: 30 KiB, k = 1: 12 KiB)
     const int XS = CK * ROW;
     float* As = smem;
     float* Xs = smem + 2 * AS;
@@ -112,9 +113,9 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     __syncthreads();   // zero fill done before the first DMA lands
 
     auto load_a = [&](int chunk, int buf) {   // 30 rows of BM m x 16 bytes: the packed image is the LDS image
-        const float* wsrc = g.wp + ((long)chunk * X3_AROWS * a.Mp + m_tile0) * 4;
+        const float* wsrc = g.wp + ((long)chunk * AROWS * a.Mp + m_tile0) * 4;
         float* Ad = As + buf * AS;
-        for (int piece = wave; piece < X3_AROWS * (BM / 64); piece += 4) {
+        for (int piece = wave; piece < AROWS * (BM / 64); piece += 4) {
             const int row = piece / (BM / 64), half = piece % (BM / 64);
             avc_glds16(wsrc + ((long)row * a.Mp + half * 64 + lane) * 4, Ad + (row * BM + half * 64) * 4);
         }
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         float* Xd = Xs + buf * XS;
         for (int r = wave; r < CK; r += 4) {
             const int c = chunk * CK + r;
+            if (c >= a.Cred) continue;   // channel padding of the last chunk: its weights are zeros, the stage holds finite values
             const long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
             const float* src = a.x.ptr + coff;
 #pragma unroll
@@ -140,18 +142,19 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
             load_x(chunk + 1, (chunk + 1) & 1);
         }
         const avc_u32x4* Ab = (const avc_u32x4*)(As + (chunk & 1) * AS);
-        const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;
+        const float* Xb = Xs + (chunk & 1) * XS + (8 * h) * ROW;   // (+ 16 kb rows for block kb)
         // Straight-line taps, software-pipelined by hand: the eight B values of tap j+1 are requested from LDS before the
         // twelve MFMAs of tap j are issued, so the LDS round trip and the split (~50 VALU) of a tap overlap the matrix
         // pipe working on the previous one (a tap loop with its parity branches compiled to read -> wait -> split -> MFMA).
-        auto fetch = [&](int tap, float (&x)[8]) {
+        auto fetch = [&](int unit, float (&x)[8]) {   // unit = tap * KB + block
+            const int tap = unit / KB, kb = unit % KB;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                x[k] = Xb[k * ROW + cb + tap];
-                if (use_mirror) x[k] += Xb[k * ROW + cbm + tap];
+                x[k] = Xb[(16 * kb + k) * ROW + cb + tap];
+                if (use_mirror) x[k] += Xb[(16 * kb + k) * ROW + cbm + tap];
             }
         };
-        auto mma = [&](int tap, const float (&x)[8]) {
+        auto mma = [&](int unit, const float (&x)[8]) {
             unsigned hi[8], mid[8], lo[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x3_split(x[k], hi[k], mid[k], lo[k]);
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int term = 0; term < 3; ++term) at[wm][term] = Ab[((tap * 3 + term) * 2 + h) * BM + wm * 32 + li];
+                for (int term = 0; term < 3; ++term) at[wm][term] = Ab[((unit * 3 + term) * 2 + h) * BM + wm * 32 + li];
             // small terms first; the WM accumulators alternate so that consecutive MFMAs are independent
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16x8(at[wm][2], bt[0], acc[wm]);
@@ -183,6 +186,10 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
         };
         float xa[8], xb[8];
         if (a.dbg & 2) {
+        } else if constexpr (KS == 1) {   // two blocks of 16 channels
+            fetch(0, xa);
+            fetch(1, xb); mma(0, xa);
+            mma(1, xb);
         } else if (!a.par) {
             fetch(0, xa);
             fetch(1, xb); mma(0, xa);
@@ -213,7 +220,9 @@ static int g_conv_x3 = 0;   // avc_set_tuning("conv_x3", 1): plans created while
 void avc_set_conv_x3(int on) { g_conv_x3 = on; }   // 2: every layer of an eligible shape, whatever its size (tests)
 
 static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
-    if (KS != X3_KS || Cred < X3_CK || Cred % X3_CK != 0) return false;
+    if (KS == 1) {   // 1x1 conv / Linear over time: 32-channel chunks, the last one zero-padded by the image
+        if (Cred < 32 || stride != 1) return false;
+    } else if (KS != 5 || Cred < 16 || Cred % 16 != 0) return false;
     if (stride != 1 && stride != 2) return false;
     if (mode == 1 && Tout < 10) return false;   // one mirror window per column
     const ConvGeom q = conv_geom(mode, stride, Tout, KS, 128, 0);
@@ -227,15 +236,16 @@ bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int 
     // (the input-gradient launches carry the mask / residual-join epilogue: in the engine they win only from 512 workgroups on)
     return g_conv_x3 >= 2 || ntn * (avc_cdiv(M, 128) * 2) >= (mode == 1 ? 512 : 256);
 }
-long avc_conv_x3_image_floats(int M, int Cred) { return (long)(Cred / X3_CK) * X3_AROWS * (avc_cdiv(M, 128) * 128) * 4; }
+long avc_conv_x3_image_floats(int M, int Cred, int KS) { return (long)avc_cdiv(Cred, 16 * x3_kb(KS)) * x3_arows(KS) * (avc_cdiv(M, 128) * 128) * 4; }
 
-void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst) {
+void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, int M_rows) {
     memset(&p, 0, sizeof(p));
-    const int M = dgrad ? Cin : Cout, Cred = dgrad ? Cout : Cin;
+    // M_rows > 0: only the first M_rows output rows of the image (the input gradient of a layer whose leading input channels need one)
+    const int M = M_rows > 0 ? M_rows : (dgrad ? Cin : Cout), Cred = dgrad ? Cout : Cin;
     p.src[0] = w;
     p.nsrc = 1; p.rows_per_src = Cout;
     p.Cout = Cout; p.Cin = Cin; p.KS = KS; p.dgrad = dgrad;
-    p.CK = X3_CK; p.nchunk = Cred / X3_CK;
+    p.CK = 16 * x3_kb(KS); p.nchunk = avc_cdiv(Cred, p.CK);
     p.M = M; p.Mp = avc_cdiv(M, 128) * 128;
     p.dst = dst;
     p.rs = 2;
@@ -246,17 +256,18 @@ int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
     a.dbg = avc_conv_ablation_bits();
     if (a.ngroups != 1 || a.in_fuse) return -1;
     const ConvGroup& g = a.g[0];
-    if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != X3_CK || g.nchunk * X3_CK != a.Cred || a.Mp % 128 != 0) return -2;
+    if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != 16 * x3_kb(g.KS) || g.nchunk != avc_cdiv(a.Cred, g.CK) || a.Mp % 128 != 0) return -2;
     if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;
     const ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, g.KS, 128, 0);
-    const size_t lds = (size_t)(2 * X3_AROWS * 256 + 2 * X3_CK * q.ROW) * 4 + 16;
+    const size_t lds = (size_t)(2 * x3_arows(g.KS) * 256 + 2 * g.CK * q.ROW) * 4 + 16;
     if (lds > 160 * 1024) return -5;
     const int ntn = a.Tout >= 128 ? a.B * avc_cdiv(a.Tout, 128) : avc_cdiv(a.B, 128 / a.Tout);
-    a.par = a.mode == 1 && a.stride == 2 && g.padL == 2 && (a.Tout >= 128 || (a.Tout % 2 == 0 && 128 % a.Tout == 0));
+    a.par = g.KS == 5 && a.mode == 1 && a.stride == 2 && g.padL == 2 && (a.Tout >= 128 || (a.Tout % 2 == 0 && 128 % a.Tout == 0));
     dim3 grid(ntn, a.Mp / 64);
     const double flops = 2.0 * a.M * a.Cred * g.KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
-    if (a.mode == 1 && a.mirror) hipLaunchKernelGGL((conv_x3_kernel<true>), grid, dim3(AVC_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL((conv_x3_kernel<false>), grid, dim3(AVC_THREADS), lds, stream, a);
+    if (g.KS == 1) hipLaunchKernelGGL((conv_x3_kernel<false, 1, 2>), grid, dim3(AVC_THREADS), lds, stream, a);
+    else if (a.mode == 1 && a.mirror) hipLaunchKernelGGL((conv_x3_kernel<true, 5, 1>), grid, dim3(AVC_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((conv_x3_kernel<false, 5, 1>), grid, dim3(AVC_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }

@@ -30,14 +30,16 @@ static __device__ __forceinline__ unsigned x3_pair(unsigned a, unsigned b) { ret
 static inline unsigned x3_pair(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
 #endif
 
-#define X3_KS 5
-#define X3_CK 16
-#define X3_AROWS (X3_KS * 3 * 2)   // (tap, term, k-half) rows of 64 m x 8 bf16 = 256 floats each
+// chunk geometry: KB blocks of 16 reduction channels per chunk (k = 5: one, k = 1: two) x KS taps; a chunk of the weight
+// image is KS * KB * 6 rows (tap, block, term, k-half) of Mp x 8 bf16
+static inline __host__ __device__ int x3_kb(int KS) { return KS == 1 ? 2 : 1; }
+static inline __host__ __device__ int x3_arows(int KS) { return KS * x3_kb(KS) * 6; }
 
-// weight image: W[Cout][Cin][KS] -> [chunk][tap][term][k-half][Mp][4 dwords], dword q of k-half h = channels chunk*16 + 8h + 2q, +1
+// weight image: W[Cout][Cin][KS] -> [chunk][tap][block][term][k-half][Mp][4 dwords], dword q = channels chunk*CK + 16 block + 8 h + 2q, +1
 //   fwd  : value(m, c, j) = W[m][c][j]          dgrad: value(m, c, j) = W[c][m][KS-1-j]   (transposed, tap-flipped)
 static __device__ __forceinline__ void avc_pack_x3_one(const PackArgs& p, long first, long stride) {
-    const long total = (long)p.nchunk * X3_AROWS * p.Mp * 4;
+    const int KB = x3_kb(p.KS);
+    const long total = (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
     const float* w = p.src[0];
     const int Cred = p.dgrad ? p.Cout : p.Cin;
     unsigned* dst = (unsigned*)p.dst;
@@ -50,10 +52,12 @@ static __device__ __forceinline__ void avc_pack_x3_one(const PackArgs& p, long f
         rest >>= 1;
         const int term = (int)(rest % 3);
         rest /= 3;
-        const int j = (int)(rest % X3_KS), chunk = (int)(rest / X3_KS);
+        const int kb = (int)(rest % KB);
+        rest /= KB;
+        const int j = (int)(rest % p.KS), chunk = (int)(rest / p.KS);
         unsigned t[2] = {0u, 0u};
         for (int u = 0; u < 2; ++u) {
-            const int c = chunk * X3_CK + 8 * h + 2 * q + u;
+            const int c = chunk * 16 * KB + 16 * kb + 8 * h + 2 * q + u;
             float v = 0.f;
             if (m < p.M && c < Cred) v = p.dgrad ? w[((long)c * p.Cin + m) * p.KS + (p.KS - 1 - j)] : w[((long)m * p.Cin + c) * p.KS + j];
             unsigned hi, mid, lo;

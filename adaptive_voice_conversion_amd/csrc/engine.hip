@@ -166,7 +166,8 @@ static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool co
 
 // Bn/Tf: batch and output length of the forward launch; Td: output length of the dgrad launch
 // rs_ps: pixel-(un)shuffle factor of the dy view the dgrad launch reads (0: never the register-stationary kernel)
-static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, int rs_ps = 1) {
+// conv_path: the layer is launched through avc_launch_conv (false: the dense stack, which reads the fp32 images in its own kernel)
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, int rs_ps = 1, bool conv_path = true) {
     L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
@@ -179,14 +180,14 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
     L.rs_f = ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(0, L.Cin, L.KS, L.stride, Tf, 1);
     L.rs_d = need_dgrad && ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(1, L.Cout, L.KS, L.stride, Td, rs_ps);
-    L.x3_f = !L.rs_f && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
-    L.x3_d = !L.rs_d && need_dgrad && ngroups == 1 && L.nsrc == 1 && L.dgM == L.Cin && avc_conv_x3_eligible(1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
-    if (L.x3_f) { L.CK = 16; L.nchunk_f = L.Cin / 16; }
-    if (L.x3_d) { L.CKd = 16; L.nchunk_d = L.Cout / 16; }
+    L.x3_f = conv_path && !L.rs_f && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
+    L.x3_d = conv_path && !L.rs_d && need_dgrad && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
+    if (L.x3_f) { L.CK = L.KS == 1 ? 32 : 16; L.nchunk_f = avc_cdiv(L.Cin, L.CK); }
+    if (L.x3_d) { L.CKd = L.KS == 1 ? 32 : 16; L.nchunk_d = avc_cdiv(L.Cout, L.CKd); }
     if (L.rs_f) L.wrs_f = p->alloc(avc_conv_rs_image_floats(L.Cout, L.Cin, L.KS));
     if (L.rs_d) L.wrs_d = p->alloc(avc_conv_rs_image_floats(L.dgM, L.Cout, L.KS));
-    if (L.x3_f) L.wrs_f = p->alloc(avc_conv_x3_image_floats(L.Cout, L.Cin));
-    if (L.x3_d) L.wrs_d = p->alloc(avc_conv_x3_image_floats(L.dgM, L.Cout));
+    if (L.x3_f) L.wrs_f = p->alloc(avc_conv_x3_image_floats(L.Cout, L.Cin, L.KS));
+    if (L.x3_d) L.wrs_d = p->alloc(avc_conv_x3_image_floats(L.dgM, L.Cout, L.KS));
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
     if (need_dgrad) L.wpd = p->alloc((long)L.nchunk_d * L.KS * L.CKd * L.Mp_d);
     if (L.nsrc > 1) L.bpk = p->alloc((long)32 * L.Mp_f);
@@ -337,10 +338,10 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
         }
     }
     for (int l = 0; l < p->spk.nd; ++l) {
-        finish_layer(p, p->layers[p->spk.dn1[l]], dg, 0, 1, B, B);
-        finish_layer(p, p->layers[p->spk.dn2[l]], dg, 0, 1, B, B);
+        finish_layer(p, p->layers[p->spk.dn1[l]], dg, 0, 1, B, B, 1, 1, false);
+        finish_layer(p, p->layers[p->spk.dn2[l]], dg, 0, 1, B, B, 1, 1, false);
     }
-    finish_layer(p, p->layers[p->spk.outl], dg, 0, 1, B, B);
+    finish_layer(p, p->layers[p->spk.outl], dg, 0, 1, B, B, 1, 1, false);
     if (!spk_only) {
         finish_layer(p, p->layers[p->enc.heads], dg, 0, B, p->Tb, p->Tb);
         finish_layer(p, p->layers[d.in_conv], dg, 0, B, p->Tb, p->Tb);
@@ -850,7 +851,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     }
     if (L.need_dgrad && L.x3_d) {
         PackArgs r;
-        avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d);
+        avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d, L.dgM);
         out.push_back(r);
     } else if (L.need_dgrad && L.rs_d) {
         PackArgs r;

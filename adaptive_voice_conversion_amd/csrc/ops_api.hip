@@ -28,8 +28,9 @@ int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, flo
 }
 // split-bf16 weight image of conv_x3.hip (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad)
 long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad) {
-    if (KS != 5 || (dgrad ? Cout : Cin) % 16 != 0) return -1;
-    return avc_conv_x3_image_floats(dgrad ? Cin : Cout, dgrad ? Cout : Cin);
+    const int Cred = dgrad ? Cout : Cin;
+    if (!((KS == 5 && Cred % 16 == 0) || (KS == 1 && Cred >= 32))) return -1;
+    return avc_conv_x3_image_floats(dgrad ? Cin : Cout, Cred, KS);
 }
 int avc_pack_weight_x3(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream) {
     if (avc_packed_weight_floats_x3(Cout, Cin, KS, dgrad) < 0) return -2;
@@ -121,7 +122,7 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.g[0].CK = avc_conv_ck(KS);
     a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = out; a.g[0].out2 = out2; a.g[0].res = res; a.g[0].mask = nullptr;
     a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
-    if (tile == 97) { a.g[0].CK = 16; a.g[0].nchunk = Cin / 16; }   // wp is a split-bf16 image (avc_pack_weight_x3)
+    if (tile == 97) { a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK); }   // wp is a split-bf16 image (avc_pack_weight_x3)
     return avc_launch_conv(a, (hipStream_t)stream, tile);
 }
 
@@ -149,7 +150,7 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     a.g[0].CK = avc_conv_ck(KS);
     a.g[0].wp = wpd; a.g[0].bias = nullptr; a.g[0].out = dx; a.g[0].out2 = dx2; a.g[0].res = res; a.g[0].mask = mask;
     a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
-    if (tile == 97) { a.g[0].CK = 16; a.g[0].nchunk = Cout / 16; }
+    if (tile == 97) { a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK); }
     return avc_launch_conv(a, (hipStream_t)stream, tile);
 }
 

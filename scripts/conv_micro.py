@@ -48,7 +48,7 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
     wp, wpd = pack(w, 0), pack(w, 1)
     rs_ok = KS == 5 and Cin == 128
     wrs, wrsd = (pack_rs(w, 0), pack_rs(w, 1)) if rs_ok else (None, None)
-    x3_ok = KS == 5 and Cin % 16 == 0 and Cout % 16 == 0 and 97 in tiles
+    x3_ok = ((KS == 5 and Cin % 16 == 0 and Cout % 16 == 0) or (KS == 1 and Cin >= 32 and Cout >= 32)) and 97 in tiles
     wx3, wx3d = (pack_x3(w, 0), pack_x3(w, 1)) if x3_ok else (None, None)
     flops = 2.0 * Cout * Cin * KS * B * To
     res = []
@@ -83,6 +83,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "x3":
         run(B, 128, 128, 128, 5, 2, tiles=(0, 97), which="fd")
         run(B, 128, 256, 64, 5, 1, tiles=(0, 97), which="f")
     run(64, 128, 128, 1024, 5, 1, tiles=(0, 97), which="fd")
+    run(256, 1104, 128, 128, 1, 1, tiles=(0, 97), which="fd")
+    run(256, 128, 1024, 128, 1, 1, tiles=(0, 97), which="f")
+    run(256, 128, 128, 128, 1, 1, tiles=(0, 97), which="fd")
+    run(1, 1200, 2050, 401, 1, 1, tiles=(0, 97), which="f")
+    run(1, 2050, 1200, 401, 1, 1, tiles=(0, 97), which="f")
     sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s2":

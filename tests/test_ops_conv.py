@@ -470,7 +470,9 @@ def pack_x3(lib, dev, w, dgrad):
 
 
 X3 = [
-    # B, Cin, Cout, T, stride
+    # B, Cin, Cout, T, stride   (k = 5; a negative stride marks a 1x1 conv)
+    (2, 40, 48, 40, -1),      # 1x1: two 32-channel chunks, the second zero-padded (40 channels)
+    (1, 80, 130, 70, -1),     # 1x1: three chunks (80 = 2.5), three row tiles
     (2, 16, 32, 40, 1),       # one chunk, partial second tile
     (3, 32, 48, 16, 1),       # two chunks, several samples per tile, rows >= Cout masked
     (2, 32, 32, 21, 2),       # stride 2, odd T (dgrad: all taps)
@@ -478,6 +480,7 @@ X3 = [
     (1, 32, 144, 70, 1),      # three row tiles
     pytest.param(64, 128, 128, 128, 1, marks=GPU),
     pytest.param(64, 128, 128, 64, 2, marks=GPU),
+    pytest.param(64, 1104, 128, 128, -1, marks=GPU),
 ]
 
 
@@ -487,9 +490,12 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     if kind == "emu" and B * Cin * Cout * T > 3e6:
         pytest.skip("gpu-sized")
     lib, dev = backend(kind)
+    KS = 5
+    if stride < 0:
+        KS, stride = 1, 1
     g = torch.Generator().manual_seed(B * 31 + T)
     x = torch.randn(B, Cin, T, generator=g)
-    w = torch.randn(Cout, Cin, 5, generator=g) / (Cin * 5) ** 0.5
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
     b = torch.randn(Cout, generator=g)
     xd64 = x.double().requires_grad_(True)
     y64 = O.pad_conv(xd64, w.double(), b.double(), stride)
@@ -497,7 +503,7 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     wp = pack_x3(lib, dev, w.to(dev), 0)
     out = torch.full(y32.shape, float("nan"), device=dev)
     xd = x.to(dev)
-    rc = lib.avc_conv1d_fwd(P(xd), xd.stride(0), xd.stride(1), 1, B, Cin, T, P(wp), P(b.to(dev)), Cout, 5, stride, 0, P(out),
+    rc = lib.avc_conv1d_fwd(P(xd), xd.stride(0), xd.stride(1), 1, B, Cin, T, P(wp), P(b.to(dev)), Cout, KS, stride, 0, P(out),
                             out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, 97, None)
     assert rc == 0, rc
     e_x3 = (out.cpu().double() - y64.detach()).abs().max().item()
@@ -513,12 +519,14 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     (dx64,) = torch.autograd.grad(y64, xd64, dy.double())
     xg = x.clone().requires_grad_(True)
     (dx32,) = torch.autograd.grad(O.pad_conv(xg, w, None, stride), xg, dy)
+    if KS == 1 and Cout % 16 != 0 and Cout < 32:
+        return
     wpd = pack_x3(lib, dev, w.to(dev), 1)
     dx = torch.full((B, Cin, T), float("nan"), device=dev)
     dyd = dy.to(dev)
-    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cout, dy.shape[2], P(wpd), Cin, 5, stride, T, P(dx),
+    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cout, dy.shape[2], P(wpd), Cin, KS, stride, T, P(dx),
                               dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, 97, None)
-    if T < 10:
+    if T < 10 and KS == 5:
         assert rc != 0
         return
     assert rc == 0, rc
