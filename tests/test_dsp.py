@@ -253,3 +253,23 @@ def test_inference_from_path_wav_to_wav(kind, tmp_path):
     n = min(len(wav), len(ref))
     if len(wav) == len(ref):
         assert np.linalg.norm(wav[:n] - ref[:n]) <= 2e-2 * np.linalg.norm(ref[:n])
+
+
+def test_load_wav_decodes_pcm_stereo_and_resamples(tmp_path):
+    """dsp.load_wav (the file-I/O edge of get_spectrograms: the reference calls librosa.load(path, sr=hp.sr)): int16 PCM is
+    scaled to [-1, 1), channels are averaged, a different rate is resampled to the requested one."""
+    from scipy.io import wavfile
+    sr = 8000
+    t = np.arange(4000) / sr
+    tone = 0.5 * np.sin(2 * np.pi * 440 * t)
+    wavfile.write(tmp_path / "mono16.wav", sr, (tone * 32767).astype(np.int16))
+    y = P.load_wav(str(tmp_path / "mono16.wav"), sr)
+    assert y.dtype == np.float32 and y.shape == (4000,)
+    np.testing.assert_allclose(y, tone, atol=2.0 / 32768)
+    wavfile.write(tmp_path / "stereo.wav", sr, np.stack([tone, -tone + 0.2], axis=1).astype(np.float32))
+    np.testing.assert_allclose(P.load_wav(str(tmp_path / "stereo.wav"), sr), np.full(4000, 0.1), atol=1e-6)
+    wavfile.write(tmp_path / "slow.wav", sr // 2, tone[::2].astype(np.float32))
+    up = P.load_wav(str(tmp_path / "slow.wav"), sr)
+    assert abs(len(up) - 4000) <= 2
+    k = np.argmax(np.abs(np.fft.rfft(up[:4000 - 2])))
+    assert abs(k * sr / (4000 - 2) - 440) < 3.0                      # still a 440 Hz tone at the new rate
