@@ -46,6 +46,8 @@ int avc_conv_ablation_bits();
 int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s);
 int avc_launch_dsp_frames(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);
 int avc_launch_dsp_ola(const float* tf, int B, int T, int hop, int n_fft, int win, float* y, hipStream_t s);
+int avc_launch_dsp_frames_ragged(const float* y, const int* toff, int B, int Ttot, int hop, int n_fft, int win, float* frames, hipStream_t s);
+int avc_launch_dsp_ola_ragged(const float* tf, const int* toff, int B, int Ttot, int hop, int n_fft, int win, float* y, hipStream_t s);
 int avc_launch_dsp_phase(const float* est, const float* S, int F, int T, float* out, hipStream_t s);
 int avc_launch_dsp_mag(const float* spec, int F, int T, float* mag, hipStream_t s);
 int avc_launch_dsp_db_norm(const float* in, int C, int T, float ref_db, float max_db, float* out, hipStream_t s);

@@ -90,6 +90,52 @@ __global__ void __launch_bounds__(AVC_THREADS) dsp_ola_kernel(const float* tf, i
     }
 }
 
+// ---- utterances of DIFFERENT lengths in one launch set: toff[b] = first frame (column) of utterance b, toff[B] = all frames;
+// utterance b has T_b = toff[b+1] - toff[b] frames and hop (T_b - 1) samples, stored back to back from sample hop (toff[b] - b)
+static __device__ __forceinline__ int dsp_find(const int* toff, int B, long key, int hop, bool samples) {
+    int lo = 0, hi = B - 1;   // largest b with start(b) <= key
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const long start = samples ? (long)hop * (toff[mid] - mid) : (long)toff[mid];
+        if (start <= key) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(AVC_THREADS) dsp_frames_ragged_kernel(const float* y, const int* toff, int B, int hop, int n_fft, int win, float* frames) {
+    const int n0 = (n_fft - win) / 2;
+    const long TT = toff[B], total = (long)win * TT;
+    for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < total; e += (long)gridDim.x * AVC_THREADS) {
+        const int k = (int)(e / TT);
+        const long c = e - (long)k * TT;
+        const int b = dsp_find(toff, B, c, hop, false);
+        const int t = (int)(c - toff[b]);
+        const long L = (long)hop * (toff[b + 1] - toff[b] - 1);
+        frames[e] = y[(long)hop * (toff[b] - b) + dsp_reflect((long)t * hop + n0 + k - n_fft / 2, L)];
+    }
+}
+__global__ void __launch_bounds__(AVC_THREADS) dsp_ola_ragged_kernel(const float* tf, const int* toff, int B, int hop, int n_fft, int win, float* y) {
+    const int n0 = (n_fft - win) / 2;
+    const long TT = toff[B], Ly = (long)hop * (TT - B);
+    for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < Ly; e += (long)gridDim.x * AVC_THREADS) {
+        const int b = dsp_find(toff, B, e, hop, true);
+        const long s = e - (long)hop * (toff[b] - b);
+        const int T = toff[b + 1] - toff[b];
+        const long q = s + n_fft / 2 - n0;
+        long t1 = q / hop;
+        long t0 = (q - win + hop) / hop;
+        if (q - win + 1 <= 0) t0 = 0;
+        if (t1 > T - 1) t1 = T - 1;
+        float acc = 0.f, wss = 0.f;
+        for (long t = t0; t <= t1; ++t) {
+            const int k = (int)(q - t * hop);
+            const float w = 0.5f - 0.5f * cospif(2.0f * (float)k / (float)win);
+            acc += tf[(long)k * TT + toff[b] + t];
+            wss += w * w;
+        }
+        y[e] = wss > 1.17549435e-38f ? acc / wss : acc;
+    }
+}
+
 // Griffin-Lim projection (utils.py:142-143): X_best = spectrogram * est / max(1e-8, |est|)
 __global__ void __launch_bounds__(AVC_THREADS) dsp_phase_kernel(const float* est, const float* S, int F, int T, float* out) {
     const long total = (long)F * T;
@@ -207,6 +253,14 @@ int avc_launch_dsp_ola(const float* tf, int B, int T, int hop, int n_fft, int wi
     if (Ly < 1) return -1;
     ProfScope ps(AVC_K_MISC, 0.0, 4.0 * B * ((double)win * T + Ly), s);
     hipLaunchKernelGGL(dsp_ola_kernel, dim3(dsp_blocks((long)B * Ly)), dim3(AVC_THREADS), 0, s, tf, B, T, hop, n_fft, win, y, Ly);
+    return (int)hipGetLastError();
+}
+int avc_launch_dsp_frames_ragged(const float* y, const int* toff, int B, int Ttot, int hop, int n_fft, int win, float* frames, hipStream_t s) {
+    hipLaunchKernelGGL(dsp_frames_ragged_kernel, dim3(dsp_blocks((long)win * Ttot)), dim3(AVC_THREADS), 0, s, y, toff, B, hop, n_fft, win, frames);
+    return (int)hipGetLastError();
+}
+int avc_launch_dsp_ola_ragged(const float* tf, const int* toff, int B, int Ttot, int hop, int n_fft, int win, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(dsp_ola_ragged_kernel, dim3(dsp_blocks((long)hop * (Ttot - B))), dim3(AVC_THREADS), 0, s, tf, toff, B, hop, n_fft, win, y);
     return (int)hipGetLastError();
 }
 int avc_launch_dsp_phase(const float* est, const float* S, int F, int T, float* out, hipStream_t s) {

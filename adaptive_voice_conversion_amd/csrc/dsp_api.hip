@@ -99,6 +99,37 @@ int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int wi
     return avc_dsp_griffin_lim_batch(S, 1, T, n_fft, hop_length, win_length, n_iter, basis_fwd, basis_inv, ws, y, stream);
 }
 
+// Utterances of DIFFERENT lengths: S is [F][Ttot] with utterance b in columns toff[b] .. toff[b+1]-1 (toff: B + 1 device ints,
+// toff[0] = 0, toff[B] = Ttot; the caller guarantees every utterance has enough frames for the reflect padding:
+// hop (T_b - 1) > n_fft / 2), y receives the waveforms back to back: utterance b at sample hop (toff[b] - b).
+int avc_dsp_griffin_lim_ragged(const float* S, const int* toff, int B, int Ttot, int n_fft, int hop_length, int win_length, int n_iter,
+                               const float* basis_fwd, const float* basis_inv, float* ws, float* y, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !toff || !basis_fwd || !basis_inv || !ws || !y || B < 1 || Ttot < 2 * B || n_iter < 0)
+        return -1;
+    const int F = n_fft / 2 + 1, F2 = n_fft + 2;
+    auto up = [](long n) { return (n + 63) / 64 * 64; };
+    float* xbest = ws;
+    float* est = xbest + up((long)F2 * Ttot);
+    float* fr = est + up((long)F2 * Ttot);
+    float* xt = fr + up((long)win_length * Ttot);
+    hipStream_t s = (hipStream_t)stream;
+    auto istft = [&](const float* spec, float* out) {
+        int rc = avc_conv1d_fwd(spec, 0, Ttot, 1, 1, F2, Ttot, basis_inv, nullptr, win_length, 1, 1, 0, fr, 0, Ttot, 1, 1, nullptr, 0, 0, 0, 0, 0,
+                                nullptr, 0, stream);
+        return rc ? rc : avc_launch_dsp_ola_ragged(fr, toff, B, Ttot, hop_length, n_fft, win_length, out, s);
+    };
+    int rc = avc_launch_dsp_phase(nullptr, S, F, Ttot, xbest, s);
+    for (int i = 0; i < n_iter && !rc; ++i) {
+        rc = istft(xbest, xt);
+        if (!rc) rc = avc_launch_dsp_frames_ragged(xt, toff, B, Ttot, hop_length, n_fft, win_length, fr, s);
+        if (!rc) rc = avc_conv1d_fwd(fr, 0, Ttot, 1, 1, win_length, Ttot, basis_fwd, nullptr, F2, 1, 1, 0, est, 0, Ttot, 1, 1, nullptr, 0, 0, 0, 0, 0,
+                                     nullptr, 0, stream);
+        if (!rc) rc = avc_launch_dsp_phase(est, S, F, Ttot, xbest, s);
+    }
+    if (!rc) rc = istft(xbest, y);
+    return rc;
+}
+
 int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream) {
     if (!spec || !mag || T < 1) return -1;
     return avc_launch_dsp_mag(spec, n_fft / 2 + 1, T, mag, (hipStream_t)stream);

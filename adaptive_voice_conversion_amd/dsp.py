@@ -225,15 +225,30 @@ class MelDSP:
         return y
 
     def melspectrogram2wav_batch(self, mels, do_trim=True, n_iter=None):
-        """utils.py:89-109 for B utterances of EQUAL length ([B, T, n_mels] or a list of [T, n_mels]): one launch set.
-        Returns a list of float32 numpy waveforms (trim makes their lengths differ)."""
+        """utils.py:89-109 for B utterances in ONE launch set ([B, T, n_mels] or a list of [T_b, n_mels] of any lengths: their
+        frames are the columns of one GEMM per transform; unequal lengths go through avc_dsp_griffin_lim_ragged).
+        Returns a list of float32 numpy waveforms."""
+        hp = self.hp
         mels = [torch.as_tensor(m, dtype=torch.float32) for m in mels]
-        B, T = len(mels), mels[0].shape[0]
-        if any(m.shape != mels[0].shape for m in mels):
-            raise ValueError("melspectrogram2wav_batch needs equally long utterances (group them by length)")
-        amp = self._amplitudes(torch.cat(mels, dim=0))                       # [C][B T]
-        y = self._griffin_lim_cat(self._matmul(self.mel_inv_w, amp), B, T, n_iter)
-        return [self._finish(y[b], do_trim) for b in range(B)]
+        B = len(mels)
+        Ts = [int(m.shape[0]) for m in mels]
+        if any(hp.hop_length * (T - 1) <= hp.n_fft // 2 for T in Ts):
+            raise ValueError("signal too short for the reflect padding of the STFT (needs more than n_fft/2 samples)")
+        amp = self._amplitudes(torch.cat(mels, dim=0))                       # [C][sum T]
+        mag = self._matmul(self.mel_inv_w, amp)
+        if all(T == Ts[0] for T in Ts):
+            y = self._griffin_lim_cat(mag, B, Ts[0], n_iter)
+            return [self._finish(y[b], do_trim) for b in range(B)]
+        toff = torch.tensor(np.concatenate([[0], np.cumsum(Ts)]), dtype=torch.int32, device=self.device)
+        Ttot = int(sum(Ts))
+        ws = torch.empty(self.lib.avc_dsp_griffin_lim_ws_floats(Ttot, hp.n_fft, hp.hop_length, hp.win_length), device=self.device)
+        y = torch.empty(hp.hop_length * (Ttot - B), device=self.device)
+        with self._dev():
+            self._ok(self.lib.avc_dsp_griffin_lim_ragged(_P(mag), _P(toff), B, Ttot, hp.n_fft, hp.hop_length, hp.win_length,
+                                                         hp.n_iter if n_iter is None else n_iter, _P(self.basis_fwd), _P(self.basis_inv),
+                                                         _P(ws), _P(y), self._stream()))
+        starts = [hp.hop_length * (sum(Ts[:b]) - b) for b in range(B)]
+        return [self._finish(y[starts[b]:starts[b] + hp.hop_length * (Ts[b] - 1)].contiguous(), do_trim) for b in range(B)]
 
     def _finish(self, wav, do_trim):
         hp = self.hp

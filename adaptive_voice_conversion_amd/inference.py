@@ -110,18 +110,10 @@ class Inferencer(object):
 
     def convert_batch_to_wav(self, pairs, max_streams=4, do_trim=True, n_iter=None):
         """`convert_batch` + the audio back end: the converted mels are denormalised (inference.py:68) and vocoded by
-        `melspectrogram2wav`, utterances of equal length sharing ONE batched Griffin-Lim launch set (dsp.MelDSP).
+        `melspectrogram2wav` -- all utterances, whatever their lengths, in ONE batched Griffin-Lim launch set (dsp.MelDSP).
         Returns (list of float32 waveforms, list of converted mels) in input order."""
         mels = [self.denormalize(m.numpy()) for m in self.convert_batch(pairs, max_streams)]
-        dsp = self.dsp()
-        groups = defaultdict(list)
-        for i, m in enumerate(mels):
-            groups[m.shape[0]].append(i)
-        wavs = [None] * len(mels)
-        for _, idx in groups.items():
-            for i, w in zip(idx, dsp.melspectrogram2wav_batch([mels[i] for i in idx], do_trim=do_trim, n_iter=n_iter)):
-                wavs[i] = w
-        return wavs, mels
+        return self.dsp().melspectrogram2wav_batch(mels, do_trim=do_trim, n_iter=n_iter), mels   # ONE Griffin-Lim launch set, any lengths
 
     def convert_batch(self, pairs, max_streams=4):
         """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T') share one engine

@@ -186,8 +186,14 @@ def test_batched_griffin_lim_equals_one_utterance_at_a_time(kind):
     assert len(many) == 3
     for a, b in zip(one, many):
         assert a.shape == b.shape and np.array_equal(a, b)
-    with pytest.raises(ValueError, match="equally long"):
-        dsp.melspectrogram2wav_batch([mels[0], mels[1][:-3]])
+    # ... and utterances of DIFFERENT lengths (avc_dsp_griffin_lim_ragged): same columns, same dot products
+    ragged = [mels[0], mels[1][:-7], mels[2][:-13]]
+    one_r = [dsp.melspectrogram2wav(m, do_trim=False, n_iter=2) for m in ragged]
+    many_r = dsp.melspectrogram2wav_batch(ragged, do_trim=False, n_iter=2)
+    for a, b in zip(one_r, many_r):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    with pytest.raises(ValueError, match="reflect padding"):
+        dsp.melspectrogram2wav_batch([mels[0], mels[1][:2]])
 
 
 @GPU
