@@ -9,7 +9,7 @@ oracle through the C ABI at its own size:
                                        against the fp64 oracle on the engine's ReLU branch: rel-L2 <=
                                        max(1e-4, 2 x the fp32 oracle's own distance from fp64) -- at this size
                                        fp32 summation order alone moves the reference by up to 1e-3
-  config 5  T=1024 whole model       : same bars at B=4
+  config 5  T=1024 whole model       : same bars at B=4 AND at the config's own B=64 (all 166 gradient tensors)
   config 4  B=1024 inference         : samples are independent -> 16 random rows vs O.ae_inference
   + a ReLU-branch check that does NOT take the masks from the engine (weak #2 of the verdict)
 
@@ -55,7 +55,7 @@ def _fwd_bwd(kind, cfgname, B, T, seed=0):
     ("emu", "tiny", 5, 32, "logic twin"),
     pytest.param("gpu", "m80", 256, 128, "BASELINE configs[1]: B=256, 80x128, fp32 train step", marks=GPU),
     pytest.param("gpu", "m80", 4, 1024, "BASELINE configs[4]'s segment length: T=1024 whole model", marks=GPU),
-    pytest.param("gpu", "m80", 64, 1024, "BASELINE configs[4]: T=1024, B=64 (forward + losses + gradient norm only)", marks=GPU),
+    pytest.param("gpu", "m80", 64, 1024, "BASELINE configs[4]: T=1024, B=64, every gradient tensor", marks=GPU),
 ])
 def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
     cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T)
@@ -70,9 +70,6 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
     gtot = grads.cpu().norm().item()
     rtot = float(np.sqrt(sum(float(g.double().pow(2).sum()) for g in grads_ref.values())))
     assert gtot == pytest.approx(rtot, rel=5e-3)     # whole-gradient norm, no branch matching
-    if B * T > 256 * 128:                             # (the B=64 x T=1024 mask read-back is 8x config 2's; norms suffice there)
-        print(f"[{kind}/{cfgname} B={B} T={T}] {label}: forward/loss parity ok, |g| {gtot:.6f} vs oracle {rtot:.6f}")
-        return
     # At this size a weight gradient is a sum of B*T_l = 4e3..3e4 terms that mostly cancel (the mean-loss gradient
     # shrinks like 1/sqrt(B) against its summands), and fp32 itself is no longer exact to 1e-4: the fp32 ORACLE
     # differs from its own fp64 run by up to 1e-3 per tensor at B=256 on the same ReLU branch (measured, fp32
@@ -118,6 +115,68 @@ def test_fp32x3_mode_meets_the_same_bars(kind, cfgname, B, T):
         test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, f"fp32x3 mode at B={B}, T={T}")
     finally:
         _COMPUTE[0] = "fp32"
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU),
+                                              pytest.param("gpu", "m80", 4, 1024, marks=GPU)])
+def test_bf16_compute_mode_at_graded_shape(kind, cfgname, B, T):
+    """BASELINE configs[2]'s precision (bf16 products, fp32 accumulate, fp32 master / optimizer state) at the shapes the
+    bench quotes -- the launcher picks other tiles / split factors there than at the B = 4 case of tests/test_engine.py.
+    (1) forward rel-L2 <= 3e-2 against the fp32 oracle (SURVEY 8c's bf16 bar);
+    (2) forward against the oracle's bf16-operand twin (O.bf16_operands: the same rounding points, fp32 accumulate):
+        what is left is summation order plus the few operands that sit on a bf16 rounding boundary -- rel-L2 <= 2e-3;
+    (3) every parameter gradient against that twin evaluated in fp64 accumulation on the ENGINE's ReLU branch:
+        err(engine) <= max(1.5e-2, 2 x err(fp32-accumulating twin)) per tensor, median <= 6e-3.  Why not tighter: rounding is
+        discontinuous -- an operand that differs by 1e-7 between two implementations lands on the other side of a bf16
+        rounding boundary with probability 1e-7 / 2^-9, which injects a 2^-8 relative error; layer after layer that
+        feedback settles at the bf16 rounding level itself (measured on the tiny net: 1e-8 at the output layer's
+        gradient, 6e-4 two layers up, 4-5e-3 at the far end of the backward pass).  So two CORRECT bf16-operand
+        implementations agree to a few bf16 ulps and no better; against the unrounded fp32 oracle the same gradients
+        sit at ~2e-2 (tests/test_engine.py::test_bf16_compute_mode_vs_fp32_oracle)."""
+    _COMPUTE[0] = "bf16"
+    try:
+        cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T)
+    finally:
+        _COMPUTE[0] = "fp32"
+    assert plan.compute_dtype == "bf16"
+    Cz = cfg["ContentEncoder"]["c_out"]
+    mine = {"emb": out["emb"], "mu": out["muls"][:, :Cz], "log_sigma": out["muls"][:, Cz:], "dec": out["dec"]}
+    o32 = dict(zip(("mu", "log_sigma", "emb", "dec"), O.ae_forward(x, eps, sd, cfg)))
+    e32 = {k: _rel(mine[k], o32[k]) for k in mine}
+    assert max(e32.values()) < 3e-2, e32
+    with O.bf16_operands():
+        o16 = dict(zip(("mu", "log_sigma", "emb", "dec"), O.ae_forward(x, eps, sd, cfg)))
+    e16 = {k: _rel(mine[k], o16[k]) for k in mine}
+    assert max(e16.values()) < 2e-3, e16
+    masks = [m.cpu() for m in plan.relu_masks(ws)]
+    with O.relu_masks(masks), O.bf16_operands():
+        _, g32 = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with O.relu_masks(masks), O.bf16_operands():
+        _, g64 = O.loss_and_grads(x.double(), eps.double(), sd64, cfg, 1.0)
+    from tests.test_engine import zero_grad_bias
+    g = grads.cpu().double()
+    errs, worst, worst_ref = [], 0.0, 0.0
+    for (off, n, shape), k in zip(plan.param_info, g64):
+        gi, ref = g[off:off + n].view(shape), g64[k]
+        assert torch.isfinite(gi).all(), k
+        d = ref.norm().item()
+        if zero_grad_bias(k, cfg):
+            assert d < 1e-4 and (gi - ref).norm().item() < 2e-5, k
+            continue
+        e_eng, e_ref = (gi - ref).norm().item() / d, (g32[k].double() - ref).norm().item() / d
+        errs.append(e_eng)
+        assert e_eng <= max(1.5e-2, 2.0 * e_ref), (k, e_eng, e_ref)
+        worst, worst_ref = max(worst, e_eng), max(worst_ref, e_ref)
+    errs.sort()
+    print(f"[{kind}/{cfgname} B={B} T={T}] bf16 compute: forward rel-L2 vs the fp32 oracle {max(e32.values()):.2e}, vs the bf16-operand oracle "
+          f"{max(e16.values()):.2e}; per-tensor gradient vs the bf16-operand oracle (fp64 accumulate, engine's ReLU branch): worst {worst:.2e} / "
+          f"median {errs[len(errs) // 2]:.2e}; the fp32-accumulating oracle's own worst {worst_ref:.2e}")
+    assert errs[len(errs) // 2] < 6e-3
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 32, 128, marks=GPU)])
