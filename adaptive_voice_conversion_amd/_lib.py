@@ -34,7 +34,27 @@ class ReluSite(ctypes.Structure):
                [(n, ctypes.c_long) for n in ("act_off", "sb", "sc", "st", "y_off", "stat_off", "cond_off", "cond_sb")]
 
 
+class Tuning(ctypes.Structure):
+    """avc_tuning (include/avc_hip.h): launch heuristics / diagnostic switches a plan captures at creation."""
+    _fields_ = [(n, ctypes.c_int) for n in ("struct_size", "single_stream", "dec_split_min", "conv_x3", "wgrad_x3", "dgrad_par", "bank_switch",
+                                            "conv_ck5", "wgrad_batch", "wgrad_batch_wgs", "wgrad_target_wgs", "conv_ablation", "wgrad_ablation",
+                                            "op_compute_dtype")] + \
+               [(n, ctypes.c_long) for n in ("wgrad_batch_units", "tile_thr11", "tile_thr21", "ck16_wgs", "ck32_wgs", "kg_wgs")]
+
+
+PLAN_X3 = 4
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+
+def make_tuning(lib, overrides=None):
+    """Library defaults (avc_tuning_init) with ``overrides`` ({field: value}) applied."""
+    t = Tuning()
+    lib.avc_tuning_init(ctypes.byref(t))
+    for k, v in (overrides or {}).items():
+        if not hasattr(t, k) or k == "struct_size":
+            raise KeyError(f"unknown tuning field {k!r}")
+        setattr(t, k, int(v))
+    return t
 
 
 def declare(lib):
@@ -47,8 +67,12 @@ def declare(lib):
     lib.avc_plan_param_range.argtypes = [c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
     lib.avc_plan_stream_wait_grads.argtypes = [c_void_p, c_int, c_void_p]
     lib.avc_set_tuning.argtypes = [ctypes.c_char_p, c_int]
-    lib.avc_set_single_stream.argtypes = [c_int]
-    lib.avc_set_single_stream.restype = None
+    lib.avc_tuning_init.argtypes = [ctypes.POINTER(Tuning)]
+    lib.avc_tuning_init.restype = None
+    lib.avc_get_op_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    lib.avc_get_op_tuning.restype = None
+    lib.avc_plan_create_tuned.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, c_int, ctypes.POINTER(Tuning), ctypes.POINTER(c_void_p)]
+    lib.avc_plan_set_single_stream.argtypes = [c_void_p, c_int]
     lib.avc_gather_segments.argtypes = [c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.avc_plan_destroy.argtypes = [c_void_p]
     lib.avc_plan_destroy.restype = None
@@ -64,14 +88,6 @@ def declare(lib):
     lib.avc_plan_relu_site.argtypes = [c_void_p, c_int, ctypes.POINTER(ReluSite)]
     lib.avc_plan_set_compute_dtype.argtypes = [c_void_p, c_int]
     lib.avc_plan_compute_dtype.argtypes = [c_void_p]
-    lib.avc_set_op_compute_dtype.argtypes = [c_int]
-    lib.avc_set_decoder_split_min.argtypes = [c_int]
-    lib.avc_set_in_fusion.argtypes = [c_int]
-    lib.avc_set_in_fusion.restype = None
-    lib.avc_set_debug_ablation.argtypes = [c_int, c_int]
-    lib.avc_set_debug_ablation.restype = None
-    lib.avc_set_decoder_split_min.restype = None
-    lib.avc_set_op_compute_dtype.restype = None
     lib.avc_plan_out_len.argtypes = [c_void_p]
     lib.avc_plan_latent_len.argtypes = [c_void_p]
     lib.avc_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
@@ -86,9 +102,6 @@ def declare(lib):
     # op-level entry points
     lib.avc_packed_weight_floats.argtypes = [c_int] * 4
     lib.avc_packed_weight_floats.restype = c_long
-    lib.avc_packed_weight_floats_rs.argtypes = [c_int] * 4
-    lib.avc_packed_weight_floats_rs.restype = c_long
-    lib.avc_pack_weight_rs.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.avc_packed_weight_floats_x3.argtypes = [c_int] * 4
     lib.avc_packed_weight_floats_x3.restype = c_long
     lib.avc_pack_weight_x3.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]

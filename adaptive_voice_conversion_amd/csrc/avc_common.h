@@ -30,6 +30,14 @@ enum {
     AVC_RES_UP2 = 5,        // fwd nearest x2: r[t/2]
 };
 
+// packed weight images (pack_weight_kernel)
+enum {
+    AVC_IMG_PLAIN = 0,  // [chunk][tap][r][Mp]: one row of Mp output channels per (tap, reduction channel) -- dense.hip, stacked biases, the d_emb GEMM
+    AVC_IMG_X3 = 2,     // split-bf16 image of conv_x3.hip
+    AVC_IMG_K4 = 3,     // [chunk][tap][unit][h][Mp][u]: reduction channel = chunk CK + 8 unit + 2 u + h; the four k-steps u of a lane are
+                        // 16 contiguous bytes (one ds_read_b128 per four MFMAs) -- conv_gemm.hip
+};
+
 struct ConvSrc {
     const float* ptr;
     long sb, sc;  // element strides of batch / channel
@@ -38,7 +46,7 @@ struct ConvSrc {
 };
 
 struct ConvGroup {
-    const float* wp;    // packed weights [nchunk][KS][CK][Mp]
+    const float* wp;    // packed weights (AVC_IMG_*)
     const float* bias;  // [M] or null
     float* out;         // primary output (may be null)
     float* out2;        // secondary output (may be null)
@@ -64,19 +72,9 @@ struct ConvArgs {
     int ngroups;
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16; // AVC_COMPUTE_*
-    int rs;   // 1: g[0].wp is a register-stationary weight image -> conv_rs.hip
+    int img;  // weight image g[0].wp points at: AVC_IMG_K4 (conv_gemm.hip) or AVC_IMG_X3 (conv_x3.hip)
     int par;  // stride-2 dgrad: columns of one parity per wave, each wave multiplies only the taps that meet non-zero
               // positions of the zero-upsampled dy (set by the launcher)
-    // fused InstanceNorm epilogue (64x64 tile, Tout in {16, 32, 64}: every (b, m) row is complete inside the
-    // tile): g[0].out <- conv + bias (y, kept for the backward), in_out <- relu(IN(y) * gamma + beta) [+ residual],
-    // in_mean / in_rstd <- row statistics (index b * in_C + m)
-    int in_fuse;
-    const float* in_cond;  // AdaIN affine [B][in_cond_sb]: beta = [off + m], gamma = [off + in_C + m]; null = plain IN
-    long in_cond_sb;
-    int in_cond_off, in_C;
-    float* in_out;
-    float* in_mean;
-    float* in_rstd;
     ConvGroup g[AVC_MAX_GROUPS];
 };
 

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "avc_common.h"
+#include "avc_hip.h"
 
 struct PackArgs {
     const float* src[12];
@@ -10,38 +11,25 @@ struct PackArgs {
     int Cout, Cin, KS;       // stacked forward shape
     int dgrad, CK, nchunk, M, Mp;
     float* dst;
-    int rs;       // 1: register-stationary image of conv_rs.hip (nsrc = 1): [slab][q][lane][4] + a zero block; 2: split-bf16 image of conv_x3.hip
-    int rs_nq, rs_nslab;
+    int img;      // AVC_IMG_*
 };
+
+// library defaults / the calling thread's op-level tuning (ops_api.hip)
+const avc_tuning& avc_default_tuning();
+avc_tuning& avc_op_tuning();
 long avc_pack_total(const PackArgs& p);
 
-extern "C" int avc_conv_ck(int KS);
-int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups, int Kred);   // Kred = reduction channels x taps
+int avc_conv_ck(const avc_tuning& tun, int KS);
+int avc_conv_pick_tile(const avc_tuning& tun, int Mp, int B, int Tout, int ngroups, int Kred);   // Kred = reduction channels x taps
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups);
-int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile);
-int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile);
+int avc_conv_ck_for(const avc_tuning& tun, int KS, long wgs, int mode, int stride, int Tout, int tile);
+int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile, const avc_tuning& tun);
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
-// register-stationary conv (conv_rs.hip)
-bool avc_conv_rs_eligible(int mode, int Cred, int KS, int stride, int Tout, int xps);
-long avc_conv_rs_image_floats(int M, int Cred, int KS);
-void avc_pack_rs_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst);
-int avc_launch_pack_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, hipStream_t stream);
-int avc_launch_conv_rs(const ConvArgs& a, hipStream_t stream);
-void avc_set_conv_rs(int on);
-// split-bf16 conv (conv_x3.hip): ConvArgs.rs == 2, PackArgs.rs == 2
-bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int B, int M);
+// split-bf16 conv (conv_x3.hip): ConvArgs.img == AVC_IMG_X3
+bool avc_conv_x3_eligible(const avc_tuning& tun, int mode, int Cred, int KS, int stride, int Tout, int B, int M);
 long avc_conv_x3_image_floats(int M, int Cred, int KS);
-void avc_set_conv_x3(int on);
-void avc_set_wgrad_x3(int on);
-int avc_wgrad_x3();
 void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, int M_rows = 0);
-int avc_launch_conv_x3(const ConvArgs& a, hipStream_t stream);
-// one-shot short-row conv (conv_small.hip): same packed images as conv_gemm.hip
-bool avc_conv_small_eligible(const ConvArgs& a, bool forced);
-int avc_launch_conv_small(const ConvArgs& a, hipStream_t stream);
-void avc_set_conv_small(int on);
-void avc_set_dgrad_par(int on);
-int avc_conv_ablation_bits();
+int avc_launch_conv_x3(const ConvArgs& a, hipStream_t stream, const avc_tuning& tun);
 // mel <-> waveform DSP (dsp.hip)
 int avc_launch_dsp_basis(int which, int n_fft, int win, float* W, hipStream_t s);
 int avc_launch_dsp_frames(const float* y, long L, int B, int T, int hop, int n_fft, int win, float* frames, hipStream_t s);
@@ -58,13 +46,11 @@ int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
-void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+void avc_wgrad_plan(const avc_tuning& tun, int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit);
 void avc_wgrad_geometry(WgradArgs& a);
 void avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);
-int avc_wgrad_target_wgs();
-int avc_launch_wgrad_batch(const WgradArgs* layers, int n, hipStream_t stream);
-int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream);
+int avc_launch_wgrad_batch(const WgradArgs* layers, int n, hipStream_t stream, int ablation = 0);
 #define AVC_REDUCE_MAXSEG 32
 int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream);
 
@@ -104,12 +90,3 @@ int avc_launch_gather_segments(const float* corpus, long n_rows, int M, const lo
                                hipStream_t s);
 int avc_launch_add_transposed(float* dst, const float* src, int B, int C, hipStream_t s);
 
-void avc_set_wgrad_batch(int layers, int target_wgs);
-void avc_set_wgrad_units(long units);
-void avc_set_conv_ck5(int ck);
-void avc_set_bank_switch(int on);
-void avc_set_conv_heuristic(int which, long v);
-void avc_set_wgrad_target_wgs(int n);
-void avc_set_in_variant(int v);
-void avc_set_conv_ablation(int bits);
-void avc_set_wgrad_ablation(int bits);

@@ -15,11 +15,12 @@
 //                      windows of its mirror images before the MFMA, so dx is
 //                      produced directly with T columns and no padded buffer.
 //
-// Tiling: workgroup = 4 waves (2x2), wave tile = (32*WM) x (32*WN), K-chunks of
-// CK reduction channels x KS taps staged through LDS (weights arrive pre-packed
-// in LDS-image order; the source tile is loaded once per chunk and serves all
-// KS taps through shifted windows).  Register-staged double buffering, one
-// barrier per chunk.  Epilogue fuses bias, ReLU, pixel-shuffle store, the
+// Tiling: workgroup = 4 waves (2x2), wave tile = (32*WM) rows x 32 columns, K-chunks of
+// CK reduction channels x KS taps staged through LDS by direct global->LDS DMA
+// (weights arrive pre-packed in LDS-image order; the source tile is loaded once
+// per chunk and serves all KS taps through shifted windows).  Both operands sit in
+// LDS with the four k-steps of a lane contiguous: one ds_read_b128 per operand
+// per four MFMAs.  Double-buffered stages, one barrier per chunk.  Epilogue fuses bias, ReLU, pixel-shuffle store, the
 // residual join (identity / ceil-mode avg-pool / their adjoints) and the ReLU
 // mask of the backward pass.
 #include <hip/hip_runtime.h>
@@ -31,50 +32,36 @@
 #include "conv_shared.h"
 #include "conv_x3_shared.h"
 
-// one K-chunk of MFMAs: A fragments from the packed-weight stage, B fragments as shifted windows
-// of the source tile (plus the two mirror windows of the reflect-padding adjoint when MIRROR).
-// A "unit" is 4 k-steps (8 reduction channels of one tap).
-// MIR: 0 = no mirror window, 1 = ONE mirror window per column (cbl; a column of a sample of >= 6 frames is within pad
-// of at most one edge), 2 = both windows (very short samples)
-template <int WM, int WN, int MIR>
-static __device__ __forceinline__ void conv_load_unit(float (&av)[4][WM], float (&bv)[4][WN], const float* Arow, const float* Xrow,
-                                                      int ROW, const int (&cb)[WN], const int (&cbl)[WN], const int (&cbr)[WN]) {
-    constexpr int BM = 64 * WM;
+// LDS images (floats), per stage:
+//   A  [tap][unit][h][BM rows][u]   = the packed weight image (AVC_IMG_K4) of this row tile, copied by 16-byte LDS-DMA
+//   X  [unit][h][ROW positions][u]  = the source tile; reduction channel of (unit, h, u) = 8 unit + 2 u + h
+// so the four k-steps u = 0..3 of one "unit" (8 reduction channels of one tap: four v_mfma_f32_32x32x2_f32, lane half h
+// supplies k = h) are 16 contiguous bytes for every lane of both operands: ONE ds_read_b128 per operand per four MFMAs
+// (round 2 issued four ds_read_b32 each; the MFMA issue-rate probe, profiles/r02_mfma_probe.log, says reads set the rate).
+// A tap is a 16-byte shift of the X address, so all KS taps are served from the one tile.
+// MIR: 0 = no mirror window, 1 = ONE mirror window per column (a column of a sample of >= 2 (padL + padR) + 2 frames is within
+// pad of at most one edge), 2 = both windows (very short samples)
+template <int WM, int MIR>
+static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4& bv, const float* Ap, const float* Xp, int cb4, int cbl4, int cbr4) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int wm = 0; wm < WM; ++wm) av[u][wm] = Arow[(2 * u) * BM + wm * 32];
-        const float* xr = Xrow + (2 * u) * ROW;
-#pragma unroll
-        for (int wn = 0; wn < WN; ++wn) {
-            float v = xr[cb[wn]];
-            if (MIR == 1) v = v + xr[cbl[wn]];
-            if (MIR == 2) v = v + xr[cbl[wn]] + xr[cbr[wn]];
-            bv[u][wn] = v;
-        }
-    }
+    for (int wm = 0; wm < WM; ++wm) av[wm] = *(const f32x4*)(Ap + wm * 128);
+    f32x4 v = *(const f32x4*)(Xp + cb4);
+    if (MIR >= 1) v += *(const f32x4*)(Xp + cbl4);
+    if (MIR == 2) v += *(const f32x4*)(Xp + cbr4);
+    bv = v;
 }
-template <int WM, int WN, bool BF>
-static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const float (&av)[4][WM], const float (&bv)[4][WN]) {
+template <int WM, bool BF>
+static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM], const f32x4 (&av)[WM], const f32x4& bv) {
     if constexpr (BF) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
-        avc_s16x4 ap[WM], bp[WN];
+        const avc_s16x4 bp = avc_pack_bf16x4(bv[0], bv[1], bv[2], bv[3]);
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) ap[wm] = avc_pack_bf16x4(av[0][wm], av[1][wm], av[2][wm], av[3][wm]);
-#pragma unroll
-        for (int wn = 0; wn < WN; ++wn) bp[wn] = avc_pack_bf16x4(bv[0][wn], bv[1][wn], bv[2][wn], bv[3][wn]);
-#pragma unroll
-        for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-            for (int wn = 0; wn < WN; ++wn) acc[wm][wn] = avc_mfma_bf16(ap[wm], bp[wn], acc[wm][wn]);
+        for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16(avc_pack_bf16x4(av[wm][0], av[wm][1], av[wm][2], av[wm][3]), bp, acc[wm]);
         return;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-            for (int wn = 0; wn < WN; ++wn)
-                acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][wm], bv[u][wn], acc[wm][wn], 0, 0, 0);
+        for (int wm = 0; wm < WM; ++wm) acc[wm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm][u], bv[u], acc[wm], 0, 0, 0);
 }
 
 // KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
@@ -82,44 +69,41 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], cons
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
 // TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
 // taps of a column meet the zeros of the zero-upsampled dy)
-template <int WM, int WN, int MIR, int KSC, int GRC, bool BF, int TS = 0>
-static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK,
-                                                      int ROW, int h, int a_lane, const int (&cb)[WN], const int (&cbl)[WN],
-                                                      const int (&cbr)[WN]) {
-    constexpr int BM = 64 * WM;
+template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0>
+static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
+                                                      int a_lane4, int cb4, int cbl4, int cbr4) {
+    constexpr int BM4 = 64 * WM * 4;   // floats of one (tap, unit, h) plane of the A stage
     if constexpr (KSC > 0) {
         constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
         constexpr int U = NTAP * GRC;
-        constexpr int CKC = 8 * GRC;
-        float av[2][4][WM], bv[2][4][WN];
-        auto unit_ptrs = [&](int u, const float*& Arow, const float*& Xrow) {
-            const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g4 = u % GRC;
-            Arow = Ab + (tap * CKC + 8 * g4 + h) * BM + a_lane;
-            Xrow = Xb + (8 * g4 + h) * ROW + tap;
+        f32x4 av[2][WM], bv[2];
+        auto unit_ptrs = [&](int u, const float*& Ap, const float*& Xp) {
+            const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g8 = u % GRC;
+            Ap = Ab + ((tap * GRC + g8) * 2 + h) * BM4 + a_lane4;
+            Xp = Xb + ((g8 * 2 + h) * ROW + tap) * 4;
         };
-        const float *Ar, *Xr;
-        unit_ptrs(0, Ar, Xr);
-        conv_load_unit<WM, WN, MIR>(av[0], bv[0], Ar, Xr, ROW, cb, cbl, cbr);
+        const float *Ap, *Xp;
+        unit_ptrs(0, Ap, Xp);
+        conv_load_unit<WM, MIR>(av[0], bv[0], Ap, Xp, cb4, cbl4, cbr4);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u + 1 < U) {
-                unit_ptrs(u + 1, Ar, Xr);
-                conv_load_unit<WM, WN, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ar, Xr, ROW, cb, cbl, cbr);
+                unit_ptrs(u + 1, Ap, Xp);
+                conv_load_unit<WM, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
             }
-            // (pinning this order with sched_barrier(0) was measured: no gain with 4 waves/SIMD, r1 log)
-            conv_mma_unit<WM, WN, BF>(acc, av[u & 1], bv[u & 1]);
+            conv_mma_unit<WM, BF>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
         const int groups = CK >> 3;
         for (int tap = 0; tap < KS; ++tap) {
-            const float* Arow = Ab + (tap * CK + h) * BM + a_lane;
-            const float* Xrow = Xb + h * ROW + tap;
-            for (int g4 = 0; g4 < groups; ++g4) {
-                float av[4][WM], bv[4][WN];
-                conv_load_unit<WM, WN, MIR>(av, bv, Arow, Xrow, ROW, cb, cbl, cbr);
-                conv_mma_unit<WM, WN, BF>(acc, av, bv);
-                Arow += 8 * BM;
-                Xrow += 8 * ROW;
+            const float* Ap = Ab + (tap * groups * 2 + h) * BM4 + a_lane4;
+            const float* Xp = Xb + (h * ROW + tap) * 4;
+            for (int g8 = 0; g8 < groups; ++g8) {
+                f32x4 av[WM], bv;
+                conv_load_unit<WM, MIR>(av, bv, Ap, Xp, cb4, cbl4, cbr4);
+                conv_mma_unit<WM, BF>(acc, av, bv);
+                Ap += 2 * BM4;
+                Xp += 2 * ROW * 4;
             }
         }
     }
@@ -129,9 +113,9 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
 // runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
 // summed through LDS in a fixed order at the end (deterministic).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool INF = false, bool PAR = false>
+template <int WM, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 64 * WM, BN = 64;
     constexpr int NTHREADS = AVC_THREADS * KG;
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[blockIdx.z];
@@ -144,6 +128,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     const int li = lane & 31, h = lane >> 5;
 
     const int KS = g.KS, padL = g.padL, padR = g.padR, CK = g.CK, nchunk = g.nchunk;
+    const int GR = CK >> 3;
     const int Tout = a.Tout;
     const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
     const int ROW = q.ROW;
@@ -154,14 +139,20 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     float* As = smem + kg * 2 * AS;                 // this group's two A stages
     float* Xs = smem + KG * 2 * AS + kg * 2 * XS;   // ... and X stages
 
-    // ---- per-lane source descriptors of the X tile: lane l owns LDS positions p = 64*j + l of every
-    // row (one row = one reduction channel), so the descriptor depends on p only and each chunk's
-    // loads are dword LDS-DMAs (no staging registers, no index table): offset of the element inside
-    // its channel row, or -1 where the tile holds a structural zero (halo / null window / masked).
-    int xoff[AVC_CONV_NJ];
+    // ---- per-lane source descriptors of the X tile.  One dword LDS-DMA instruction fills 64 consecutive floats of an
+    // (unit, h) plane = 16 positions x 4 k-steps: lane l fetches position 16 j + (l >> 2) of reduction channel
+    // 8 unit + 2 (l & 3) + h.  The destination is lane-contiguous, the SOURCE address is the lane's own -- that is what
+    // interleaves four channel rows of the [B, C, T] tensor into 16-byte fragments without any staging register.
+    // Wave w stages the position groups j = 2 jj + (w >> 1) of the planes pl = (w & 1), (w & 1) + 2, ...: it keeps only ITS
+    // offsets (chunk-invariant): xo[jj] = element offset of the position inside a channel row plus the lane's channel
+    // offset, or -1 where the tile holds a structural zero (halo / null window / masked / past the row).
+    const int ul = lane & 3;
+    const long lu = (a.x.ps == 1) ? (long)(2 * ul) * a.x.sc : (long)ul * a.x.sc;   // channel 2u of the unit (ps = 2: pixel-unshuffled view, model.py:52-59)
+    const int jpar = wave >> 1;
+    int xo[AVC_CONV_NJ4 / 2];
 #pragma unroll
-    for (int j = 0; j < AVC_CONV_NJ; ++j) {
-        const int p = 64 * j + lane;
+    for (int jj = 0; jj < AVC_CONV_NJ4 / 2; ++jj) {
+        const int p = 16 * (2 * jj + jpar) + (lane >> 2);
         int sp = -1;
         if (p < q.ROWDATA) {
             int seg = p / q.SEG, qq = p - seg * q.SEG;
@@ -171,30 +162,29 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
                 if (a.mode == 0) {
                     int v = pp - padL;
                     int r = avc_reflect(v, a.Tsrc);
-                    if (r >= 0 && r < a.Tsrc) sp = (int)(b * a.x.sb + (long)r * a.x.st);
+                    if (r >= 0 && r < a.Tsrc) sp = (int)(b * a.x.sb + (long)r * a.x.st + lu);
                 } else {
                     int v = pp - (KS - 1);
                     if (v >= 0) {
                         int vs = v / a.stride;
-                        if (vs * a.stride == v && vs < a.Tsrc) sp = (int)(b * a.x.sb + (long)vs * a.x.st);
+                        if (vs * a.stride == v && vs < a.Tsrc) sp = (int)(b * a.x.sb + (long)vs * a.x.st + lu);
                     }
                 }
             }
         }
-        xoff[j] = sp;
+        xo[jj] = sp;
     }
     // both X stages start as zeros; structural zeros are never overwritten afterwards
     for (int e = tid; e < KG * 2 * XS; e += NTHREADS) smem[KG * 2 * AS + e] = 0.f;
 
-    // ---- per-lane column bases into an LDS row
-    int cb[WN], cbl[WN], cbr[WN], colb[WN], colt[WN];
-    bool colv[WN];
-#pragma unroll
-    for (int wn = 0; wn < WN; ++wn) {
-        int n = wave_n * (32 * WN) + wn * 32 + li;
+    // ---- this lane's column (float index of its position inside an X plane = 4 x position)
+    int cb4, cbl4, cbr4, colb, colt;
+    bool colv;
+    {
+        int n = wave_n * 32 + li;
         int bl, t;
         bool v;
-        if (PAR) {   // (WN == 1) wave_n = parity of the wave's columns, li = slot inside the parity class
+        if (PAR) {   // wave_n = parity of the wave's columns, li = slot inside the parity class
             if (Tout >= BN) {
                 bl = 0;
                 t = q.t0 + 2 * li + wave_n;
@@ -214,9 +204,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             t = n - bl * Tout;
             v = (bl < q.SPT) && (q.b0 + bl < a.B);
         }
-        colb[wn] = q.b0 + bl;
-        colt[wn] = t;
-        colv[wn] = v;
+        colb = q.b0 + bl;
+        colt = t;
+        colv = v;
         int base = q.ROWDATA, bL = q.ROWDATA, bR = q.ROWDATA;
         if (v) {
             if (a.mode == 0) {
@@ -229,63 +219,61 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
                 }
             }
         }
-        cb[wn] = base;
-        cbl[wn] = bL;
-        cbr[wn] = bR;
+        cb4 = 4 * base;
+        cbl4 = 4 * bL;
+        cbr4 = 4 * bR;
     }
 
-    f32x16 acc[WM][WN];
+    f32x16 acc[WM];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < WN; ++wn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[wm][r] = 0.f;
 
     const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
-    const int nj = (ROW + 63) >> 6;
+    const int nj = (ROW + 15) >> 4;
 
     // reflect-adjoint windows are needed only by waves that own a column within pad of a sample edge
     bool use_mirror = false;
     const bool one_window = Tout >= 2 * (padL + padR) + 2;   // left-edge columns [1, padL] and right-edge columns [Tout-1-padR, Tout-2] are disjoint
     if (MIRROR) {
-        bool mine = false;
-#pragma unroll
-        for (int wn = 0; wn < WN; ++wn) {
-            mine |= (cbl[wn] != q.ROWDATA) || (cbr[wn] != q.ROWDATA);
-            if (one_window && cbl[wn] == q.ROWDATA) cbl[wn] = cbr[wn];   // the column's only mirror window
-        }
+        const bool mine = (cbl4 != 4 * q.ROWDATA) || (cbr4 != 4 * q.ROWDATA);
+        if (one_window && cbl4 == 4 * q.ROWDATA) cbl4 = cbr4;   // the column's only mirror window
         use_mirror = __any(mine);
     }
 
     __syncthreads();  // zero fill done before the first DMA lands
 
-    // weights: packed image == LDS image -> direct global->LDS DMA, 16 B per lane, no staging registers
+    // weights: packed image == LDS image -> direct global->LDS DMA, 16 B per lane, no staging registers.
+    // Piece = 64 rows x 4 k-steps of one (tap, unit, h) plane.
     auto load_a = [&](int chunk, int buf) {
-        const float* wsrc = g.wp + (long)chunk * KS * CK * a.Mp + m_tile0;
+        const float* wsrc = g.wp + (long)chunk * KS * CK * a.Mp + (long)m_tile0 * 4 + lane * 4;
         float* Ad = As + buf * AS;
         for (int piece = wave; piece < npieces; piece += 4) {
-            int f = piece * 256 + lane * 4;
-            int row = f / BM, col = f - row * BM;
-            avc_glds16(wsrc + (long)row * a.Mp + col, Ad + piece * 256);
+            const int plane = WM == 1 ? piece : piece >> 1, sub = WM == 1 ? 0 : piece & 1;
+            avc_glds16(wsrc + (long)plane * a.Mp * 4 + sub * 256, Ad + piece * 256);
         }
     };
-    // source tile: wave w stages rows w, w+4, ... of the chunk, 64 positions per DMA instruction
+    // source tile: this wave's position groups of its planes (see xo above)
+    const int njw = (nj - jpar + 1) >> 1;   // position groups j = 2 jj + jpar < nj
     auto load_x = [&](int chunk, int buf) {
-        float* Xd = Xs + buf * XS;
-        for (int r = wave; r < CK; r += 4) {
-            const int c = chunk * CK + r;
-            if (c < a.Cred) {
-                const long coff = (a.x.ps == 1) ? (long)c * a.x.sc : (long)(c / a.x.ps) * a.x.sc + (c % a.x.ps);
-                const float* src = a.x.ptr + coff;
-#pragma unroll
-                for (int j = 0; j < AVC_CONV_NJ; ++j)
-                    if (j < nj && xoff[j] >= 0) avc_glds4(src + xoff[j], Xd + r * ROW + 64 * j);
-            } else {  // channel padding of the last chunk
-#pragma unroll
-                for (int j = 0; j < AVC_CONV_NJ; ++j)
-                    if (j < nj && 64 * j + lane < ROW) Xd[r * ROW + 64 * j + lane] = 0.f;
+        float* Xd = Xs + buf * XS + 64 * jpar;
+        const int c_chunk = chunk * CK;
+        for (int pl = wave & 1; pl < 2 * GR; pl += 2) {
+            const int c0 = c_chunk + 8 * (pl >> 1), hh = pl & 1;
+            if (c0 >= a.Cred) break;   // channel padding of the last chunk: the weight image holds zeros there, the (finite) stale tile is harmless
+            const long pbase = (a.x.ps == 1) ? (long)(c0 + hh) * a.x.sc : (long)(c0 >> 1) * a.x.sc + hh;
+            long fix = 0;   // a unit that straddles Cred: lanes past the last channel read the last valid one (times zero weights)
+            if (c0 + 8 > a.Cred) {
+                int c = c0 + 2 * ul + hh;
+                c = c < a.Cred ? c : a.Cred - 1;
+                fix = ((a.x.ps == 1) ? (long)c * a.x.sc : (long)(c >> 1) * a.x.sc + (c & 1)) - (pbase + lu);
             }
+            const float* src = a.x.ptr + pbase + fix;
+            float* dst = Xd + pl * ROW * 4;
+#pragma unroll
+            for (int jj = 0; jj < AVC_CONV_NJ4 / 2; ++jj)
+                if (jj < njw && xo[jj] >= 0) avc_glds4(src + xo[jj], dst + 128 * jj);
         }
     };
 
@@ -295,7 +283,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     }
     __syncthreads();
 
-    const int a_lane = wave_m * (32 * WM) + li;
+    const int a_lane4 = (wave_m * (32 * WM) + li) * 4;
     const int nit = (nchunk + KG - 1) / KG;
     for (int it = 0; it < nit; ++it) {
         const int chunk = it * KG + kg;
@@ -309,145 +297,70 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         if ((a.dbg & 2) || chunk >= nchunk) {
         } else if constexpr (PAR) {   // even columns: taps 0, 2, 4; odd columns: taps 1, 3 (k = 5, padL = 2)
             if (wave_n == 0) {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             } else {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
-                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, WN, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if (MIRROR && use_mirror)
-            conv_chunk_mma<WM, WN, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if constexpr (KSC < 0) {
             // grouped launch of layers with different tap counts (the conv bank, k = 1..8): the workgroup's (taps,
             // chunk depth) pair is uniform, so each pair gets its own straight-line chunk
-            switch (KS * 8 + (CK >> 3)) {
-                case 1 * 8 + 4: conv_chunk_mma<WM, WN, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 2 * 8 + 2: conv_chunk_mma<WM, WN, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 3 * 8 + 2: conv_chunk_mma<WM, WN, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 4 * 8 + 1: conv_chunk_mma<WM, WN, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 5 * 8 + 1: conv_chunk_mma<WM, WN, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 6 * 8 + 1: conv_chunk_mma<WM, WN, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 7 * 8 + 1: conv_chunk_mma<WM, WN, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                case 8 * 8 + 1: conv_chunk_mma<WM, WN, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr); break;
-                default: conv_chunk_mma<WM, WN, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            switch (KS * 8 + GR) {
+                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else
-            conv_chunk_mma<WM, WN, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane, cb, cbl, cbr);
+            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         if (!(a.dbg & 4)) __syncthreads();
     }
 
     if (KG > 1) {  // fixed-order sum of the groups' partial tiles through the (now free) stage memory
-        float* red = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (WM * WN * 16 * 64) + lane;
+        float* red = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (WM * 16 * 64) + lane;
         if (kg > 0) {
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((wm * WN + wn) * 16 + r) * 64] = acc[wm][wn][r];
+                for (int r = 0; r < 16; ++r) red[(wm * 16 + r) * 64] = acc[wm][r];
         }
         __syncthreads();
         if (kg > 0) return;
 #pragma unroll
         for (int k2 = 1; k2 < KG; ++k2) {
-            const float* rk = smem + ((k2 - 1) * 4 + wave) * (WM * WN * 16 * 64) + lane;
+            const float* rk = smem + ((k2 - 1) * 4 + wave) * (WM * 16 * 64) + lane;
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[wm][wn][r] += rk[((wm * WN + wn) * 16 + r) * 64];
+                for (int r = 0; r < 16; ++r) acc[wm][r] += rk[(wm * 16 + r) * 64];
         }
     }
 
     // ---- epilogue
     if (a.dbg & 8) return;
-    if constexpr (INF && WM == 1 && WN == 1) {  // (its own instantiation: the row statistics cost ~90 registers)
-        {
-            // Fused InstanceNorm (+ AdaIN affine + ReLU + residual): the tile holds whole (b, m) rows
-            // (Tout = 16 / 32: inside one wave's 32 columns; 64: the two wave_n halves, joined through LDS).
-            // Two-pass statistics like the row kernel; the normalise step is the shared in_xhat / in_preact.
-            const bool v = colv[0];
-            const int b = colb[0], t = colt[0];
-            const int G = Tout < 32 ? Tout : 32;
-            const float invT = 1.0f / (float)Tout;
-            float* red = smem + KG * 4 * 1024;  // behind the split-K exchange area: [pass][wave_m][wave_n][32 rows]
-            float val[16], mean[16], rstd[16];
-            auto row_total = [&](float (&x)[16], int pass) {
+    if (!colv) return;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = x[r];
-                    for (int o = G >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-                    x[r] = s;
-                }
-                if (Tout == 64) {
-                    float* rp = red + pass * 128 + wave_m * 64;
-                    if (li == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rp[wave_n * 32 + h * 16 + r] = x[r];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) x[r] = rp[h * 16 + r] + rp[32 + h * 16 + r];
-                }
-            };
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_tile0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                val[r] = acc[0][0][r] + ((g.bias && m < a.M) ? g.bias[m] : 0.f);
-                mean[r] = v ? val[r] : 0.f;
-            }
-            row_total(mean, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                mean[r] *= invT;
-                const float d = v ? val[r] - mean[r] : 0.f;
-                rstd[r] = d * d;
-            }
-            row_total(rstd, 1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rstd[r] = 1.0f / sqrtf(rstd[r] * invT + AVC_IN_EPS);  // biased variance
-            if (!v) return;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_tile0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= a.M) continue;
-                const long o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
-                g.out[o] = val[r];
-                float gamma = 1.f, beta = 0.f;
-                if (a.in_cond) {
-                    const float* cr = a.in_cond + (long)b * a.in_cond_sb + a.in_cond_off;
-                    beta = cr[m];
-                    gamma = cr[a.in_C + m];
-                }
-                float w = fmaxf(in_preact(in_xhat(val[r], mean[r], rstd[r]), gamma, beta), 0.f);
-                if (a.res_mode != AVC_RES_NONE) w += conv_load_res(a, g.res, b, m, t);
-                a.in_out[o] = w;
-                if (t == 0) {
-                    a.in_mean[(long)b * a.in_C + m] = mean[r];
-                    a.in_rstd[(long)b * a.in_C + m] = rstd[r];
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int wn = 0; wn < WN; ++wn) {
-        if (!colv[wn]) continue;
-#pragma unroll
-        for (int wm = 0; wm < WM; ++wm)
-            conv_store_frag(a, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
-    }
+    for (int wm = 0; wm < WM; ++wm) conv_store_frag(a, g, acc[wm], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb, colt);
 }
 
 // --------------------------------------------------------------------------
-// weight packing: W[Cout][Cin][KS] (state_dict layout) -> LDS-image order
-//   fwd  : Wp[chunk][j][r][m]  = W[m][chunk*CK + r][j]
-//   dgrad: Wp[chunk][j][r][m]  = W[chunk*CK + r][m][KS-1-j]   (transposed, tap-flipped)
+// weight packing: W[Cout][Cin][KS] (state_dict layout) -> LDS-image order.  With red = chunk*CK + r the reduction
+// channel, m the output row, j the tap:
+//   AVC_IMG_PLAIN  Wp[chunk][j][r][m]
+//   AVC_IMG_K4     Wp[chunk][j][unit][h][m][u],  r = 8 unit + 2 u + h      (conv_gemm.hip: 16-byte fragments)
+//   value: fwd  W[m][red][j];  dgrad  W[red][m][KS-1-j]   (transposed, tap-flipped)
 // Several source tensors of identical shape can be stacked along the forward
 // output-channel axis (the 12 AdaIN affine Linears, the mu/log_sigma heads).
 // --------------------------------------------------------------------------
@@ -468,39 +381,34 @@ __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs
 }
 
 static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride) {
-    if (p.rs == 2) {
+    if (p.img == AVC_IMG_X3) {
         avc_pack_x3_one(p, first, stride);
         return;
     }
-    if (p.rs) {  // register-stationary image (conv_rs.hip): ks = 4q + u = c2 * KS + j, c = 2 * c2 + (lane >> 5), m = 32 * slab + (lane & 31)
-        const long total = (long)p.rs_nslab * p.rs_nq * 256;
-        const int M = p.dgrad ? p.Cin : p.Cout, Cred = p.dgrad ? p.Cout : p.Cin;
-        const int NKS = p.KS * ((Cred + 1) / 2);
-        const float* w = p.src[0];
-        for (long e = first; e < total + 128; e += stride) {
-            float v = 0.f;   // (the last 128 floats: the zero block the DMA reads structural zeros from)
-            if (e < total) {
-                const int u = (int)(e & 3), lane = (int)((e >> 2) & 63);
-                const long rest = e >> 8;
-                const int q = (int)(rest % p.rs_nq), slab = (int)(rest / p.rs_nq);
-                const int ks = 4 * q + u;
-                const int c2 = ks / p.KS, j = ks - c2 * p.KS;
-                const int c = 2 * c2 + (lane >> 5), m = 32 * slab + (lane & 31);
-                if (ks < NKS && m < M && c < Cred)
-                    v = p.dgrad ? w[((long)c * p.Cin + m) * p.KS + (p.KS - 1 - j)] : w[((long)m * p.Cin + c) * p.KS + j];
-            }
-            p.dst[e] = v;
-        }
-        return;
-    }
     long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
+    const int GR = p.CK >> 3;
     for (long e = first; e < total; e += stride) {
-        int m = (int)(e % p.Mp);
-        long rest = e / p.Mp;
-        int r = (int)(rest % p.CK);
-        rest /= p.CK;
-        int j = (int)(rest % p.KS);
-        int chunk = (int)(rest / p.KS);
+        int m, r, j, chunk;
+        if (p.img == AVC_IMG_K4) {
+            const int u = (int)(e & 3);
+            long rest = e >> 2;
+            m = (int)(rest % p.Mp);
+            rest /= p.Mp;
+            const int h = (int)(rest & 1);
+            rest >>= 1;
+            const int unit = (int)(rest % GR);
+            rest /= GR;
+            j = (int)(rest % p.KS);
+            chunk = (int)(rest / p.KS);
+            r = 8 * unit + 2 * u + h;
+        } else {
+            m = (int)(e % p.Mp);
+            long rest = e / p.Mp;
+            r = (int)(rest % p.CK);
+            rest /= p.CK;
+            j = (int)(rest % p.KS);
+            chunk = (int)(rest / p.KS);
+        }
         int red = chunk * p.CK + r;
         float v = 0.f;
         if (!p.dgrad) {
@@ -521,53 +429,41 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
-static int g_conv_ck5 = 8;  // chunk depth of the k >= 4 layers at the op level (micro-benchmark knob, avc_set_tuning)
-void avc_set_conv_ck5(int ck) { g_conv_ck5 = (ck == 8 || ck == 16 || ck == 32) ? ck : 8; }
-extern "C" int avc_conv_ck(int KS) { return KS >= 4 ? g_conv_ck5 : (KS >= 2 ? 16 : 32); }
-
-// launch-heuristic thresholds (avc_set_tuning "tile_thr11" / "tile_thr21" / "ck16_wgs" / "ck32_wgs" / "kg_wgs"; measured defaults)
-static long g_tile_thr11 = 8192, g_tile_thr21 = 4096, g_ck16_wgs = 256, g_ck32_wgs = 256, g_kg_wgs = 256;   // r2 sweep (profiles/r02_tune_sweeps.log)
-void avc_set_conv_heuristic(int which, long v) {
-    if (which == 0) g_tile_thr11 = v;
-    if (which == 1) g_tile_thr21 = v;
-    if (which == 2) g_ck16_wgs = v;
-    if (which == 3) g_ck32_wgs = v;
-    if (which == 4) g_kg_wgs = v;
+int avc_conv_ck(const avc_tuning& tun, int KS) {
+    const int ck5 = (tun.conv_ck5 == 16 || tun.conv_ck5 == 32) ? tun.conv_ck5 : 8;
+    return KS >= 4 ? ck5 : (KS >= 2 ? 16 : 32);
 }
-// tile choice shared by the launcher and the plan (which sizes CK from it)
-int avc_conv_pick_tile(int Mp, int B, int Tout, int ngroups, int Kred) {
-    // measured on MI355X (profiles/r01_conv_micro_*.log): at equal work the 64x64 tile beats 128x64
-    // and 128x128 (more resident waves hide the per-chunk LDS/DMA latency; the fp32 MFMA needs no
-    // bigger tile for operand reuse), so take the smallest tile unless the grid gets very large
+
+// tile choice shared by the launcher and the plan (which sizes CK from it): 11 = 64 rows x 64 columns, 21 = 128 x 64
+int avc_conv_pick_tile(const avc_tuning& tun, int Mp, int B, int Tout, int ngroups, int Kred) {
+    // measured on MI355X (profiles/r01_conv_micro_*.log): at equal work the 64x64 tile beats 128x64 (more resident waves hide
+    // the per-chunk LDS/DMA latency; the fp32 MFMA needs no bigger tile for operand reuse), so take the smallest tile unless
+    // the grid gets very large.  (A 128x128 tile existed through round 2; no graded configuration selected it.)
     auto ntn = [&](int BN) { return Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout); };
     long t11 = (long)(Mp / 64) * ntn(64) * ngroups;
-    long t21 = (long)(Mp / 128) * ntn(64) * ngroups;
     // r2 sweeps (profiles/r02_tune_sweeps.log): launches whose workgroups carry little reduction work -- the grouped bank
     // (k = 1..8 over 80 mel rows) and 1x1 convs over <= 256 channels -- keep gaining from 64x64 tiles up to ~8k
     // workgroups (their cost is the epilogue: more, smaller workgroups overlap it better); the k = 5, 128-channel convs
     // switch to 128x64 beyond ~4k (B = 1024 inference: 7.54 vs 7.66 ms)
-    const long thr11 = (ngroups > 1 || (Kred > 0 && Kred <= 256)) ? g_tile_thr11 : (g_tile_thr11 < 4095 ? g_tile_thr11 : 4095);
-    if (t11 <= thr11) return 11;
-    if (t21 <= g_tile_thr21) return 21;
-    return 22;
+    const long thr11 = (ngroups > 1 || (Kred > 0 && Kred <= 256)) ? tun.tile_thr11 : (tun.tile_thr11 < 4095 ? tun.tile_thr11 : 4095);
+    return t11 <= thr11 ? 11 : 21;
 }
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
-    int BM = (tile / 10 == 1) ? 64 : 128, BN = (tile % 10 == 1) ? 64 : 128;
+    int BM = (tile / 10 == 1) ? 64 : 128, BN = 64;
     long ntn = Tout >= BN ? (long)B * avc_cdiv(Tout, BN) : (long)avc_cdiv(B, BN / Tout);
     return (long)(Mp / BM) * ntn * ngroups;
 }
 // K-chunk depth: layers that cannot put two workgroups on every CU are latency-bound per chunk
 // (global -> LDS round trip vs. ~1.3k MFMA cycles), so they take twice the channels per chunk
-int avc_conv_ck_for(int KS, long wgs, int mode, int stride, int Tout, int tile) {
-    int ck = avc_conv_ck(KS);
-    if (KS >= 4 && wgs <= g_ck16_wgs) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
-        int BN = (tile % 10 == 1) ? 64 : 128;
-        ConvGeom q = conv_geom(mode, stride, Tout, KS, BN, 0);
-        if (q.ROW <= 64 * AVC_CONV_NJ) ck = 16;
+int avc_conv_ck_for(const avc_tuning& tun, int KS, long wgs, int mode, int stride, int Tout, int tile) {
+    int ck = avc_conv_ck(tun, KS);
+    if (KS >= 4 && wgs <= tun.ck16_wgs) {  // measured (r1 conv micro): CK=16 wins up to 2 workgroups per CU, loses beyond
+        ConvGeom q = conv_geom(mode, stride, Tout, KS, 64, 0);
+        if (q.ROW <= 16 * AVC_CONV_NJ4) ck = 16;
         // at most one workgroup per CU: the forward kernel gains another ~6 % from four chunks of 32
         // (r1 sweep: T_l = 16/32 forward 26.0 -> 24.5 us; the dgrad variant does not move)
         int BM = (tile / 10 == 1) ? 64 : 128;
-        if (KS == 5 && mode == 0 && wgs <= g_ck32_wgs && tile != 11 && q.ROW <= 64 * AVC_CONV_NJ && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
+        if (KS == 5 && mode == 0 && wgs <= tun.ck32_wgs && tile != 11 && q.ROW <= 16 * AVC_CONV_NJ4 && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
     }
     return ck;
 }
@@ -585,83 +481,62 @@ static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
 
 static int conv_ntiles_n(const ConvArgs& a, int BN) {
     if (a.Tout >= BN) return a.B * avc_cdiv(a.Tout, BN);
-    int spt = BN / a.Tout;
-    return avc_cdiv(a.B, spt);
+    int worst = 1;   // (the groups of a grouped launch may fit different numbers of short samples into a tile)
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        const int n = avc_cdiv(a.B, conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0).SPT);
+        worst = n > worst ? n : worst;
+    }
+    return worst;
 }
 
-template <int KG, bool BF>
-static void conv_launch_infuse(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
-    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, BF, true>), grid, block, lds, stream, a);
-}
-
-template <int WM, int WN, int KG, bool BF>
+template <int WM, int KG, bool BF>
 static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
-    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
-    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, 0, 0, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
-    else if (fast == -1 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, -1, 0, 1, BF>), grid, block, lds, stream, a);
-    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 1, 4, KG, BF>), grid, block, lds, stream, a);   // 1x1, 32-channel chunks
-    else hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 0, 0, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == -1 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, -1, 0, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 1, 4, KG, BF>), grid, block, lds, stream, a);   // 1x1, 32-channel chunks
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
 }
 
 // stride-2 dgrad with one column parity per wave (half the MFMAs of the zero-upsampled correlation)
 template <int KG, bool BF>
 static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, false, true>), grid, block, lds, stream, a);
-    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, false, true>), grid, block, lds, stream, a);
-    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, false, true>), grid, block, lds, stream, a);
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, true, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, true, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
 }
-static int g_dgrad_par = 1;   // avc_set_tuning("dgrad_par", 0): stride-2 dgrad multiplies all five taps of the zero-upsampled dy
-void avc_set_dgrad_par(int on) { g_dgrad_par = on ? 1 : 0; }
-
-static int g_bank_switch = 1;   // avc_set_tuning("bank_switch", 0): the grouped bank launch on the generic (run-time taps) chunk loop
-void avc_set_bank_switch(int on) { g_bank_switch = on ? 1 : 0; }
-
-// ablation bits of scripts/conv_ablate.py (timing experiments; results are wrong by construction when set)
-static int g_conv_ablation = 0;
-void avc_set_conv_ablation(int bits) { g_conv_ablation = bits; }
-int avc_conv_ablation_bits() { return g_conv_ablation; }
 
 // returns 0 on success, negative on unsupported geometry
-int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
-    if (a_in.rs == 2 || force_tile == 97) return avc_launch_conv_x3(a_in, stream);
-    if (a_in.rs || force_tile == 99) return avc_launch_conv_rs(a_in, stream);
-    if ((force_tile == 0 || force_tile == 98) && !g_conv_ablation && avc_conv_small_eligible(a_in, force_tile == 98)) return avc_launch_conv_small(a_in, stream);
-    if (force_tile == 98) return -8;
+int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, const avc_tuning& tun) {
+    if (a_in.img == AVC_IMG_X3 || force_tile == 97) return avc_launch_conv_x3(a_in, stream, tun);
     ConvArgs a = a_in;
-    a.dbg = g_conv_ablation;
+    a.dbg = tun.conv_ablation;
     if (a.ngroups < 1 || a.ngroups > AVC_MAX_GROUPS) return -1;
     if (a.Mp % 128 != 0) return -2;
+    if (a.x.ps != 1 && a.x.ps != 2) return -2;   // (pixel-unshuffled dy views of the decoder: upsample factors are 1 or 2)
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
-    int tile = force_tile == 12 ? 11 : force_tile;  // (the 64x128 tile measured no better than 64x64 and was dropped)
-    if (tile == 0) tile = avc_conv_pick_tile(a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
-    int BM = (tile / 10 == 1) ? 64 : 128;
-    int BN = (tile % 10 == 1) ? 64 : 128;
+    int tile = (force_tile == 12 || force_tile == 22) ? 21 : force_tile;  // (64x128 / 128x128 tiles were measured no better and dropped)
+    if (tile == 98) return -8;   // (round 2's one-shot short-row kernel; gone)
+    if (tile == 0) tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
+    if (tile != 11 && tile != 21) return -2;
+    const int BM = (tile == 11) ? 64 : 128, BN = 64;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         if (a.g[gi].CK % 8 != 0) return -2;
-        if (q.ROW > 64 * AVC_CONV_NJ) return -3;
+        if (q.ROW > 16 * AVC_CONV_NJ4) return -3;
     }
-    if (a.in_fuse && !(tile == 11 && a.mode == 0 && a.ops == 1 && a.ngroups == 1 && a.ot == 1 && (a.Tout == 16 || a.Tout == 32 || a.Tout == 64) &&
-                       a.g[0].out && a.in_out && a.in_mean && a.in_rstd))
-        return -7;
     size_t lds = conv_lds_bytes(a, BM, BN);
     dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
     // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
     int kgroups = 1;
-    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= g_kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
+    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
-    if (a.in_fuse) {  // row-statistics exchange area behind the split-K exchange area
-        size_t need = ((size_t)kgroups * 4096 + 256) * 4;
-        lds = lds > need ? lds : need;
-    }
     if (lds > 160 * 1024) return -5;
     dim3 block(AVC_THREADS * kgroups);
     double flops = 0;
@@ -671,34 +546,29 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile) {
     const bool mir = a.mode == 1 && a.mirror;
     // the model's kernel_size (5) with the chunk depths the plan uses gets straight-line chunks
     const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0)))
-                     : ((a.ngroups > 1 && a.mode == 0 && g_bank_switch) ? -1
-                        : ((a.ngroups == 1 && a.g[0].KS == 1 && a.g[0].CK == 32 && g_bank_switch) ? 14 : 0));
+                     : ((a.ngroups > 1 && a.mode == 0 && tun.bank_switch) ? -1
+                        : ((a.ngroups == 1 && a.g[0].KS == 1 && a.g[0].CK == 32 && tun.bank_switch) ? 14 : 0));
     const bool bf = a.bf16 == AVC_COMPUTE_BF16;
-    a.par = g_dgrad_par && a.mode == 1 && a.stride == 2 && tile == 11 && a.ngroups == 1 && (fast == 1 || fast == 2) && !a.in_fuse && !a.dbg &&
+    a.par = tun.dgrad_par && a.mode == 1 && a.stride == 2 && tile == 11 && a.ngroups == 1 && (fast == 1 || fast == 2) && !a.dbg &&
             a.g[0].padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
-#define AVC_LAUNCH_CONV(WM_, WN_, KG_)                                                                             \
-    do {                                                                                                           \
-        if (bf) conv_launch_variant<WM_, WN_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
-        else conv_launch_variant<WM_, WN_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
+#define AVC_LAUNCH_CONV(WM_, KG_)                                                                             \
+    do {                                                                                                      \
+        if (bf) conv_launch_variant<WM_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
+        else conv_launch_variant<WM_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
     } while (0)
     if (a.par) {
         if (kgroups == 2) { if (bf) conv_launch_par<2, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<2, false>(a, mir, fast, grid, block, lds, stream); }
         else { if (bf) conv_launch_par<1, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<1, false>(a, mir, fast, grid, block, lds, stream); }
-    } else if (a.in_fuse) {  // (validated above: 64x64 tile, forward)
-        const int f = fast == 4 ? 0 : fast;
-        if (kgroups == 2) { if (bf) conv_launch_infuse<2, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<2, false>(a, f, grid, block, lds, stream); }
-        else { if (bf) conv_launch_infuse<1, true>(a, f, grid, block, lds, stream); else conv_launch_infuse<1, false>(a, f, grid, block, lds, stream); }
-    } else if (tile == 22) AVC_LAUNCH_CONV(2, 2, 1);
-    else if (tile == 21) AVC_LAUNCH_CONV(2, 1, 1);
-    else if (kgroups == 2) AVC_LAUNCH_CONV(1, 1, 2);
-    else AVC_LAUNCH_CONV(1, 1, 1);
+    } else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
+    else if (kgroups == 2) AVC_LAUNCH_CONV(1, 2);
+    else AVC_LAUNCH_CONV(1, 1);
 #undef AVC_LAUNCH_CONV
     return (int)hipGetLastError();
 }
 
 long avc_pack_total(const PackArgs& p) {
-    if (p.rs == 2) return (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
-    return p.rs ? (long)p.rs_nslab * p.rs_nq * 256 + 128 : (long)p.nchunk * p.KS * p.CK * p.Mp;
+    if (p.img == AVC_IMG_X3) return (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
+    return (long)p.nchunk * p.KS * p.CK * p.Mp;
 }
 
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {

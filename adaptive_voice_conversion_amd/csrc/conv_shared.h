@@ -2,7 +2,9 @@
 #pragma once
 #include "avc_common.h"
 
-#define AVC_CONV_NJ 6   // source-tile rows of up to 384 positions
+#define AVC_CONV_NJ 6   // source-tile rows of up to 384 positions (conv_x3.hip: 64 positions per LDS-DMA instruction)
+#define AVC_CONV_NJ4 10  // conv_gemm.hip: 16 positions x 4 k-steps per LDS-DMA instruction
+#define AVC_CONV_MAXROW4 (16 * AVC_CONV_NJ4)
 
 struct ConvGeom {
     int b0, t0, SPT, ncols, SEG, seg_p0, ROWDATA, ROW;
@@ -18,6 +20,12 @@ static inline __host__ __device__ ConvGeom conv_geom(int mode, int stride, int T
         q.ncols = BN;
     } else {
         q.SPT = BN / Tout;
+        if (BN == 64) {   // conv_gemm.hip keeps ROW / 16 per-lane source offsets in registers: very short rows (T_l < 8, the
+                          // bottleneck of 17..63-frame utterances) take fewer samples per tile instead of a longer LDS row
+            const int seg = (mode == 0) ? (Tout - 1) * stride + KS : Tout + 3 * (KS - 1);
+            const int fit = (AVC_CONV_MAXROW4 - KS) / seg;
+            q.SPT = q.SPT < fit ? q.SPT : (fit < 1 ? 1 : fit);
+        }
         q.b0 = tile * q.SPT;
         q.t0 = 0;
         q.ncols = Tout;

@@ -472,10 +472,6 @@ static WgradKey wgrad_key(const WgradArgs& a) {
     return k;
 }
 
-static int g_wgrad_target_wgs = 256;  // workgroups per launch the split-K aims for (avc_set_tuning)
-void avc_set_wgrad_target_wgs(int n) { g_wgrad_target_wgs = n >= 1 ? n : 256; }
-int avc_wgrad_target_wgs() { return g_wgrad_target_wgs; }
-
 // K-chunk geometry of one layer (32 columns of the (b, t) axis per chunk; short samples are packed)
 void avc_wgrad_geometry(WgradArgs& a) {
     if (a.Tout >= 32) {
@@ -500,7 +496,7 @@ void avc_wgrad_geometry(WgradArgs& a) {
 // chosen so that the launch has about `target_wgs` workgroups, but at least 4 chunks (128 columns) per
 // workgroup so that the slab write + fixed-order reduce stay a small fraction of the work.
 void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
-    if (target_wgs < 1) target_wgs = g_wgrad_target_wgs;
+    if (target_wgs < 1) target_wgs = 256;
     for (int i = 0; i < n; ++i) avc_wgrad_geometry(L[i]);
     std::vector<char> done((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
@@ -529,12 +525,12 @@ void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
     }
 }
 
-void avc_wgrad_plan(int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
+void avc_wgrad_plan(const avc_tuning& tun, int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
                     int* chunks_per_wg, int* nsplit) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tout = Tout; a.KS = KS; a.stride = 1;
-    avc_wgrad_plan_batch(&a, 1, g_wgrad_target_wgs);
+    avc_wgrad_plan_batch(&a, 1, tun.wgrad_target_wgs);
     *Tc = a.Tc; *spc = a.spc; *chunks_per_sample = a.chunks_per_sample; *total_chunks = a.total_chunks;
     *chunks_per_wg = a.chunks_per_wg; *nsplit = a.nsplit;
 }
@@ -566,13 +562,10 @@ static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& 
                       : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream);
 }
 
-// ablation bits of scripts/wgrad_ablate.py (timing experiments; results are wrong by construction when set)
-static int g_wgrad_ablation = 0;
-void avc_set_wgrad_ablation(int bits) { g_wgrad_ablation = bits; }
-
 // launches every layer of the batch (planned by avc_wgrad_plan_batch, slabs assigned): one launch per kernel
 // instance present, <= AVC_WGRAD_MAXL layers per launch
-int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream) {
+// ablation: timing-experiment bits of scripts/wgrad_ablate.py (results are wrong by construction when set)
+int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ablation) {
     std::vector<char> done((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
@@ -581,7 +574,7 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream) {
         const WgradKey k = wgrad_key(a0);
         WgradBatch bt;
         memset(&bt, 0, sizeof(bt));
-        bt.dbg = g_wgrad_ablation;
+        bt.dbg = ablation;
         int wgs = 0;
         size_t lds = 0;
         double flops = 0;
@@ -614,11 +607,6 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream) {
         // (layers of this key beyond AVC_WGRAD_MAXL stay !done and open their own launch when the outer loop reaches them)
     }
     return 0;
-}
-
-int avc_launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t stream) {
-    (void)nsplit;
-    return avc_launch_wgrad_batch(&a, 1, stream);
 }
 
 int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {

@@ -216,9 +216,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
 }
 
 // --------------------------------------------------------------------------
-static int g_conv_x3 = 0;   // avc_set_tuning("conv_x3", 1): plans created while it is 1 run their big k = 5 layers on this kernel
-void avc_set_conv_x3(int on) { g_conv_x3 = on; }   // 2: every layer of an eligible shape, whatever its size (tests)
-
+// avc_tuning.conv_x3: 1 = the big k = 5 layers of a plan run on this kernel, 2 = every layer of an eligible shape, whatever its size (tests)
 static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
     if (KS == 1) {   // 1x1 conv / Linear over time: 32-channel chunks, the last one zero-padded by the image
         if (Cred < 32 || stride != 1) return false;
@@ -230,11 +228,11 @@ static bool x3_shape_ok(int mode, int Cred, int KS, int stride, int Tout) {
 }
 // a plan layer takes this kernel when the launch fills the chip with 64 x 128 tiles (measured: 256 workgroups still win,
 // 128 lose to the exact-fp32 kernel, profiles/r02_conv_micro_x3.log)
-bool avc_conv_x3_eligible(int mode, int Cred, int KS, int stride, int Tout, int B, int M) {
-    if (!g_conv_x3 || !x3_shape_ok(mode, Cred, KS, stride, Tout)) return false;
+bool avc_conv_x3_eligible(const avc_tuning& tun, int mode, int Cred, int KS, int stride, int Tout, int B, int M) {
+    if (!tun.conv_x3 || !x3_shape_ok(mode, Cred, KS, stride, Tout)) return false;
     const long ntn = Tout >= 128 ? (long)B * avc_cdiv(Tout, 128) : avc_cdiv(B, 128 / Tout);
     // (the input-gradient launches carry the mask / residual-join epilogue: in the engine they win only from 512 workgroups on)
-    return g_conv_x3 >= 2 || ntn * (avc_cdiv(M, 128) * 2) >= (mode == 1 ? 512 : 256);
+    return tun.conv_x3 >= 2 || ntn * (avc_cdiv(M, 128) * 2) >= (mode == 1 ? 512 : 256);
 }
 long avc_conv_x3_image_floats(int M, int Cred, int KS) { return (long)avc_cdiv(Cred, 16 * x3_kb(KS)) * x3_arows(KS) * (avc_cdiv(M, 128) * 128) * 4; }
 
@@ -248,13 +246,13 @@ void avc_pack_x3_args(PackArgs& p, const float* w, int Cout, int Cin, int KS, in
     p.CK = 16 * x3_kb(KS); p.nchunk = avc_cdiv(Cred, p.CK);
     p.M = M; p.Mp = avc_cdiv(M, 128) * 128;
     p.dst = dst;
-    p.rs = 2;
+    p.img = AVC_IMG_X3;
 }
 
-int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream) {
+int avc_launch_conv_x3(const ConvArgs& a_in, hipStream_t stream, const avc_tuning& tun) {
     ConvArgs a = a_in;
-    a.dbg = avc_conv_ablation_bits();
-    if (a.ngroups != 1 || a.in_fuse) return -1;
+    a.dbg = tun.conv_ablation;
+    if (a.ngroups != 1) return -1;
     const ConvGroup& g = a.g[0];
     if (!x3_shape_ok(a.mode, a.Cred, g.KS, a.stride, a.Tout) || g.CK != 16 * x3_kb(g.KS) || g.nchunk != avc_cdiv(a.Cred, g.CK) || a.Mp % 128 != 0) return -2;
     if (a.mode == 0 && (g.padL >= a.Tsrc || g.padR >= a.Tsrc)) return -6;

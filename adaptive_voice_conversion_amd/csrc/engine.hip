@@ -55,10 +55,10 @@ struct LayerP {
     long wpf = -1, wpd = -1, bpk = -1;
     int CK = 8, CKd = 8, nchunk_f = 0, nchunk_d = 0, Mp_f = 0, Mp_d = 0, dgM = 0;
     bool need_dgrad = true;
-    // register-stationary kernel (conv_rs.hip) for this layer's forward / input-gradient launch, and its images
-    bool rs_f = false, rs_d = false;
     bool x3_f = false, x3_d = false;   // split-bf16 kernel (conv_x3.hip): image at wrs_f / wrs_d, 16-channel chunks
     long wrs_f = -1, wrs_d = -1;
+    bool conv_path = true;             // launched through conv_gemm.hip (AVC_IMG_K4 images); false: the dense stack (AVC_IMG_PLAIN)
+    long wplain = -1;                  // extra AVC_IMG_PLAIN forward image (the affine layer: its d_emb GEMM reads it as a [Kp][Mp] matrix)
 };
 
 struct EncNet {
@@ -114,16 +114,13 @@ struct avc_plan {
     // streams beside the dgrad / InstanceNorm-backward chain of each branch
     mutable hipStream_t wstream[2] = {nullptr, nullptr};
     mutable std::vector<hipEvent_t> wev;   // sized by the dry run of the backward pass (one per ordering edge)
-    mutable hipEvent_t wjoin[2];
-    mutable hipEvent_t ev_pack[2];
+    mutable hipEvent_t wjoin[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_pack[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_dec_grads = nullptr;   // recorded when the decoder's parameter gradients are final
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
     int flags = 0;            // AVC_PLAN_*
-    int wgrad_batch = 12;      // weight gradients per batched launch (captured at plan creation: the dry run sizes slabs and events with it)
-    int wgrad_target = 256;   // workgroups a batched weight-gradient launch aims for
-    int wgrad_x3 = 0;         // split-bf16 products in the weight-gradient launches (avc_set_tuning("wgrad_x3", 1) at plan creation)
-    long wgrad_units = 1L << 40;  // pending (tile x K-chunk) units that trigger a launch before wgrad_batch layers are pending
+    avc_tuning tun;           // launch heuristics / diagnostic switches, captured at plan creation (the dry run sizes slabs and events with them)
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
 
@@ -165,27 +162,24 @@ static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool co
 }
 
 // Bn/Tf: batch and output length of the forward launch; Td: output length of the dgrad launch
-// rs_ps: pixel-(un)shuffle factor of the dy view the dgrad launch reads (0: never the register-stationary kernel)
-// conv_path: the layer is launched through avc_launch_conv (false: the dense stack, which reads the fp32 images in its own kernel)
-static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, int rs_ps = 1, bool conv_path = true) {
+// conv_path: the layer is launched through avc_launch_conv (false: the dense stack, which reads plain fp32 images in its own kernel)
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, bool conv_path = true) {
+    const avc_tuning& tun = p->tun;
+    L.conv_path = conv_path;
     L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
     L.Mp_d = avc_cdiv(L.dgM, 128) * 128;
-    int tf = avc_conv_pick_tile(L.Mp_f, Bn, Tf, ngroups, L.Cin * L.KS);
-    L.CK = avc_conv_ck_for(L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
-    int td = avc_conv_pick_tile(L.Mp_d, Bn, Td, 1, L.Cout * L.KS);
-    L.CKd = avc_conv_ck_for(L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
+    int tf = avc_conv_pick_tile(tun, L.Mp_f, Bn, Tf, ngroups, L.Cin * L.KS);
+    L.CK = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
+    int td = avc_conv_pick_tile(tun, L.Mp_d, Bn, Td, 1, L.Cout * L.KS);
+    L.CKd = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
     L.nchunk_f = avc_cdiv(L.Cin, L.CK);
     L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
-    L.rs_f = ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(0, L.Cin, L.KS, L.stride, Tf, 1);
-    L.rs_d = need_dgrad && ngroups == 1 && L.nsrc == 1 && rs_ps > 0 && avc_conv_rs_eligible(1, L.Cout, L.KS, L.stride, Td, rs_ps);
-    L.x3_f = conv_path && !L.rs_f && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
-    L.x3_d = conv_path && !L.rs_d && need_dgrad && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
+    L.x3_f = conv_path && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
+    L.x3_d = conv_path && need_dgrad && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
     if (L.x3_f) { L.CK = L.KS == 1 ? 32 : 16; L.nchunk_f = avc_cdiv(L.Cin, L.CK); }
     if (L.x3_d) { L.CKd = L.KS == 1 ? 32 : 16; L.nchunk_d = avc_cdiv(L.Cout, L.CKd); }
-    if (L.rs_f) L.wrs_f = p->alloc(avc_conv_rs_image_floats(L.Cout, L.Cin, L.KS));
-    if (L.rs_d) L.wrs_d = p->alloc(avc_conv_rs_image_floats(L.dgM, L.Cout, L.KS));
     if (L.x3_f) L.wrs_f = p->alloc(avc_conv_x3_image_floats(L.Cout, L.Cin, L.KS));
     if (L.x3_d) L.wrs_d = p->alloc(avc_conv_x3_image_floats(L.dgM, L.Cout, L.KS));
     L.wpf = p->alloc((long)L.nchunk_f * L.KS * L.CK * L.Mp_f);
@@ -233,16 +227,6 @@ static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, b
     }
 }
 
-static int g_wgrad_batch = 12, g_wgrad_batch_target = 256;
-static int g_wgrad_x3 = 0;
-void avc_set_wgrad_x3(int on) { g_wgrad_x3 = on ? 1 : 0; }
-int avc_wgrad_x3() { return g_wgrad_x3; }
-static long g_wgrad_units = 1L << 40;
-void avc_set_wgrad_units(long u) { g_wgrad_units = u > 0 ? u : (1L << 40); }  // defaults of new plans (avc_set_tuning "wgrad_batch" / "wgrad_batch_wgs")
-void avc_set_wgrad_batch(int layers, int target_wgs) {
-    if (layers >= 1) g_wgrad_batch = layers;
-    if (target_wgs >= 1) g_wgrad_batch_target = target_wgs;
-}
 static void plan_init_streams(avc_plan* p);
 
 extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan** out) {
@@ -250,8 +234,13 @@ extern "C" int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_con
 }
 
 extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, avc_plan** out) {
+    return avc_plan_create_tuned(cfg, B, T, T_cond, flags, nullptr, out);
+}
+
+extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out) {
     if (!cfg || !out || B < 1 || T < 1) return fail(-1, "avc_plan_create: bad arguments");
-    if (flags & ~(AVC_PLAN_INFERENCE | AVC_PLAN_SPEAKER_ONLY)) return fail(-1, "avc_plan_create_ex: unknown flag");
+    if (flags & ~(AVC_PLAN_INFERENCE | AVC_PLAN_SPEAKER_ONLY | AVC_PLAN_X3)) return fail(-1, "avc_plan_create: unknown flag");
+    if (tuning && tuning->struct_size != (int)sizeof(avc_tuning)) return fail(-1, "avc_plan_create_tuned: avc_tuning of another library version (use avc_tuning_init)");
     if (flags & AVC_PLAN_SPEAKER_ONLY) flags |= AVC_PLAN_INFERENCE;
     if (T_cond <= 0) T_cond = T;
     const bool infer = (flags & AVC_PLAN_INFERENCE) != 0, spk_only = (flags & AVC_PLAN_SPEAKER_ONLY) != 0;
@@ -267,10 +256,15 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
     avc_plan* p = new avc_plan();
     p->cfg = *cfg;
     p->flags = flags;
-    p->wgrad_batch = g_wgrad_batch;
-    p->wgrad_target = g_wgrad_batch_target;
-    p->wgrad_x3 = g_wgrad_x3;
-    p->wgrad_units = g_wgrad_units;
+    p->tun = tuning ? *tuning : avc_default_tuning();
+    if (p->tun.wgrad_batch < 1) p->tun.wgrad_batch = 1;
+    if (p->tun.wgrad_batch_wgs < 1) p->tun.wgrad_batch_wgs = 256;
+    if (p->tun.wgrad_batch_units < 1) p->tun.wgrad_batch_units = 1L << 40;
+    if (p->tun.dec_split_min < 2) p->tun.dec_split_min = 2;
+    if (flags & AVC_PLAN_X3) {   // compute mode "fp32x3" 
+        if (p->tun.conv_x3 < 1) p->tun.conv_x3 = 1;
+        p->tun.wgrad_x3 = 1;
+    }
     p->B = B;
     p->T = T;
     p->Tc = T_cond;
@@ -338,18 +332,22 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
         }
     }
     for (int l = 0; l < p->spk.nd; ++l) {
-        finish_layer(p, p->layers[p->spk.dn1[l]], dg, 0, 1, B, B, 1, 1, false);
-        finish_layer(p, p->layers[p->spk.dn2[l]], dg, 0, 1, B, B, 1, 1, false);
+        finish_layer(p, p->layers[p->spk.dn1[l]], dg, 0, 1, B, B, 1, false);
+        finish_layer(p, p->layers[p->spk.dn2[l]], dg, 0, 1, B, B, 1, false);
     }
-    finish_layer(p, p->layers[p->spk.outl], dg, 0, 1, B, B, 1, 1, false);
+    finish_layer(p, p->layers[p->spk.outl], dg, 0, 1, B, B, 1, false);
     if (!spk_only) {
         finish_layer(p, p->layers[p->enc.heads], dg, 0, B, p->Tb, p->Tb);
         finish_layer(p, p->layers[d.in_conv], dg, 0, B, p->Tb, p->Tb);
         for (int l = 0; l < d.n; ++l) {
             finish_layer(p, p->layers[d.c1[l]], dg, 0, B, d.T[l], d.T[l]);
-            finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l], 1, dc.upsample[l]);
+            finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l]);
         }
         finish_layer(p, p->layers[d.affine], dg, 0, 1, B, B);
+        if (dg) {   // d(emb) = W^T dcond runs through the weight-gradient kernel, which reads W as a plain [Kp][Mp] matrix
+            LayerP& La = p->layers[d.affine];
+            La.wplain = p->alloc((long)La.nchunk_f * La.CK * La.Mp_f);
+        }
         finish_layer(p, p->layers[d.out_conv], dg, 0, B, p->Tout, p->Tout);
     }
 
@@ -524,33 +522,29 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
 }
 
 extern "C" void avc_plan_destroy(avc_plan* p) {
-    if (p && p->side_state == 1) {
-        hipStreamDestroy(p->side);
-        hipEventDestroy(p->ev_fork);
-        hipEventDestroy(p->ev_join);
-        for (int i = 0; i < 2; ++i) {
-            hipStreamDestroy(p->wstream[i]);
-            hipEventDestroy(p->wjoin[i]);
-            hipEventDestroy(p->ev_pack[i]);
-        }
-        for (hipEvent_t e : p->wev) hipEventDestroy(e);
-        hipEventDestroy(p->ev_dec_grads);
-        hipEventDestroy(p->ev_all_grads);
+    if (!p) return;
+    // every handle that exists, whatever state plan_init_streams ended in
+    if (p->side) hipStreamDestroy(p->side);
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
+    for (int i = 0; i < 2; ++i) {
+        if (p->wstream[i]) hipStreamDestroy(p->wstream[i]);
+        if (p->wjoin[i]) hipEventDestroy(p->wjoin[i]);
+        if (p->ev_pack[i]) hipEventDestroy(p->ev_pack[i]);
     }
+    for (hipEvent_t e : p->wev)
+        if (e) hipEventDestroy(e);
+    if (p->ev_dec_grads) hipEventDestroy(p->ev_dec_grads);
+    if (p->ev_all_grads) hipEventDestroy(p->ev_all_grads);
     delete p;
 }
 
 // fork/join helpers: `side` runs one independent branch while the caller's stream runs the other
-static int g_force_single = 0;
-extern "C" void avc_set_single_stream(int on) { g_force_single = on; }
-static int g_no_in_fusion = 1;  // 1 = InstanceNorm always as its own row kernel (default: the fused epilogue measured slower)
-static int g_in_fusion_max_t = 64;  // rows up to this length are fused when fusion is on (16 | 32 | 64)
-extern "C" void avc_set_in_fusion(int on) {
-    g_no_in_fusion = on ? 0 : 1;
-    g_in_fusion_max_t = (on == 16 || on == 32) ? on : 64;   // avc_set_in_fusion(16 | 32): only the latency-bound short rows
+extern "C" int avc_plan_set_single_stream(avc_plan* p, int on) {
+    if (!p) return fail(-1, "avc_plan_set_single_stream: null plan");
+    p->tun.single_stream = on ? 1 : 0;
+    return 0;
 }
-static int g_dec_split_min = 32;  // smallest batch whose decoder forward runs as two half-batch chains
-extern "C" void avc_set_decoder_split_min(int n) { g_dec_split_min = n < 2 ? 2 : n; }
 
 extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
     if (!p || (dtype != AVC_COMPUTE_F32 && dtype != AVC_COMPUTE_BF16)) return fail(-1, "avc_plan_set_compute_dtype: dtype must be 0 (fp32) or 1 (bf16 operands)");
@@ -581,7 +575,7 @@ static void plan_init_streams(avc_plan* p) {
     for (hipEvent_t& e : p->wev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     p->side_state = ok ? 1 : -1;
 }
-static bool side_ready(const avc_plan* p) { return !g_force_single && p->side_state == 1; }
+static bool side_ready(const avc_plan* p) { return !p->tun.single_stream && p->side_state == 1; }
 static hipStream_t fork_side(const avc_plan* p, hipStream_t mainS) {
     if (!side_ready(p)) return mainS;
     hipEventRecord(p->ev_fork, mainS);
@@ -633,10 +627,11 @@ extern "C" int avc_plan_param_range(const avc_plan* p, int part, long* offset, l
     return 0;
 }
 // make `stream` wait until the gradients of `part` written by the LAST avc_backward call on this plan are final
-// (a no-op before the first call, and for single-stream plans whose caller already orders on its own stream)
+// (a no-op before the first call).  -9: the plan could not create helper streams / events -- nothing was ordered, the
+// caller must make `stream` wait for the stream avc_backward ran on.
 extern "C" int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream) {
     if (!p || (p->flags & AVC_PLAN_INFERENCE)) return fail(-1, "avc_plan_stream_wait_grads: not a training plan");
-    if (p->side_state != 1) return 0;
+    if (p->side_state != 1) return fail(-9, "avc_plan_stream_wait_grads: the plan has no helper streams / events (order on the stream avc_backward ran on)");
     hipEvent_t e = (part == AVC_GRADS_DECODER) ? p->ev_dec_grads : p->ev_all_grads;
     return (int)hipStreamWaitEvent((hipStream_t)stream, e, 0);
 }
@@ -671,8 +666,8 @@ static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, 
     a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
     a.M = L.Cout; a.Mp = L.Mp_f;
     a.ngroups = 1;
-    set_group(a.g[0], ws + ((L.rs_f || L.x3_f) ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
-    a.rs = L.x3_f ? 2 : (L.rs_f ? 1 : 0);
+    set_group(a.g[0], ws + (L.x3_f ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+    a.img = L.x3_f ? AVC_IMG_X3 : AVC_IMG_K4;
     a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.act = act;
@@ -691,8 +686,8 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
     a.ngroups = 1;
-    set_group(a.g[0], ws + ((L.rs_d || L.x3_d) ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
-    a.rs = L.x3_d ? 2 : (L.rs_d ? 1 : 0);
+    set_group(a.g[0], ws + (L.x3_d ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
+    a.img = L.x3_d ? AVC_IMG_X3 : AVC_IMG_K4;
     a.g[0].out = dx;
     return a;
 }
@@ -770,7 +765,7 @@ static int flush_wgrads(BwdCtx& c) {
     const int n = (int)c.pend.size();
     std::vector<WgradArgs> L((size_t)n);
     for (int i = 0; i < n; ++i) L[i] = c.pend[i].a;
-    avc_wgrad_plan_batch(L.data(), n, c.p->wgrad_target);
+    avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
     for (int i = 0; i < n; ++i) {
         WgradArgs& a = L[i];
         const long wsz = (long)a.Cout * a.Cin * a.KS;
@@ -805,7 +800,7 @@ static int flush_wgrads(BwdCtx& c) {
     c.pend.clear();
     c.pend_units = 0;
     if (c.dry) return 0;
-    int rc = avc_launch_wgrad_batch(L.data(), n, ls);
+    int rc = avc_launch_wgrad_batch(L.data(), n, ls, c.p->tun.wgrad_ablation);
     if (rc) return rc;
     return c.red.flush(ls);
 }
@@ -820,13 +815,13 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.dy.ptr = dy; a.dy.sb = ysb; a.dy.sc = ysc; a.dy.st = yst; a.dy.ps = yps;
     a.B = Bn; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
-    a.bf16 = (L.bf16 == AVC_COMPUTE_F32 && c.p->wgrad_x3) ? AVC_COMPUTE_F32X3 : L.bf16;
+    a.bf16 = (L.bf16 == AVC_COMPUTE_F32 && c.p->tun.wgrad_x3) ? AVC_COMPUTE_F32X3 : L.bf16;
     pw.L = &L;
     avc_wgrad_geometry(a);
     c.pend_units += (long)a.tiles * a.total_chunks;
     c.pend.push_back(pw);
     // flush when the batch is worth a launch: enough work to give every CU a long K run, or enough layers
-    if ((int)c.pend.size() >= c.p->wgrad_batch || c.pend_units >= c.p->wgrad_units) return flush_wgrads(c);
+    if ((int)c.pend.size() >= c.p->tun.wgrad_batch || c.pend_units >= c.p->tun.wgrad_batch_units) return flush_wgrads(c);
     return 0;
 }
 
@@ -838,31 +833,30 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
     a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
     a.dst = ws + L.wpf;
+    a.img = L.conv_path ? AVC_IMG_K4 : AVC_IMG_PLAIN;
     if (L.x3_f) {   // only the image the launch will read
         PackArgs r;
         avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
         out.push_back(r);
-    } else if (L.rs_f) {
-        PackArgs r;
-        avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
-        out.push_back(r);
     } else {
         out.push_back(a);
+    }
+    if (L.wplain >= 0) {
+        PackArgs b = a;
+        b.img = AVC_IMG_PLAIN;
+        b.dst = ws + L.wplain;
+        out.push_back(b);
     }
     if (L.need_dgrad && L.x3_d) {
         PackArgs r;
         avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d, L.dgM);
-        out.push_back(r);
-    } else if (L.need_dgrad && L.rs_d) {
-        PackArgs r;
-        avc_pack_rs_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 1, ws + L.wrs_d);
         out.push_back(r);
     } else if (L.need_dgrad) {
         a.dgrad = 1; a.CK = L.CKd; a.nchunk = L.nchunk_d; a.M = L.dgM; a.Mp = L.Mp_d;
         a.dst = ws + L.wpd;
         out.push_back(a);
     }
-    if (L.nsrc > 1) {  // stacked bias = "weight" with Cin = 1, KS = 1: first Mp floats of the image
+    if (L.nsrc > 1) {  // stacked bias = "weight" with Cin = 1, KS = 1: first Mp floats of the plain image
         PackArgs b;
         memset(&b, 0, sizeof(b));
         for (int i = 0; i < L.nsrc; ++i) b.src[i] = p->par(params, L.b[i]);
@@ -870,6 +864,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
         b.Cout = L.Cout; b.Cin = 1; b.KS = 1;
         b.dgrad = 0; b.CK = 32; b.nchunk = 1; b.M = L.Cout; b.Mp = L.Mp_f;
         b.dst = ws + L.bpk;
+        b.img = AVC_IMG_PLAIN;
         out.push_back(b);
     }
 }
@@ -897,28 +892,6 @@ static int in_bwd(const float* g, const float* y, const float* stats, int Bn, in
     return avc_launch_in_bwd(a, s);
 }
 
-// InstanceNorm fused into the producing conv's epilogue where a 64x64 tile holds whole rows
-// (conv_gemm.hip): returns true and fills the epilogue fields, or false (caller launches in_fwd).
-static bool fuse_in(ConvArgs& a, const LayerP& L, int Bn, int C, const float* cond, long cond_sb, int cond_off, const float* res,
-                    int res_mode, long rb, int Tres, float* out, float* stats, int Bfull, int b0) {
-    if (g_no_in_fusion || a.rs) return false;
-    const int T = a.Tout;
-    if (!(T == 16 || T == 32 || T == 64) || T > g_in_fusion_max_t || a.ops != 1 || a.ngroups != 1 || a.mode != 0) return false;
-    if (avc_conv_pick_tile(a.Mp, Bn, T, 1, a.Cred * a.g[0].KS) != 11) return false;
-    if (res && !(res_mode == AVC_RES_IDENTITY || res_mode == AVC_RES_AVGPOOL2)) return false;
-    a.in_fuse = 1;
-    a.in_cond = cond; a.in_cond_sb = cond_sb; a.in_cond_off = cond_off; a.in_C = C;
-    a.in_out = out;
-    a.in_mean = stats + (long)b0 * C;
-    a.in_rstd = stats + (long)Bfull * C + (long)b0 * C;
-    if (res) {
-        a.g[0].res = res;
-        a.res_mode = res_mode;
-        a.rb = rb; a.rc = Tres; a.rt = 1; a.Tres = Tres;
-    }
-    return true;
-}
-
 // --------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------
@@ -935,12 +908,13 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
     a.ob = (long)e.CC * T0; a.oc = T0; a.ot = 1; a.ops = 1;
     a.act = 1;
     a.ngroups = e.nb;
+    a.img = AVC_IMG_K4;
     for (int g = 0; g < e.nb; ++g) {
         const LayerP& L = p->layers[e.bank[g]];
         set_group(a.g[g], ws + L.wpf, p->par(params, L.b[0]), L.KS, L.CK, L.nchunk_f);
         a.g[g].out = ws + e.cat + (long)g * e.c.c_bank * T0;
     }
-    RUN(avc_launch_conv(a, s, 0));
+    RUN(avc_launch_conv(a, s, 0, p->tun));
     // raw input last (model.py:90)
     RUN(avc_launch_copy_rows(x, sxb, sxc, sxt, B, e.c.c_in, T0, ws + e.cat + (long)e.nb * e.c.c_bank * T0, (long)e.CC * T0, T0, s));
     return 0;
@@ -985,17 +959,17 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         {
             const LayerP& L = p->layers[e.in_conv];
             ConvArgs a = mk_fwd(p, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
             ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a2[l], (long)C * To, To, 1, 1);
             b.g[0].out2 = ws + e.out[l + 1];
             set_res(b, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, (long)C * Ti, Ti, 1, Ti);
-            RUN(avc_launch_conv(b, s, 0));
+            RUN(avc_launch_conv(b, s, 0, p->tun));
         }
         const int Tn = e.T[e.n];
         RUN(avc_launch_timepool_fwd(ws + e.out[e.n], B, C, Tn, ws + e.pooled, s));
@@ -1033,25 +1007,23 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
         {
             ConvArgs a = mk_fwd(p, p->layers[e.in_conv], params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
             RUN(in_fwd(ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
-            const bool f1 = fuse_in(a, p->layers[e.c1[l]], B, C, nullptr, 0, 0, nullptr, 0, 0, 0, ws + e.a1[l], ws + e.st1[l], B, 0);
-            RUN(avc_launch_conv(a, s, 0));
-            if (!f1) RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
             ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
             const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
-            const bool f2 = fuse_in(b, p->layers[e.c2[l]], B, C, nullptr, 0, 0, ws + e.out[l], rmode, (long)C * Ti, Ti, ws + e.out[l + 1], ws + e.st2[l], B, 0);
-            RUN(avc_launch_conv(b, s, 0));
-            if (!f2) RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
+            RUN(avc_launch_conv(b, s, 0, p->tun));
+            RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
         }
         const int Tb = p->Tb;
         ConvArgs h = mk_fwd(p, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
-        RUN(avc_launch_conv(h, s, 0));
+        RUN(avc_launch_conv(h, s, 0, p->tun));
     }
 
     join_side(p, mainS, sideS);
@@ -1063,7 +1035,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const long csb = (long)2 * d.n * 2 * C;
         {   // all 2n AdaIN affine Linears as ONE GEMM on emb (they share their input)
             ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         // The decoder is one serial chain of ~40 small kernels (T_l = 16..128): alone on the GPU it leaves
         // most CUs waiting on launch / pipeline latency (0.86 ms with one kernel in flight, traced).  Two
@@ -1074,33 +1046,29 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             const float* cond = ws + d.cond + (long)b0 * csb;
             {
                 ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
-                const bool f0 = fuse_in(a, p->layers[d.in_conv], Bn, C, nullptr, 0, 0, nullptr, 0, 0, 0, ws + d.out[0] + ob0, ws + d.st0, B, b0);
-                RUN(avc_launch_conv(a, s, 0));
-                if (!f0) RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+                RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
             }
             for (int l = 0; l < d.n; ++l) {
                 const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
                 const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
                 ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
-                const bool f1 = fuse_in(a, p->layers[d.c1[l]], Bn, C, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], B, b0);
-                RUN(avc_launch_conv(a, s, 0));
-                if (!f1) RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+                RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
                 // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
                 ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
                 b.ops = up;
-                const bool f2 = up == 1 && fuse_in(b, p->layers[d.c2[l]], Bn, C, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, AVC_RES_IDENTITY,
-                                                   (long)C * Ti, Ti, ws + d.out[l + 1] + oo, ws + d.st2[l], B, b0);
-                RUN(avc_launch_conv(b, s, 0));
-                if (!f2) RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                RUN(avc_launch_conv(b, s, 0, p->tun));
+                RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
                                     ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
             }
             const int To = p->Tout;
             ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
                                 ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
-            RUN(avc_launch_conv(o, s, 0));
+            RUN(avc_launch_conv(o, s, 0, p->tun));
             return 0;
         };
-        if (B >= g_dec_split_min && side_ready(p)) {
+        if (B >= p->tun.dec_split_min && side_ready(p)) {
             const int Bh = B / 2;
             const hipStream_t s2 = fork_side(p, s);
             RUN(dec_chain(0, Bh, s));
@@ -1146,7 +1114,7 @@ static int enc_back_front(BwdCtx& c, const EncNet& e, const float* x, long sxb, 
         ConvArgs a = mk_dgrad(L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, (long)e.CC * T0, T0, 1);
         a.g[0].out2 = ws + e.dcat;
         a.g[0].mask = ws + e.cat;
-        RUN(avc_launch_conv(a, c.s, 0));
+        RUN(avc_launch_conv(a, c.s, 0, p->tun));
     }
     for (int g = 0; g < e.nb; ++g) {
         const LayerP& Lb = p->layers[e.bank[g]];
@@ -1183,7 +1151,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
         if (!dry) {
             ConvArgs a = mk_dgrad(Lo, ws, ddec, (long)p->M * To, To, 1, 1, B, To, To, gA, (long)C * To, To, 1);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = d.n - 1; l >= 0; --l) {
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
@@ -1194,7 +1162,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             // dyA is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
             if (!dry) {
                 ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, up, up, B, Ti, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + d.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, up, up, B, Ti, Ti));
             dyB = c.fresh((long)B * C * Ti);
@@ -1202,7 +1170,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             if (!dry) {
                 ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L1, ws + d.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
             rot();
@@ -1213,7 +1181,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
             ConvArgs a = mk_dgrad(Li, ws, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb, ws + p->dz, (long)Cz * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
         const LayerP& La = p->layers[d.affine];
@@ -1226,7 +1194,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             WgradArgs w;
             memset(&w, 0, sizeof(w));
             w.x.ptr = ws + d.dcond; w.x.sb = 0; w.x.sc = csb; w.x.st = 1; w.x.ps = 1;
-            w.dy.ptr = ws + La.wpf; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
+            w.dy.ptr = ws + La.wplain; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
             w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = p->compute;
             avc_wgrad_plan_batch(&w, 1, 256);
@@ -1237,7 +1205,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 w.slab = ws + p->slab + off;
                 w.slab_stride = wsz;
                 w.dbslab = nullptr;
-                RUN(avc_launch_wgrad_batch(&w, 1, s));
+                RUN(avc_launch_wgrad_batch(&w, 1, s, p->tun.wgrad_ablation));
                 RUN(avc_launch_reduce(w.slab, wsz, w.nsplit, (int)wsz, ws + p->demb, 1, s));  // demb: channel-major [c_cond][B]
                 if (d_emb_up) RUN(avc_launch_add_transposed(ws + p->demb, d_emb_up, B, d.c.c_cond, s));
             }
@@ -1322,7 +1290,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, nullptr, (long)C * Ti, Ti, 1);
                 a.g[0].out2 = dyB;
                 a.g[0].mask = ws + e.a1[l];
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
             dyA = c.fresh((long)B * C * Ti);  // (the wgrad of conv2 above still reads the previous dyA)
@@ -1331,7 +1299,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
                 a.g[0].out2 = dyA;  // next: dy2 of block l-1, or d(in_conv out) for l == 0
                 a.g[0].mask = (l > 0) ? ws + e.a2[l - 1] : ws + e.h0;
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
             rot();
@@ -1349,7 +1317,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
             ConvArgs a = mk_dgrad(Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0));
+            RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
@@ -1359,7 +1327,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
             if (!dry) {
                 ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
             dyB = c.fresh((long)B * C * Ti);
@@ -1367,7 +1335,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             if (!dry) {
                 ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0));
+                RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
             rot();

@@ -8,24 +8,58 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 
-extern "C" {
-void avc_set_in_fusion(int on);
-void avc_set_decoder_split_min(int n);
+#include <string.h>
 
-// compute dtype of the op-level conv entry points (the whole-model path takes it from the plan)
-static int g_op_compute = AVC_COMPUTE_F32;
-// diagnostics: main-loop ablation switches of the conv / wgrad kernels (scripts/*_ablate.py); 0 = off
-void avc_set_debug_ablation(int conv_bits, int wgrad_bits) {
-    avc_set_conv_ablation(conv_bits);
-    avc_set_wgrad_ablation(wgrad_bits);
+// ---- tuning: library defaults + the calling thread's op-level copy (include/avc_hip.h: no process-wide mutable state)
+static avc_tuning make_default_tuning() {
+    avc_tuning t;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = (int)sizeof(avc_tuning);
+    t.dec_split_min = 32;
+    t.dgrad_par = 1;
+    t.bank_switch = 1;
+    t.conv_ck5 = 8;
+    t.wgrad_batch = 12;
+    t.wgrad_batch_wgs = 256;
+    t.wgrad_target_wgs = 256;
+    t.wgrad_batch_units = 1L << 40;
+    t.tile_thr11 = 8192;   // r2 sweeps (profiles/r02_tune_sweeps.log)
+    t.tile_thr21 = 4096;
+    t.ck16_wgs = 256;
+    t.ck32_wgs = 256;
+    t.kg_wgs = 256;
+    return t;
 }
-// register-stationary weight image of conv_rs.hip (tile code 99 of avc_conv1d_fwd / avc_conv1d_dgrad)
-long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad) {
-    return avc_conv_rs_image_floats(dgrad ? Cin : Cout, dgrad ? Cout : Cin, KS);
+const avc_tuning& avc_default_tuning() {
+    static const avc_tuning t = make_default_tuning();
+    return t;
 }
-int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream) {
-    return avc_launch_pack_rs(w, Cout, Cin, KS, dgrad, dst, (hipStream_t)stream);
+avc_tuning& avc_op_tuning() {
+    static thread_local avc_tuning t = make_default_tuning();
+    return t;
 }
+
+extern "C" {
+void avc_tuning_init(avc_tuning* t) {
+    if (t) *t = avc_default_tuning();
+}
+void avc_get_op_tuning(avc_tuning* out) {
+    if (out) *out = avc_op_tuning();
+}
+// one field of the calling thread's op-level tuning, by name
+int avc_set_tuning(const char* name, int value) {
+    if (!name) return -1;
+    avc_tuning& t = avc_op_tuning();
+#define AVC_TUNE_FIELD(f) if (!strcmp(name, #f)) { t.f = value; return 0; }
+    AVC_TUNE_FIELD(single_stream) AVC_TUNE_FIELD(dec_split_min) AVC_TUNE_FIELD(conv_x3) AVC_TUNE_FIELD(wgrad_x3) AVC_TUNE_FIELD(dgrad_par)
+    AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
+    AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(wgrad_batch_units)
+    AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs)
+#undef AVC_TUNE_FIELD
+    if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }
+    return -1;
+}
+
 // split-bf16 weight image of conv_x3.hip (tile code 97 of avc_conv1d_fwd / avc_conv1d_dgrad)
 long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad) {
     const int Cred = dgrad ? Cout : Cin;
@@ -45,35 +79,8 @@ int avc_gather_segments(const float* corpus, long n_rows, int M, const long* sta
     return avc_launch_gather_segments(corpus, n_rows, M, starts, B, T, out, (hipStream_t)stream);
 }
 
-// tuning / diagnostic knobs of the micro-benchmark scripts (they used to be environment variables)
-int avc_set_tuning(const char* name, int value) {
-    if (!name) return -1;
-    if (!strcmp(name, "conv_ck5")) avc_set_conv_ck5(value);
-    else if (!strcmp(name, "wgrad_target_wgs")) avc_set_wgrad_target_wgs(value);
-    else if (!strcmp(name, "in_variant")) avc_set_in_variant(value);
-    else if (!strcmp(name, "in_fusion")) avc_set_in_fusion(value);
-    else if (!strcmp(name, "tile_thr11")) avc_set_conv_heuristic(0, value);          // launch heuristics of conv_gemm.hip (new plans)
-    else if (!strcmp(name, "tile_thr21")) avc_set_conv_heuristic(1, value);
-    else if (!strcmp(name, "ck16_wgs")) avc_set_conv_heuristic(2, value);
-    else if (!strcmp(name, "ck32_wgs")) avc_set_conv_heuristic(3, value);
-    else if (!strcmp(name, "kg_wgs")) avc_set_conv_heuristic(4, value);
-    else if (!strcmp(name, "dec_split_min")) avc_set_decoder_split_min(value);
-    else if (!strcmp(name, "bank_switch")) avc_set_bank_switch(value);             // 0: generic chunk loop for the grouped bank launch
-    else if (!strcmp(name, "dgrad_par")) avc_set_dgrad_par(value);                 // 0: stride-2 dgrad on all five taps of the zero-upsampled dy
-    else if (!strcmp(name, "conv_small")) avc_set_conv_small(value);               // 0: short rows (T = 16 / 32) on the chunk-pipelined kernel
-    else if (!strcmp(name, "wgrad_x3")) avc_set_wgrad_x3(value);                   // 1: split-bf16 products in the whole-chunk weight-gradient launches (new plans, op level)
-    else if (!strcmp(name, "conv_x3")) avc_set_conv_x3(value);                     // 1: split-bf16 conv kernel for the big k = 5 layers of new plans
-    else if (!strcmp(name, "conv_rs")) avc_set_conv_rs(value);                     // 0: never the register-stationary conv kernel
-    else if (!strcmp(name, "wgrad_batch")) avc_set_wgrad_batch(value, 0);          // layers per batched wgrad launch (new plans)
-    else if (!strcmp(name, "wgrad_batch_wgs")) avc_set_wgrad_batch(0, value);
-    else if (!strcmp(name, "wgrad_batch_units")) avc_set_wgrad_units(value);       // pending tile x chunk units that trigger a launch early      // workgroups such a launch aims for
-    else return -1;
-    return 0;
-}
-void avc_set_op_compute_dtype(int dtype) { g_op_compute = (dtype == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; }
-
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
-    int CK = avc_conv_ck(KS);
+    int CK = avc_conv_ck(avc_op_tuning(), KS);
     int red = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
     int nchunk = avc_cdiv(red, CK), Mp = avc_cdiv(M, 128) * 128;
     return (long)nchunk * KS * CK * Mp;
@@ -91,7 +98,8 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
     p.Cin = Cin;
     p.KS = KS;
     p.dgrad = dgrad;
-    p.CK = avc_conv_ck(KS);
+    p.CK = avc_conv_ck(avc_op_tuning(), KS);
+    p.img = AVC_IMG_K4;
     int red = dgrad ? Cout : Cin;
     p.M = dgrad ? Cin : Cout;
     p.nchunk = avc_cdiv(red, p.CK);
@@ -107,7 +115,7 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
                    int tile, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = g_op_compute;
+    a.bf16 = avc_op_tuning().op_compute_dtype;
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.B = B; a.Cred = Cin; a.Tsrc = Tin;
     a.mode = 0; a.stride = stride; a.mirror = 0;
@@ -119,11 +127,12 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.res_mode = res_mode; a.res_to_primary = 0;
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
     a.ngroups = 1;
-    a.g[0].CK = avc_conv_ck(KS);
+    a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = out; a.g[0].out2 = out2; a.g[0].res = res; a.g[0].mask = nullptr;
     a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
-    if (tile == 97) { a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK); }   // wp is a split-bf16 image (avc_pack_weight_x3)
-    return avc_launch_conv(a, (hipStream_t)stream, tile);
+    a.img = AVC_IMG_K4;
+    if (tile == 97) { a.img = AVC_IMG_X3; a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK); }   // wp is a split-bf16 image (avc_pack_weight_x3)
+    return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
 
 // dx = conv1d_input_grad(dy) including the adjoint of the reflect padding
@@ -134,7 +143,7 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
                      void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = g_op_compute;
+    a.bf16 = avc_op_tuning().op_compute_dtype;
     a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
     a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
     a.mode = 1; a.stride = stride;
@@ -147,17 +156,18 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     a.res_mode = res_mode; a.res_to_primary = 1;
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
     a.ngroups = 1;
-    a.g[0].CK = avc_conv_ck(KS);
+    a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wpd; a.g[0].bias = nullptr; a.g[0].out = dx; a.g[0].out2 = dx2; a.g[0].res = res; a.g[0].mask = mask;
     a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
-    if (tile == 97) { a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK); }
-    return avc_launch_conv(a, (hipStream_t)stream, tile);
+    a.img = AVC_IMG_K4;
+    if (tile == 97) { a.img = AVC_IMG_X3; a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK); }
+    return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
 
 // workspace (floats) needed by avc_conv1d_wgrad for the split-K slabs
 long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
     int Tc, spc, cps, tot, cpw, nsplit;
-    avc_wgrad_plan(B, Cin, Cout, Tout, KS, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
+    avc_wgrad_plan(avc_op_tuning(), B, Cin, Cout, Tout, KS, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
     return (long)nsplit * ((long)Cout * Cin * KS + Cout);
 }
 int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* dy, long syb, long syc, int syt, int yps,
@@ -165,17 +175,20 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
                      void* stream) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = (g_op_compute == AVC_COMPUTE_F32 && avc_wgrad_x3()) ? AVC_COMPUTE_F32X3 : g_op_compute;
+    {
+        const avc_tuning& t = avc_op_tuning();
+        a.bf16 = (t.op_compute_dtype == AVC_COMPUTE_F32 && t.wgrad_x3) ? AVC_COMPUTE_F32X3 : t.op_compute_dtype;
+    }
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = KS; a.padL = KS / 2; a.stride = stride;
-    avc_wgrad_plan_batch(&a, 1, avc_wgrad_target_wgs());
+    avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
     const int nsplit = a.nsplit;
     long wsz = (long)Cout * Cin * KS;
     a.slab = ws; a.slab_stride = wsz;
     a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;
-    int rc = avc_launch_wgrad_batch(&a, 1, (hipStream_t)stream);
+    int rc = avc_launch_wgrad_batch(&a, 1, (hipStream_t)stream, avc_op_tuning().wgrad_ablation);
     if (rc) return rc;
     rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, KS, (hipStream_t)stream);
     if (rc || !db) return rc;

@@ -508,10 +508,6 @@ __global__ void __launch_bounds__(AVC_THREADS) clip_adam_kernel(const AdamArgs a
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
-static int g_in_variant = 0;  // InstanceNorm kernel variant sweep of scripts/in_micro.py (avc_set_tuning)
-void avc_set_in_variant(int v) { g_in_variant = v; }
-static int in_variant() { return g_in_variant; }
-
 template <int LPR, int NV>
 static void launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
     int rpb = AVC_THREADS / LPR;
@@ -529,15 +525,6 @@ int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.out) % 16 == 0);
     if (!fast) {
         hipLaunchKernelGGL(instnorm_fwd_generic_kernel, dim3(avc_cdiv(a.R, 4)), dim3(AVC_THREADS), 0, s, a);
-    } else if (in_variant() == 1) {  // two float4 per lane: half the shuffle steps, twice the loads in flight
-        if (n4 <= 4) launch_in_fwd<4, 1>(a, s);
-        else if (n4 <= 8) launch_in_fwd<4, 2>(a, s);
-        else if (n4 <= 16) launch_in_fwd<8, 2>(a, s);
-        else if (n4 <= 32) launch_in_fwd<16, 2>(a, s);
-        else if (n4 <= 64) launch_in_fwd<32, 2>(a, s);
-        else if (n4 <= 128) launch_in_fwd<64, 2>(a, s);
-        else if (n4 <= 256) launch_in_fwd<64, 4>(a, s);
-        else launch_in_fwd<64, 8>(a, s);
     } else if (n4 <= 4) launch_in_fwd<4, 1>(a, s);
     else if (n4 <= 8) launch_in_fwd<8, 1>(a, s);
     else if (n4 <= 16) launch_in_fwd<16, 1>(a, s);
@@ -555,15 +542,6 @@ int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s) {
     bool fast = (a.T % 4 == 0) && n4 <= 512 && (((uintptr_t)a.y | (uintptr_t)a.g | (uintptr_t)a.dy) % 16 == 0);
     if (!fast) {
         hipLaunchKernelGGL(instnorm_bwd_generic_kernel, dim3(avc_cdiv(a.R, 4)), dim3(AVC_THREADS), 0, s, a);
-    } else if (in_variant() == 1) {  // two float4 per lane: half the shuffle steps, twice the loads in flight
-        if (n4 <= 4) launch_in_bwd<4, 1>(a, s);
-        else if (n4 <= 8) launch_in_bwd<4, 2>(a, s);
-        else if (n4 <= 16) launch_in_bwd<8, 2>(a, s);
-        else if (n4 <= 32) launch_in_bwd<16, 2>(a, s);
-        else if (n4 <= 64) launch_in_bwd<32, 2>(a, s);
-        else if (n4 <= 128) launch_in_bwd<64, 2>(a, s);
-        else if (n4 <= 256) launch_in_bwd<64, 4>(a, s);
-        else launch_in_bwd<64, 8>(a, s);
     } else if (n4 <= 4) launch_in_bwd<4, 1>(a, s);
     else if (n4 <= 8) launch_in_bwd<8, 1>(a, s);
     else if (n4 <= 16) launch_in_bwd<16, 1>(a, s);

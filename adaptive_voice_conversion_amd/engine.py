@@ -65,14 +65,16 @@ class Plan:
 
     COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp32x3": 0, "f32x3": 0}
 
-    def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None):
+    def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None, tuning=None):
         """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
         rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3); "fp32x3" = fp32-accurate
         products from three bf16 terms per operand on the bf16 matrix core for the big k = 5 convs and the whole-chunk weight
         gradients (opt-in; csrc/conv_x3.hip), exact fp32 everywhere else.
         mode: "train" (forward + loss + backward), "inference" (forward only: the workspace holds no gradient,
         slab or dy buffers) or "speaker" (only the speaker encoder runs, AE.get_speaker_embeddings).
-        device: the plan's helper streams are created on it (default: the current device)."""
+        device: the plan's helper streams are created on it (default: the current device).
+        tuning: {avc_tuning field: value} overrides of the launch heuristics / diagnostic switches the plan captures
+        (A/B measurements and tests; include/avc_hip.h).  The library has no process-wide knobs."""
         self.lib = lib if lib is not None else _lib.load()
         self.cfg = cfg_from_dict(config)
         self.B, self.T, self.T_cond = int(B), int(T), int(T_cond or T)
@@ -84,16 +86,12 @@ class Plan:
         if key not in self.COMPUTE:
             raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE)}, got {compute_dtype!r}")
         x3 = key in ("fp32x3", "f32x3")
-        if x3:   # captured by the plan at creation (process-wide knobs: one host call at a time, include/avc_hip.h)
-            self.lib.avc_set_tuning(b"conv_x3", 1)
-            self.lib.avc_set_tuning(b"wgrad_x3", 1)
-        try:
-            with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
-                rc = self.lib.avc_plan_create_ex(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(h))
-        finally:
-            if x3:
-                self.lib.avc_set_tuning(b"conv_x3", 0)
-                self.lib.avc_set_tuning(b"wgrad_x3", 0)
+        if x3:
+            flags |= _lib.PLAN_X3
+        self.tuning = dict(tuning or {})
+        tun = _lib.make_tuning(self.lib, self.tuning)
+        with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
+            rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(tun), ctypes.byref(h))
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
@@ -132,8 +130,17 @@ class Plan:
 
     def stream_wait_grads(self, part, stream):
         """Make ``stream`` (a torch.cuda.Stream) wait until that part of the gradients of the last
-        ``backward`` call is final (data-parallel overlap)."""
-        self._chk(self.lib.avc_plan_stream_wait_grads(self.h, int(part), ctypes.c_void_p(stream.cuda_stream)))
+        ``backward`` call is final (data-parallel overlap).  Returns False when the plan has no helper
+        streams / events (nothing was ordered: the caller must wait for the stream backward ran on)."""
+        rc = self.lib.avc_plan_stream_wait_grads(self.h, int(part), ctypes.c_void_p(stream.cuda_stream))
+        if rc == -9:
+            return False
+        self._chk(rc)
+        return True
+
+    def set_single_stream(self, on):
+        """Profiling aid: every kernel of this plan on the caller's stream."""
+        self._chk(self.lib.avc_plan_set_single_stream(self.h, int(bool(on))))
 
     def buffer(self, name):
         off = self.lib.avc_plan_buffer(self.h, name.encode())

@@ -183,12 +183,14 @@ class _AEFunction(torch.autograd.Function):
 class AE(nn.Module):
     """model.py:373-395."""
 
-    def __init__(self, config, lib=None, compute_dtype=None):
-        """``compute_dtype`` ("fp32" default | "bf16"; also read from ``config["compute_dtype"]``) is an
-        extension over the reference: the precision of the conv / Linear matrix products (engine.Plan)."""
+    def __init__(self, config, lib=None, compute_dtype=None, tuning=None):
+        """``compute_dtype`` ("fp32" default | "bf16" | "fp32x3"; also read from ``config["compute_dtype"]``) is an
+        extension over the reference: the precision of the conv / Linear matrix products (engine.Plan).
+        ``tuning``: {avc_tuning field: value} captured by every plan of this module (A/B measurements, tests)."""
         super().__init__()
         self.config = config
         self._lib = lib
+        self._tuning = dict(tuning or {})
         self.compute_dtype = compute_dtype or (config.get("compute_dtype") if isinstance(config, dict) else None) or "fp32"
         cfg_from_dict(config)  # validates (raises on sn / lrelu / dropout)
         self.speaker_encoder = SpeakerEncoder(**config["SpeakerEncoder"])
@@ -247,7 +249,7 @@ class AE(nn.Module):
         key = (int(B), int(T), int(Tc), str(device))
 
         def make():
-            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype, mode=mode, device=device)
+            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype, mode=mode, device=device, tuning=self._tuning)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")
             return _Entry(plan, torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device))

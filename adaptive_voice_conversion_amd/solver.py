@@ -108,7 +108,8 @@ class Solver(object):
     def build_model(self):
         if self.config["data_loader"].get("frame_size", 1) != 1:
             raise NotImplementedError("data_loader.frame_size != 1")
-        self.model = cc(AE(self.config, lib=self._lib)) if self._lib is None else AE(self.config, lib=self._lib)
+        tuning = getattr(self.args, "tuning", None)
+        self.model = cc(AE(self.config, lib=self._lib, tuning=tuning)) if self._lib is None else AE(self.config, lib=self._lib, tuning=tuning)
         o = self.config["optimizer"]
         self.opt = FusedClipAdam(self.model, lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"],
                                  weight_decay=o["weight_decay"], lib=self._lib)
@@ -118,6 +119,7 @@ class Solver(object):
         # reparameterisation noise (model.py:383): every rank draws from its OWN generator stream
         self._eps_gen = None
         self._comm_stream = None
+        self._wire = None   # persistent bf16 gradient bucket (allreduce_dtype: bf16)
 
     # ---- one training step (solver.py:81-97) -------------------------------------
     def _draw_eps(self, B, C, Tb, device):
@@ -138,26 +140,33 @@ class Solver(object):
         # the bf16 matrix products that produced them.
         wire_bf16 = self.config.get("allreduce_dtype", "bf16" if str(self.config.get("compute_dtype", "fp32")).lower() in ("bf16", "bfloat16") else "fp32") == "bf16"
 
-        def reduce(seg):
-            if not wire_bf16:
+        def reduce(seg, wire):
+            if wire is None:
                 d.all_reduce(seg)
                 return
-            wire = seg.to(torch.bfloat16)
+            wire.copy_(seg)            # persistent bf16 bucket: no per-step allocation
             d.all_reduce(wire)
             seg.copy_(wire)
+        (do, dn), (eo, en) = plan.param_range(_lib.GRADS_DECODER), plan.param_range(_lib.GRADS_ENCODERS)
+        wd = we = None
+        if wire_bf16:
+            if self._wire is None or self._wire.device != grads.device or self._wire.numel() != grads.numel():
+                self._wire = torch.empty(grads.numel(), dtype=torch.bfloat16, device=grads.device)
+            wd, we = self._wire[do:do + dn], self._wire[eo:eo + en]
         if not grads.is_cuda:
-            reduce(grads)
+            reduce(grads[do:do + dn], wd)
+            reduce(grads[eo:eo + en], we)
             return
         if self._comm_stream is None or self._comm_stream.device != grads.device:
             self._comm_stream = torch.cuda.Stream(device=grads.device)
         cs, main = self._comm_stream, torch.cuda.current_stream(grads.device)
-        (do, dn), (eo, en) = plan.param_range(_lib.GRADS_DECODER), plan.param_range(_lib.GRADS_ENCODERS)
-        plan.stream_wait_grads(_lib.GRADS_DECODER, cs)
+        if not plan.stream_wait_grads(_lib.GRADS_DECODER, cs):
+            cs.wait_stream(main)                   # a plan without helper streams / events: order behind the whole backward
         with torch.cuda.stream(cs):
-            reduce(grads[do:do + dn])
+            reduce(grads[do:do + dn], wd)
         cs.wait_stream(main)                       # the whole backward (avc_backward joins its helper streams into main)
         with torch.cuda.stream(cs):
-            reduce(grads[eo:eo + en])
+            reduce(grads[eo:eo + en], we)
         main.wait_stream(cs)
 
     def ae_step(self, data, lambda_kl, eps=None, sync=True):
@@ -176,7 +185,9 @@ class Solver(object):
         plan.backward(flat, x, None, eps, grads, ws, lambda_kl=float(lambda_kl))
         prescale = 1.0
         d = _dist()
-        if d is not None:   # (also with world_size 1: the same code path a multi-GPU job runs)
+        if d is not None and (d.get_world_size() > 1 or self.config.get("allreduce_world1", False)):
+            # (world_size 1: nothing to reduce -- and no bf16 round trip of the gradients; `allreduce_world1: true` keeps the
+            # collective path for tests that exercise it with one rank)
             self._allreduce_grads(d, plan, grads)
             prescale = 1.0 / d.get_world_size()
         gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)

@@ -54,13 +54,15 @@ def profile_classes(solver, x, eps, steps):
     ms, launches = (ctypes.c_double * n)(), (ctypes.c_long * n)()
     flops, nbytes = (ctypes.c_double * n)(), (ctypes.c_double * n)()
     torch.cuda.synchronize()
-    lib.avc_set_single_stream(1)   # one stream: event brackets then measure each kernel class in isolation
+    plan = solver.model._plan(x.shape[0], x.shape[2], x.shape[2], x.device)[0]
+    was_single = bool(plan.tuning.get("single_stream", 0))
+    plan.set_single_stream(True)   # one stream: event brackets then measure each kernel class in isolation
     lib.avc_prof_begin()
     for _ in range(steps):
         solver.ae_step(x, 1.0, eps=eps, sync=False)
     torch.cuda.synchronize()
     lib.avc_prof_end(ms, launches, flops, nbytes)
-    lib.avc_set_single_stream(0)
+    plan.set_single_stream(was_single)
     out = {}
     for i in range(n):
         if launches[i]:
@@ -379,7 +381,7 @@ def main():
                          "the whole step enqueued when it starts; the reported time is then meaningless")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
-                    help="avc_set_tuning knob applied before the plans are created (A/B measurements), e.g. conv_rs=0, wgrad_batch=1")
+                    help="avc_tuning field captured by the plans (A/B measurements), e.g. wgrad_batch=1, kg_wgs=0")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -408,19 +410,23 @@ def main():
 
     from adaptive_voice_conversion_amd import _lib
     from adaptive_voice_conversion_amd.solver import Solver
+    tuning = {}
     if a.single_stream:
-        _lib.load().avc_set_single_stream(1)
+        tuning["single_stream"] = 1
     for kv in a.tune:
         k, v = kv.split("=")
-        if _lib.load().avc_set_tuning(k.encode(), int(v)) != 0:
-            raise SystemExit(f"unknown tuning knob {k!r}")
+        tuning[k] = int(v)
+    try:
+        _lib.make_tuning(_lib.load(), tuning)
+    except KeyError as e:
+        raise SystemExit(str(e))
     cfg = stock_config(a.mels)
     if a.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
     if a.dtype == "f32x3":   # opt-in: fp32-accurate products from three bf16 terms on the bf16 matrix core
         cfg["compute_dtype"] = "fp32x3"
     torch.manual_seed(0)
-    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log")
+    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log", tuning=tuning)
     solver = Solver(cfg, args)
     B, T = a.batch, a.frames
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # each rank: its own shard of the global batch

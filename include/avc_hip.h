@@ -23,9 +23,12 @@
  *    every entry point joins them back into the caller's stream before it
  *    returns.  ONE call per plan may be in flight on the host at a time (two
  *    host threads need two plans); different plans are independent.
- *  - the only process-wide state are the diagnostic / tuning knobs set by the
- *    avc_set_* functions below (defaults: all off; no environment variable is
- *    read), which must not be changed while another thread is inside the library.
+ *  - the library has NO process-wide mutable state.  Launch heuristics and
+ *    diagnostic switches are an `avc_tuning` value that a plan captures at
+ *    creation (avc_plan_create_tuned); the op-level entry points at the end of
+ *    this header read a THREAD-LOCAL avc_tuning that avc_set_tuning edits for
+ *    the calling thread only (micro-benchmarks and kernel tests).  No
+ *    environment variable is read anywhere.
  *  - the gradient all-reduce of data-parallel training deliberately lives in
  *    the host framework (torch.distributed "nccl" = RCCL over xGMI):
  *    this library exposes where to cut (avc_plan_param_range) and when each
@@ -113,32 +116,41 @@ int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 int avc_plan_param_range(const avc_plan* p, int part, long* offset, long* numel);
 int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream);
 
-/* 1 = run both encoder branches on the caller's stream only (profiling / debugging); default 0 */
-void avc_set_single_stream(int on);
-
-/* diagnostics only: ablation bits of the conv / wgrad main loops for the timing experiments of
- * scripts/conv_ablate.py and scripts/wgrad_ablate.py (bit0 no DMA, bit1 no MFMA, bit2 no barrier,
- * bit3 no epilogue store).  Non-zero bits produce WRONG results by construction; default 0. */
-void avc_set_debug_ablation(int conv_bits, int wgrad_bits);
-
-/* 1 = InstanceNorm / AdaIN / ReLU of rows that fit one conv tile (T_l = 16, 32, 64) run in the producing
- * conv's epilogue; 0 (default) = always as their own row kernels.  Experimental: same results, but the
- * fused epilogue measured 2-4 % slower end to end on MI355X than the stand-alone row kernels. */
-void avc_set_in_fusion(int on);   /* 0 off (default), 1 = rows of 16/32/64 frames, 16 | 32 = only rows up to that length */
-
-/* smallest batch whose decoder forward is issued as two half-batch kernel chains on two streams
- * (default 32; tuning / test knob, results are the same function either way) */
-void avc_set_decoder_split_min(int n);
+/* ---- launch heuristics and diagnostic switches (plan-scoped) ---------------------------------------------
+ * avc_tuning_init fills the library defaults; a plan copies the struct at creation and never looks at the
+ * caller's copy again.  Every field is an A/B-measurement or test aid: production code passes NULL. */
+typedef struct avc_tuning {
+    int struct_size;        /* sizeof(avc_tuning) of the caller (set by avc_tuning_init; a mismatch is refused) */
+    int single_stream;      /* 1: every kernel on the caller's stream (profiling / per-class event brackets) */
+    int dec_split_min;      /* smallest batch whose decoder forward runs as two half-batch chains on two streams (32) */
+    int conv_x3;            /* 1: split-bf16 conv kernel (csrc/conv_x3.hip) for the k = 5 layers that fill the chip; 2: every eligible layer */
+    int wgrad_x3;           /* 1: split-bf16 products in the whole-chunk weight-gradient launches */
+    int dgrad_par;          /* 0: stride-2 dgrad multiplies all taps of the zero-upsampled dy (default 1: one column parity per wave) */
+    int bank_switch;        /* 0: generic run-time-taps chunk loop for the grouped bank launch / 1x1 convs (default 1) */
+    int conv_ck5;           /* chunk depth of the k >= 4 convs at the op level: 8 (default) | 16 | 32 */
+    int wgrad_batch;        /* weight gradients per batched launch (12) */
+    int wgrad_batch_wgs;    /* workgroups a batched weight-gradient launch aims for (256) */
+    int wgrad_target_wgs;   /* op level: split-K workgroups per weight-gradient launch (256) */
+    int conv_ablation;      /* timing experiments only, WRONG results when set: bit0 no DMA, bit1 no MFMA, bit2 no barrier, bit3 no store */
+    int wgrad_ablation;
+    int op_compute_dtype;   /* op-level conv entry points: 0 fp32, 1 bf16 operands (plans: avc_plan_set_compute_dtype) */
+    long wgrad_batch_units; /* pending (tile x K-chunk) units that trigger a batched launch early (1 << 40 = never) */
+    long tile_thr11, tile_thr21, ck16_wgs, ck32_wgs, kg_wgs;   /* conv tile / chunk-depth / split-K-group thresholds in workgroups */
+} avc_tuning;
+void avc_tuning_init(avc_tuning* t);
+/* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"
+ * (tuning->conv_x3 = 1, wgrad_x3 = 1 unless the caller's tuning already asks for more). */
+#define AVC_PLAN_X3 4
+int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out);
+/* profiling aid on an existing plan: 1 = every kernel of this plan on the caller's stream */
+int avc_plan_set_single_stream(avc_plan* p, int on);
 
 /* Compute dtype of the Conv1d / Linear matrix products (BASELINE config 3: "bf16 compute, fp32 master
  * and optimizer state").  0 = fp32 MFMA, bit-exact fp32 arithmetic (default, the reference's precision);
  * 1 = operands rounded to bf16 (round-to-nearest-even) when they enter the matrix core, fp32 accumulate.
- * Parameters, activations, statistics, gradients and the optimizer stay fp32 in memory either way.
- * Applies to the whole-model entry points of this plan; the op-level conv entry points follow
- * avc_set_op_compute_dtype (process-wide, default 0). */
+ * Parameters, activations, statistics, gradients and the optimizer stay fp32 in memory either way. */
 int avc_plan_set_compute_dtype(avc_plan* p, int dtype);
 int avc_plan_compute_dtype(const avc_plan* p);
-void avc_set_op_compute_dtype(int dtype);
 
 /* ---- whole-model entry points (replace AE.forward / AE.inference, model.py:380-391) */
 /* x: source mel [B,M,T]; x_cond: speaker mel [B,M,T_cond] (may alias x); eps: [B,c_out,Tb]
@@ -168,16 +180,11 @@ int avc_clip_adam_step(float* p, float* g, float* m, float* v, float* vmax, long
                        float beta2, float eps, float weight_decay, int amsgrad, float max_norm, float grad_prescale,
                        int write_clipped, float* ws, float* gnorm_out, void* stream);
 
-/* tuning knobs of the micro-benchmark scripts: "conv_ck5" (8|16|32: chunk depth of k >= 4 convs at the op
- * level), "wgrad_target_wgs" (split-K workgroups per weight-gradient launch, default 256), "in_variant"
- * (InstanceNorm kernel variant), "conv_rs" (0 = never the register-stationary conv kernel), "conv_x3" (1 = split-bf16 conv
- * kernel for the big k = 5 layers of new plans, 2 = for every eligible layer; csrc/conv_x3.hip), "wgrad_x3" (1 = split-bf16
- * products in the whole-chunk weight-gradient launches of new plans and of avc_conv1d_wgrad), "conv_small" (one-shot kernel
- * of the T_l = 16 / 32 layers, csrc/conv_small.hip, tile code 98 at the op level: -1 = launches of <= 64 samples (default),
- * 0 = never, bit 0 = forward, bit 1 = dgrad), "dgrad_par" (0 = stride-2 dgrad multiplies all taps of the zero-upsampled dy),
- * "wgrad_batch" / "wgrad_batch_wgs" (layers per batched weight-gradient launch / workgroups it aims for; captured by plans
- * created afterwards).  Returns -1 for an unknown name. */
+/* Edits ONE field (by name, as in the struct above; also "compute" = op_compute_dtype) of the CALLING THREAD's op-level tuning:
+ * it affects only the op-level entry points at the end of this header when called from the same thread (micro-benchmark
+ * scripts, kernel tests), never a plan.  Returns -1 for an unknown name.  avc_get_op_tuning copies the current value. */
 int avc_set_tuning(const char* name, int value);
+void avc_get_op_tuning(avc_tuning* out);
 
 /* ---- device-side segment feed (replaces PickleDataset.__getitem__ + CollateFn, data_utils.py:10-22,51-54,
  * for an HBM-resident corpus): out[b, m, t] = corpus[starts[b] + t, m], corpus = [n_rows, M] fp32 (mel bins
@@ -232,19 +239,16 @@ int avc_dsp_frame_power(const float* y, long L, int frame_length, int hop_length
 
 /* ---- op-level entry points (one per kernel family and direction) -------- */
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad);
-/* W[Cout][Cin][KS] (nn.Conv1d / nn.Linear state_dict layout; nsrc tensors stacked on Cout) -> LDS-image order */
+/* W[Cout][Cin][KS] (nn.Conv1d / nn.Linear state_dict layout; nsrc tensors stacked on Cout) -> LDS-image order of
+ * csrc/conv_gemm.hip: [chunk][tap][8-channel unit][lane half h][row m][k-step u], channel = 8 unit + 2 u + h (16-byte fragments) */
 int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Cout, int Cin, int KS, int dgrad,
                     float* dst, void* stream);
-/* weight image of the register-stationary conv kernel (csrc/conv_rs.hip; k = 5, 128 reduction channels):
- * pass it as `wp` / `wpd` together with tile = 99 */
-long avc_packed_weight_floats_rs(int Cout, int Cin, int KS, int dgrad);
 /* weight image of the split-bf16 conv kernel (csrc/conv_x3.hip; k = 5, reduction channels a multiple of 16: every operand as
  * three bf16 terms, six bf16 MFMAs per product block, fp32-level accuracy): pass it as `wp` / `wpd` together with tile = 97.
- * Whole-model plans created after avc_set_tuning("conv_x3", 1) use it for their k = 5 layers that fill the chip (opt-in; the
+ * Whole-model plans created with AVC_PLAN_X3 (or tuning.conv_x3) use it for their k = 5 layers that fill the chip (opt-in; the
  * default engine multiplies in exact fp32). */
 long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad);
 int avc_pack_weight_x3(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
-int avc_pack_weight_rs(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
 /* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b); ops = pixel_shuffle_1d factor of the store
  * (model.py:52-59); res/res_mode: y2 = y + resmap(res) (1 identity, 2 avg_pool1d(2, ceil_mode) model.py:248) */
 int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp,

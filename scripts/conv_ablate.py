@@ -1,4 +1,4 @@
-"""Ablation of the conv kernel's main loop (GPU only): avc_set_debug_ablation conv bit0 = no LDS-DMA after the first
+"""Ablation of the conv kernel's main loop (GPU only): avc_set_tuning("conv_ablation") conv bit0 = no LDS-DMA after the first
 chunks, bit1 = no MFMA/LDS reads, bit2 = no barrier.  Results are wrong by construction; timing only."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ def run(B, Cin, Cout, T, KS, tiles, mode="f"):
     for tile in tiles:
         res = []
         for dbg, name in ((0, "full"), (1, "noDMA"), (5, "noDMA,noBar"), (2, "noMFMA"), (7, "empty"), (15, "empty,noEpi")):
-            lib.avc_set_debug_ablation(dbg, 0)
+            lib.avc_set_tuning(b"conv_ablation", dbg)
             if mode == "f":
                 f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wp), P(b), Cout, KS, 1, 1, P(out),
                                                out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, tile, None)
@@ -31,7 +31,7 @@ def run(B, Cin, Cout, T, KS, tiles, mode="f"):
             assert f() == 0
             us = timeit(f)
             res.append(f"{name}: {us:6.1f}us")
-        lib.avc_set_debug_ablation(0, 0)
+        (lib.avc_set_tuning(b"conv_ablation", 0), lib.avc_set_tuning(b"wgrad_ablation", 0))
         print(f"{mode} B={B} {Cin}->{Cout} T={T} k={KS} t{tile} (ideal {flops/157.3e6:5.1f}us): " + " | ".join(res), flush=True)
 
 def run_x3(B, Cin, Cout, T):
@@ -43,12 +43,12 @@ def run_x3(B, Cin, Cout, T):
     wp = pack_x3(w, 0)
     res = []
     for dbg, name in ((0, "full"), (1, "noDMA"), (2, "noMFMA/split"), (3, "neither")):
-        lib.avc_set_debug_ablation(dbg, 0)
+        lib.avc_set_tuning(b"conv_ablation", dbg)
         f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wp), P(b), Cout, 5, 1, 1, P(out), out.stride(0), out.stride(1), 1, 1,
                                        None, 0, 0, 0, 0, 0, None, 97, None)
         assert f() == 0
         res.append(f"{name}: {timeit(f):6.1f}us")
-    lib.avc_set_debug_ablation(0, 0)
+    (lib.avc_set_tuning(b"conv_ablation", 0), lib.avc_set_tuning(b"wgrad_ablation", 0))
     print(f"x3 fwd B={B} {Cin}->{Cout} T={T}: " + " | ".join(res), flush=True)
 
 

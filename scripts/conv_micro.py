@@ -21,12 +21,6 @@ def pack_x3(w, dgrad):
     assert lib.avc_pack_weight_x3(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
     return dst
 
-def pack_rs(w, dgrad):
-    Cout, Cin, KS = w.shape
-    dst = torch.zeros(lib.avc_packed_weight_floats_rs(Cout, Cin, KS, dgrad), device=dev)
-    assert lib.avc_pack_weight_rs(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
-    return dst
-
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -36,7 +30,7 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3  # us
 
-def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
+def run(B, Cin, Cout, T, KS, stride, tiles=(21, 11), which="fdw"):
     x = torch.randn(B, Cin, T, device=dev)
     w = torch.randn(Cout, Cin, KS, device=dev) / (Cin * KS) ** 0.5
     b = torch.randn(Cout, device=dev)
@@ -46,24 +40,18 @@ def run(B, Cin, Cout, T, KS, stride, tiles=(22, 21, 11), which="fdw"):
     dy = torch.randn(B, Cout, To, device=dev)
     dx = torch.zeros(B, Cin, T, device=dev)
     wp, wpd = pack(w, 0), pack(w, 1)
-    rs_ok = KS == 5 and Cin == 128
-    wrs, wrsd = (pack_rs(w, 0), pack_rs(w, 1)) if rs_ok else (None, None)
     x3_ok = ((KS == 5 and Cin % 16 == 0 and Cout % 16 == 0) or (KS == 1 and Cin >= 32 and Cout >= 32)) and 97 in tiles
     wx3, wx3d = (pack_x3(w, 0), pack_x3(w, 1)) if x3_ok else (None, None)
     flops = 2.0 * Cout * Cin * KS * B * To
     res = []
     for tile in tiles:
-        if tile == 99 and not rs_ok:
-            continue
         if "f" in which:
-            f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wrs if tile == 99 else (wx3 if tile == 97 else wp)), P(b), Cout, KS, stride, 1, P(out),
+            f = lambda: lib.avc_conv1d_fwd(P(x), x.stride(0), x.stride(1), 1, B, Cin, T, P(wx3 if tile == 97 else wp), P(b), Cout, KS, stride, 1, P(out),
                                            out.stride(0), out.stride(1), 1, 1, None, 0, 0, 0, 0, 0, None, tile, None)
             assert f() == 0
             us = timeit(f); res.append(f"fwd t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
         if "d" in which:
-            if tile == 99 and Cout != 128:
-                continue
-            f = lambda: lib.avc_conv1d_dgrad(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, To, P(wrsd if tile == 99 else (wx3d if tile == 97 else wpd)), Cin, KS, stride, T, P(dx),
+            f = lambda: lib.avc_conv1d_dgrad(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, To, P(wx3d if tile == 97 else wpd), Cin, KS, stride, T, P(dx),
                                              dx.stride(0), dx.stride(1), 1, None, 0, 0, 0, 0, 0, None, None, tile, None)
             assert f() == 0
             us = timeit(f); res.append(f"dgr t{tile}: {us:7.1f}us {flops/us/1e6:6.1f}TF")
@@ -98,33 +86,14 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s2":
             run(256, 128, 128, T, 5, 2, tiles=(0,), which="d")
     sys.exit(0)
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
-    for ck in (8, 16):
-        lib.avc_set_tuning(b"conv_ck5", ck)
-        print("chunk depth", ck)
-        for B in (256, 128):
-            for T in (32, 16):
-                run(B, 128, 128, T, 5, 1, tiles=(11, 98), which="fd")
-        run(128, 128, 256, 32, 5, 1, tiles=(11, 98), which="f")
-    sys.exit(0)
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rs":
-    B = 256
-    for T in (128, 64, 32, 16):
-        run(B, 128, 128, T, 5, 1, tiles=(11, 99), which="fd")
-    run(B, 128, 128, 128, 5, 2, tiles=(11, 99), which="fd")
-    run(B, 128, 256, 64, 5, 1, tiles=(11, 99), which="f")
-    run(64, 128, 128, 1024, 5, 1, tiles=(11, 99), which="fd")
-    sys.exit(0)
-
 if __name__ == "__main__" and len(sys.argv) > 0 and sys.argv[0] != "x":
     B = 256
-    run(B, 128, 128, 128, 5, 1, tiles=(21, 11, 12))
-    run(B, 128, 128, 64, 5, 1, tiles=(21, 11, 12))
-    run(B, 128, 128, 32, 5, 1, tiles=(11, 12))
-    run(B, 128, 128, 16, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 128, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 64, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 32, 5, 1, tiles=(11,))
+    run(B, 128, 128, 16, 5, 1, tiles=(11,))
     run(B, 128, 128, 128, 5, 2, tiles=(21, 11))
-    run(B, 1104, 128, 128, 1, 1, tiles=(22, 21, 11, 12))
-    run(B, 80, 128, 128, 8, 1, tiles=(21, 11, 12), which="fw")
-    run(B, 128, 1024, 128, 1, 1, tiles=(22, 21, 11, 12), which="f")
+    run(B, 1104, 128, 128, 1, 1, tiles=(21, 11))
+    run(B, 80, 128, 128, 8, 1, tiles=(21, 11), which="fw")
+    run(B, 128, 1024, 128, 1, 1, tiles=(21, 11), which="f")
     run(1, 128, 128, 256, 1, 1, tiles=(11,))

@@ -82,9 +82,8 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
-    ("emu", "tiny128", 2, 40, False),   # 128 hidden channels + avc_set_tuning("conv_rs", 1): the register-stationary conv kernel in the plan
-    ("emu", "tiny128x3", 2, 40, False), # ... + avc_set_tuning("conv_x3", 2): the split-bf16 conv kernel in every eligible layer of the plan
-    pytest.param("gpu", "m80rs", 8, 128, False, marks=GPU),   # the same opt-in kernel on the stock config
+    ("emu", "tiny128", 2, 40, False),   # 128 hidden channels
+    ("emu", "tiny128x3", 2, 40, False), # ... + tuning conv_x3 = 2: the split-bf16 conv kernel in every eligible layer of the plan
     pytest.param("gpu", "m80x3", 8, 128, False, marks=GPU),   # split-bf16 kernel, every eligible layer
     pytest.param("gpu", "m80x3", 3, 40, False, marks=GPU),    # ... odd lengths
     pytest.param("gpu", "tiny", 3, 24, True, marks=GPU),
@@ -97,7 +96,7 @@ CASES = [
 
 
 def get_cfg(name):
-    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80rs": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -109,20 +108,10 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     xd = x.to(dev)
     if transposed:
         xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
-    rs = cfgname in ("tiny128", "m80rs")   # opt-in register-stationary conv kernel: captured by plans created while the knob is on
     x3 = cfgname.endswith("x3")            # opt-in split-bf16 products: conv kernel (2 = every layer of an eligible shape, whatever its size) + weight gradients
-    if rs:
-        assert lib.avc_set_tuning(b"conv_rs", 1) == 0
-    if x3:
-        assert lib.avc_set_tuning(b"conv_x3", 2) == 0 and lib.avc_set_tuning(b"wgrad_x3", 1) == 0
-    try:
-        plan = Plan(cfg, B, T, lib=lib)
-    finally:
-        lib.avc_set_tuning(b"conv_rs", 0)
-        lib.avc_set_tuning(b"conv_x3", 0)
-        lib.avc_set_tuning(b"wgrad_x3", 0)
+    plan = Plan(cfg, B, T, lib=lib, tuning={"conv_x3": 2, "wgrad_x3": 1} if x3 else None)
     assert plan.num_params == len(sd)
-    if rs or x3:   # the opt-in kernels bring their own weight images: the plan really switched
+    if x3:   # the opt-in kernel brings its own weight images: the plan really switched
         assert plan.workspace_floats > Plan(cfg, B, T, lib=lib).workspace_floats
     params = flat_params(plan, sd, dev)
     ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
@@ -409,46 +398,16 @@ def test_decoder_forward_as_two_half_batch_chains(kind, cfgname, B, T):
     params = flat_params(plan, sd, dev)
     outs, _ = O.loss_and_grads(x, eps, sd, cfg, 1.0)
     res = []
-    try:
-        for split_min in (10 ** 6, 2):
-            lib.avc_set_decoder_split_min(split_min)
-            ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
-            plan.forward(params, x.to(dev), None, eps.to(dev), ws)
-            res.append(plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu().clone())
-            torch.testing.assert_close(res[-1], outs["dec"], rtol=1e-4, atol=2e-5)
-            grads = torch.full((plan.param_floats,), float("nan"), device=dev)
-            plan.loss(x.to(dev), 10.0, ws)
-            plan.backward(params, x.to(dev), None, eps.to(dev), grads, ws, lambda_kl=1.0)   # consumes the split forward's saved tensors
-            assert torch.isfinite(grads).all()
-            res.append(grads.cpu().clone())
-    finally:
-        lib.avc_set_decoder_split_min(32)
-    torch.testing.assert_close(res[0], res[2], rtol=1e-5, atol=1e-6)
-    assert ((res[1] - res[3]).norm() / res[1].norm()).item() < 1e-3
-
-
-@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 2, 64), pytest.param("gpu", "m80", 4, 128, marks=GPU)])
-def test_instnorm_fused_into_conv_epilogue_is_the_same_function(kind, cfgname, B, T):
-    """avc_set_in_fusion(1) (experimental, off by default): InstanceNorm / AdaIN / ReLU / residual of rows
-    that fit one conv tile (T_l = 16 / 32 inside a wave, 64 across the two wave halves) computed in the
-    producing conv's epilogue.  Must match the oracle like the default path, forward and backward."""
-    lib, dev = backend(kind)
-    cfg = get_cfg(cfgname)
-    sd = O.make_state_dict(cfg, 5)
-    x, eps = O.make_inputs(cfg, B, T, 5)
-    plan = Plan(cfg, B, T, lib=lib)
-    params = flat_params(plan, sd, dev)
-    outs, _ = O.loss_and_grads(x, eps, sd, cfg, 1.0)
-    lib.avc_set_in_fusion(1)
-    try:
+    for split_min in (10 ** 6, 2):
+        plan = Plan(cfg, B, T, lib=lib, tuning={"dec_split_min": split_min})
         ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
         plan.forward(params, x.to(dev), None, eps.to(dev), ws)
-        dec = plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu()
-        torch.testing.assert_close(dec, outs["dec"], rtol=1e-4, atol=2e-5)
-        plan.loss(x.to(dev), cfg["lambda"]["lambda_rec"], ws)
+        res.append(plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu().clone())
+        torch.testing.assert_close(res[-1], outs["dec"], rtol=1e-4, atol=2e-5)
         grads = torch.full((plan.param_floats,), float("nan"), device=dev)
-        plan.backward(params, x.to(dev), None, eps.to(dev), grads, ws, lambda_kl=1.0)
-        _, grads_m = branch_matched_oracle(plan, ws, x, eps, sd, cfg)
-        check_grads(plan, grads, grads_m, tol=1e-4, cfg=cfg)
-    finally:
-        lib.avc_set_in_fusion(0)
+        plan.loss(x.to(dev), 10.0, ws)
+        plan.backward(params, x.to(dev), None, eps.to(dev), grads, ws, lambda_kl=1.0)   # consumes the split forward's saved tensors
+        assert torch.isfinite(grads).all()
+        res.append(grads.cpu().clone())
+    torch.testing.assert_close(res[0], res[2], rtol=1e-5, atol=1e-6)
+    assert ((res[1] - res[3]).norm() / res[1].norm()).item() < 1e-3

@@ -53,20 +53,22 @@ FWD = [
     (2, 8, 32, 17, 2, 1, 11),
     (1, 40, 32, 33, 1, 1, 11),    # 1x1
     (2, 16, 130, 64, 3, 1, 21),   # 128x64 tile, 2 M tiles
-    (1, 16, 128, 130, 5, 1, 22),  # 128x128 tile
+    (1, 16, 128, 130, 5, 1, 21),  # 128-row tile, three column tiles, ragged last one
+    (2, 20, 32, 32, 5, 1, 11),    # reduction channels not a multiple of 8: the last 8-channel unit straddles Cin
+    (2, 44, 32, 24, 3, 1, 11),    # ... with 16-channel chunks: a whole padded unit + a straddling one
     (5, 16, 32, 3, 5, 1, 11),     # bottleneck-sized rows
     (2, 16, 32, 21, 5, 2, 11),    # stride 2, odd T
     (2, 40, 32, 32, 5, 1, 11),    # 5 K-chunks: two split-K wave groups with unequal chunk counts
     (3, 64, 64, 16, 5, 1, 11),    # 8 K-chunks, several short samples per tile, split-K
-    (5, 128, 40, 16, 5, 1, 98),   # tile code 98 = the one-shot short-row kernel (conv_small.hip) or an error: ragged last tile, partial M slab
-    (9, 128, 128, 32, 5, 1, 98),  # 128-column tiles, B not a multiple of the 4 samples per tile
+    (5, 128, 40, 16, 5, 1, 0),    # short rows, launcher's own choice of tile / chunk depth / split-K groups
+    (9, 128, 128, 32, 5, 1, 0),
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(8, 128, 256, 64, 5, 1, 0, marks=GPU),
     pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
     pytest.param(4, 1104, 128, 128, 1, 1, 0, marks=GPU),
-    pytest.param(4, 80, 128, 128, 8, 1, 22, marks=GPU),
-    pytest.param(2, 128, 128, 1024, 5, 1, 22, marks=GPU),
+    pytest.param(4, 80, 128, 128, 8, 1, 21, marks=GPU),
+    pytest.param(2, 128, 128, 1024, 5, 1, 21, marks=GPU),
     pytest.param(2, 512, 128, 128, 7, 1, 21, marks=GPU),
 ]
 
@@ -122,15 +124,16 @@ DG = [
     (1, 16, 32, 130, 5, 1, 11),   # right mirror spans the last two tiles
     (1, 40, 32, 33, 1, 1, 11),
     (5, 16, 32, 3, 5, 1, 11),
-    (1, 16, 128, 130, 5, 1, 22),
+    (1, 16, 128, 130, 5, 1, 21),
     (2, 16, 32, 66, 5, 1, 21),
-    (5, 40, 128, 16, 5, 1, 98),   # conv_small.hip, mirror windows of 4 samples per tile
+    (2, 20, 32, 32, 5, 1, 11),    # reduction channels (Cout here) not a multiple of 8
+    (5, 40, 128, 16, 5, 1, 0),    # mirror windows of 4 samples per tile
     (3, 16, 32, 32, 5, 2, 11),    # stride 2 with one column parity per wave (even taps / odd taps): two samples per tile
     (5, 16, 32, 16, 5, 2, 11),    # ... four samples per tile, ragged last tile
     (1, 16, 32, 128, 5, 2, 11),   # ... two tiles per sample
     (1, 16, 32, 101, 5, 2, 11),   # ... odd length, partial last tile
     (2, 64, 32, 32, 5, 2, 11),    # ... with the two split-K wave groups
-    (3, 128, 128, 32, 5, 1, 98),
+    (3, 128, 128, 32, 5, 1, 0),
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
@@ -162,11 +165,11 @@ def test_conv_dgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride, tile):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("T", [16, 32])
-def test_conv_small_with_16_channel_chunks(kind, T):
-    """conv_small.hip reads the packed images of conv_gemm.hip at either chunk depth the plan uses for k = 5."""
+@pytest.mark.parametrize("T,ck", [(16, 16), (32, 16), (32, 32)])
+def test_conv_with_deeper_chunks(kind, T, ck):
+    """The plan gives layers that cannot fill the chip 16- or 32-channel K-chunks (conv_ck5 at the op level): same function."""
     lib, dev = backend(kind)
-    assert lib.avc_set_tuning(b"conv_ck5", 16) == 0
+    assert lib.avc_set_tuning(b"conv_ck5", ck) == 0
     try:
         g = torch.Generator().manual_seed(T)
         B, C = 5, 128
@@ -176,13 +179,13 @@ def test_conv_small_with_16_channel_chunks(kind, T):
         y = O.pad_conv(x, w, b, 1)
         dy = torch.randn(y.shape, generator=g)
         (dx_ref,) = torch.autograd.grad(y, x, dy)
-        out, _ = conv_fwd(lib, dev, x.detach().to(dev), w.to(dev), b.to(dev), 1, act=0, tile=98)
+        out, _ = conv_fwd(lib, dev, x.detach().to(dev), w.to(dev), b.to(dev), 1, act=0, tile=11)
         torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-5, atol=2e-5)
         wpd = pack(lib, dev, [w.to(dev)], 1)
         dx = torch.full((B, C, T), float("nan"), device=dev)
         dyd = dy.to(dev)
         rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), dyd.stride(2), 1, B, C, T, P(wpd), C, 5, 1, T, P(dx),
-                                  dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None, None, 98, None)
+                                  dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None, None, 11, None)
         assert rc == 0
         torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
     finally:
@@ -322,7 +325,7 @@ def bf16r(t):
                                                      pytest.param(8, 128, 128, 128, 5, 1, marks=GPU),
                                                      pytest.param(64, 128, 128, 16, 5, 1, marks=GPU)])
 def test_conv_bf16_operand_mode(kind, B, Cin, Cout, T, KS, stride):
-    """avc_set_op_compute_dtype(1): operands rounded to bf16 (RNE) inside the matrix core, fp32
+    """avc_set_tuning("compute", 1): operands rounded to bf16 (RNE) inside the matrix core, fp32
     accumulate.  bf16 x bf16 products are exact in fp32, so forward and wgrad must equal the fp32
     ops applied to bf16-rounded operands up to summation order; dgrad rounds the reflect-folded
     gradient, so it is compared with the fp32 result at bf16 accuracy."""
@@ -333,7 +336,7 @@ def test_conv_bf16_operand_mode(kind, B, Cin, Cout, T, KS, stride):
     x = torch.randn(B, Cin, T, generator=g)
     w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
     b = torch.randn(Cout, generator=g)
-    lib.avc_set_op_compute_dtype(1)
+    lib.avc_set_tuning(b"compute", 1)
     try:
         out, _ = conv_fwd(lib, dev, x.to(dev), w.to(dev), b.to(dev), stride=stride, act=1)
         ref = torch.relu(O.pad_conv(bf16r(x), bf16r(w), b, stride))
@@ -363,99 +366,7 @@ def test_conv_bf16_operand_mode(kind, B, Cin, Cout, T, KS, stride):
         err = ((dx.cpu() - dx_ref).norm() / dx_ref.norm()).item()
         assert 1e-5 < err < 1e-2, err
     finally:
-        lib.avc_set_op_compute_dtype(0)
-
-
-# ---- register-stationary conv kernel (csrc/conv_rs.hip): tile code 99 + its own weight image
-def pack_rs(lib, dev, w, dgrad):
-    Cout, Cin, KS = w.shape
-    n = lib.avc_packed_weight_floats_rs(Cout, Cin, KS, dgrad)
-    dst = torch.full((n,), float("nan"), device=dev)
-    assert lib.avc_pack_weight_rs(P(w), Cout, Cin, KS, dgrad, P(dst), None) == 0
-    assert torch.isfinite(dst).all()
-    return dst
-
-
-RS_FWD = [
-    # B, Cout, T, stride
-    (2, 32, 40, 1),      # partial second tile
-    (1, 160, 32, 1),     # two 128-row slab groups, rows >= Cout masked
-    (3, 32, 16, 1),      # two samples per 32-column tile, B odd
-    (2, 32, 21, 2),      # stride 2, odd T
-    (2, 32, 70, 2),      # stride 2: 128-float LDS rows
-    (11, 32, 3, 1),      # bottleneck rows: 10 samples per tile
-    pytest.param(300, 128, 128, 1, marks=GPU),   # > 256 persistent workgroups' worth of tiles
-    pytest.param(256, 256, 64, 1, marks=GPU),
-    pytest.param(64, 128, 128, 2, marks=GPU),
-    pytest.param(200, 128, 16, 1, marks=GPU),
-    pytest.param(3, 128, 1024, 1, marks=GPU),
-]
-
-
-@pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("B,Cout,T,stride", RS_FWD)
-def test_conv_rs_fwd_matches_pad_conv(kind, B, Cout, T, stride):
-    if kind == "emu" and B * Cout * T > 12000:
-        pytest.skip("gpu-sized")
-    lib, dev = backend(kind)
-    Cin, KS = 128, 5
-    g = torch.Generator().manual_seed(B * 100 + T)
-    x = torch.randn(B, Cin, T, generator=g)
-    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
-    b = torch.randn(Cout, generator=g)
-    res = torch.randn(B, Cout, T, generator=g)
-    y = torch.relu(O.pad_conv(x, w, b, stride))
-    Tout = y.shape[2]
-    wp = pack_rs(lib, dev, w.to(dev), 0)
-    out = torch.full((B, Cout, Tout), float("nan"), device=dev)
-    out2 = torch.full_like(out, float("nan"))
-    xd, bd, rd = x.to(dev), b.to(dev), res.to(dev)
-    rmode = 2 if stride == 2 else 1
-    rc = lib.avc_conv1d_fwd(P(xd), xd.stride(0), xd.stride(1), xd.stride(2), B, Cin, T, P(wp), P(bd), Cout, KS, stride, 1, P(out),
-                            out.stride(0), out.stride(1), out.stride(2), 1, P(rd), rmode, rd.stride(0), rd.stride(1), rd.stride(2), T,
-                            P(out2), 99, None)
-    assert rc == 0, rc
-    torch.testing.assert_close(out.cpu(), y, rtol=1e-5, atol=2e-5)
-    rref = O.avg_pool_ceil(res, 2) if stride == 2 else res
-    torch.testing.assert_close(out2.cpu(), y + rref, rtol=1e-5, atol=2e-5)
-
-
-RS_DG = [
-    # B, Cin(out of dgrad), T, stride
-    (2, 32, 40, 1),
-    (1, 32, 70, 1),      # right mirror in the third tile
-    (3, 32, 16, 1),
-    (2, 32, 21, 2),
-    (2, 40, 66, 2),
-    (11, 32, 6, 1),      # short rows: 5 samples per tile, partial last tile
-    pytest.param(300, 128, 128, 1, marks=GPU),
-    pytest.param(64, 128, 128, 2, marks=GPU),
-    pytest.param(200, 128, 16, 1, marks=GPU),
-    pytest.param(3, 128, 1024, 1, marks=GPU),
-]
-
-
-@pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("B,Cin,T,stride", RS_DG)
-def test_conv_rs_dgrad_matches_autograd(kind, B, Cin, T, stride):
-    if kind == "emu" and B * Cin * T > 12000:
-        pytest.skip("gpu-sized")
-    lib, dev = backend(kind)
-    Cout, KS = 128, 5
-    g = torch.Generator().manual_seed(B * 7 + T)
-    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
-    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
-    y = O.pad_conv(x, w, None, stride)
-    dy = torch.randn(y.shape, generator=g)
-    (dx_ref,) = torch.autograd.grad(y, x, dy)
-    wpd = pack_rs(lib, dev, w.to(dev), 1)
-    dx = torch.full((B, Cin, T), float("nan"), device=dev)
-    dyd = dy.to(dev)
-    rc = lib.avc_conv1d_dgrad(P(dyd), dyd.stride(0), dyd.stride(1), dyd.stride(2), 1, B, Cout, dy.shape[2], P(wpd), Cin,
-                              KS, stride, T, P(dx), dx.stride(0), dx.stride(1), dx.stride(2), None, 0, 0, 0, 0, 0, None,
-                              None, 99, None)
-    assert rc == 0, rc
-    torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-5, atol=2e-5)
+        lib.avc_set_tuning(b"compute", 0)
 
 
 # ---- split-bf16 conv kernel (csrc/conv_x3.hip): tile code 97 + its own weight image.  Every operand as three bf16 terms,
