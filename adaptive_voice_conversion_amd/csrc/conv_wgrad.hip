@@ -17,7 +17,15 @@
 #include "avc_internal.h"
 #include "conv_x3_shared.h"
 
-#define WG_DYROW 33
+// LDS row strides (floats).  General form: odd (33 / (spc XSEG) | 1): the 32 lanes of a half-wave read one column of 32 different
+// rows with ds_read_b32, conflict-free.  LIN instances (whole 32-column chunks of a stride-1 layer): rows are 16-byte aligned with
+// (stride / 4) ODD, so that a lane's four k-steps -- columns 8 g + 4 h + u of the chunk in BOTH operands -- are one ds_read_b128
+// and the 16 lanes of each ds_read_b128 service group (MI355X_MICROARCH.md, LDS) fall on 16 different 16-byte bank slots.
+static constexpr __host__ __device__ int wg_dyrow(bool lin) { return lin ? 36 : 33; }
+static constexpr __host__ __device__ int wg_xrow_lin(int KS) {
+    int r = (31 + KS + 3) / 4;       // 16-byte units covering XSEG = 31 + KS positions
+    return 4 * (r | 1);              // KS = 1: 36, 2..5: 36, 6..8: 44
+}
 #define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue)
 
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
@@ -70,7 +78,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     const int Tc = a.Tc, spc = a.spc;
     const int lgTc = 31 - __builtin_clz(Tc);
     const int XSEG = (Tc - 1) * a.stride + KS;
-    const int XROW = (spc * XSEG) | 1;  // odd row stride: conflict-free column reads
+    constexpr int WG_DYROW = wg_dyrow(LIN);
+    const int XROW = LIN ? wg_xrow_lin(KS) : ((spc * XSEG) | 1);
     const int DYS = TCO * WG_DYROW, XS = TCI * XROW;
     const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
     float* dyT = smem;             // [2][TCO][WG_DYROW]
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     // that are never stored.  The chunk-invariant byte offsets live in producer registers, the
     // chunk origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
     constexpr int NPD = (TCO * WG_DYROW + 255) / 256;  // dy pieces per wave
-    constexpr int NPX = (TCI * (KS == 1 ? 33 : 71) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
+    constexpr int NPX = (TCI * (LIN ? wg_xrow_lin(KS) : (KS == 1 ? 33 : 71)) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
     // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the
     // reflection is chunk-invariant, so the x offsets are complete and only the base moves.
     const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
@@ -298,15 +307,24 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
                 if constexpr (X3 && LIN && !BF) {
                     // two blocks of 16 columns: lane-half h owns columns 16 kb + 8 h .. + 7 of the chunk
                     constexpr int NX = 8 + KS - 1;   // x values under the KS shifted windows of 8 columns
-                    auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {
+                    auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {   // 16-byte aligned rows (LIN): ds_read_b128
                         const float* ap = arow + 16 * kb + 8 * h;
                         const float* bp = brow + 16 * kb + 8 * h;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) av[i] = ap[i];
+                        for (int i4 = 0; i4 < 2; ++i4) {
+                            const f32x4 v = *(const f32x4*)(ap + 4 * i4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) av[4 * i4 + i] = v[i];
+                        }
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int i = 0; i < NX; ++i) xv[nb][i] = bp[nb * 32 * XROW + i];
+                            for (int i4 = 0; i4 < (NX + 3) / 4; ++i4) {
+                                const f32x4 v = *(const f32x4*)(bp + nb * 32 * XROW + 4 * i4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (4 * i4 + i < NX) xv[nb][4 * i4 + i] = v[i];
+                            }
                     };
                     auto block = [&](const float (&av)[8], const float (&xv)[NB][NX]) {
                         unsigned ah[8], am[8], al[8];
@@ -349,6 +367,50 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
                     fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
                     block(a0, x0);
                     block(a1, x1);
+                } else if constexpr (LIN) {
+                    // Four groups of 8 columns per chunk; in group g lane-half h owns columns 8 g + 4 h + u, u = k-step 0..3, in BOTH
+                    // operands (the sum over columns does not care about the order).  Its four dy values are ONE ds_read_b128, and the
+                    // 4 + KS - 1 x values under its KS shifted windows are (KS + 6) / 4 more: 3 reads per 20 MFMAs at k = 5, where
+                    // round 2 issued 6 ds_read_b32 per 5 (the consumer waves run alone on their SIMD: every read they issue is
+                    // matrix-pipe idle time, profiles/r02_mfma_probe.log).  BF: the same fragments rounded to bf16, one
+                    // v_mfma_f32_32x32x8_bf16 per tap and group.
+                    constexpr int NX4 = (KS + 6) / 4;          // 16-byte reads covering 4 + KS - 1 values
+                    auto ldgrp = [&](int g, f32x4& av, f32x4 (&xv)[NB][NX4]) {
+                        const int c = 8 * g + 4 * h;
+                        av = *(const f32x4*)(arow + c);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int i4 = 0; i4 < NX4; ++i4) xv[nb][i4] = *(const f32x4*)(brow + nb * 32 * XROW + c + 4 * i4);
+                    };
+                    f32x4 av[2], xv[2][NB][NX4];
+                    ldgrp(0, av[0], xv[0]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cur = g & 1;
+                        if (g + 1 < 4) ldgrp(g + 1, av[cur ^ 1], xv[cur ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay in front of the MFMAs they overlap with ...
+                        if constexpr (BF) {
+                            const avc_s16x4 ap = avc_pack_bf16x4(av[cur][0], av[cur][1], av[cur][2], av[cur][3]);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int j = 0; j < KS; ++j) {
+                                    const avc_s16x4 bp = avc_pack_bf16x4(xv[cur][nb][j >> 2][j & 3], xv[cur][nb][(j + 1) >> 2][(j + 1) & 3],
+                                                                         xv[cur][nb][(j + 2) >> 2][(j + 2) & 3], xv[cur][nb][(j + 3) >> 2][(j + 3) & 3]);
+                                    acc[nb * KS + j] = avc_mfma_bf16(ap, bp, acc[nb * KS + j]);
+                                }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                    for (int j = 0; j < KS; ++j)
+                                        acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], xv[cur][nb][(u + j) >> 2][(u + j) & 3], acc[nb * KS + j], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // ... and one group ahead only
+                    }
                 } else if constexpr (BF) {
                     // four k-steps (8 columns) per v_mfma_f32_32x32x8_bf16: slot j of lane-half h carries
                     // column 2(4g + j) + h of the chunk in both operands; operands are rounded to bf16 here
@@ -451,7 +513,8 @@ static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
 static size_t wgrad_lds_bytes(const WgradArgs& a, int NB, int WCO) {
     const int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
-    const int XROW = (a.spc * XSEG) | 1;
+    const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
+    const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
     return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 16;
 }
 

@@ -380,6 +380,9 @@ def main():
                     help="tracing aid: park the GPU this long before every timed step so that the (tracer-slowed) host has "
                          "the whole step enqueued when it starts; the reported time is then meaningless")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-class table here")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (CUDA tensors staged through the "
+                         "host: lets N ranks SHARE one GPU, which executes the multi-rank code path on a 1-GPU box; not a scaling number)")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
                     help="avc_tuning field captured by the plans (A/B measurements), e.g. wgrad_batch=1, kg_wgs=0")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -394,13 +397,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if a.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()   # ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()   # what the RCCL process group actually has
     if a.gpus != world and rank == 0:
         print(f"warning: --gpus {a.gpus} but the process group has {world} rank(s)", file=sys.stderr)
@@ -517,7 +525,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": workload + (" + device-side segment gather from an HBM-resident corpus inside the timed loop" if feed else ""),
                        "baseline_config_index": cfg_idx, "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
-                       "world_size": world, "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
+                       "world_size": world, "dist_backend": (a.dist_backend if world > 1 else None), "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
                        "tuning": a.tune or None,
                        "allreduce": ("decoder range on a communication stream under the encoders' backward, encoders' range after it; "
                                      "RCCL via torch.distributed nccl") if world > 1 else None,

@@ -17,14 +17,14 @@ from oracle import avc_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, out_dir, steps):
+def _launch(world, out_dir, steps, backend="nccl"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "nccl", str(out_dir), str(steps)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), backend, str(out_dir), str(steps)]
     subprocess.run(cmd, env=env, check=True, timeout=600)
 
 
@@ -64,3 +64,23 @@ def test_two_rank_nccl_step_equals_global_batch_step(tmp_path):
     assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
     diff = (params - r0["params"]).abs()
     assert (diff > 2e-6).float().mean().item() < 5e-3
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_over_gloo_equal_the_global_batch_step(tmp_path):
+    """the N > 1 code path on hardware that IS available -- two ranks that share the one leased GPU,
+    CUDA tensors through a gloo group.  Executes, outside the simulator, what a 2-GPU RCCL job executes: the decoder-range
+    all-reduce on the communication stream behind avc_plan_stream_wait_grads, the encoders' range behind the whole backward,
+    the optimizer behind both, the 1/W prescale, per-rank noise streams, the rank-0 atomic checkpoint -- and must equal the
+    global-batch step of one process like the 2-rank gloo test does on CPU (tests/test_dist_gloo.py)."""
+    _launch(2, tmp_path, 2, backend="gloo")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["comm_stream"] and r1["comm_stream"], "the overlapped all-reduce branch did not run"
+    assert torch.equal(r0["params"], r1["params"]), "replicas diverged"
+    assert not torch.equal(r0["eps_draw"], r1["eps_draw"]), "ranks share one noise stream"
+    params, metas = _single(8, 2)
+    assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
+    diff = (params - r0["params"]).abs()
+    assert (diff > 2e-6).float().mean().item() < 5e-3
+    sd = torch.load(tmp_path / "ckpt.ckpt", map_location="cpu")
+    assert len(sd) == 166 and not list(tmp_path.glob("*.tmp.*"))
