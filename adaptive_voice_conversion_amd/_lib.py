@@ -43,6 +43,7 @@ class Tuning(ctypes.Structure):
 
 
 PLAN_X3 = 4
+PLAN_RAGGED = 8
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 
@@ -73,6 +74,10 @@ def declare(lib):
     lib.avc_get_op_tuning.restype = None
     lib.avc_plan_create_tuned.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, c_int, ctypes.POINTER(Tuning), ctypes.POINTER(c_void_p)]
     lib.avc_plan_set_single_stream.argtypes = [c_void_p, c_int]
+    lib.avc_plan_create_ragged.argtypes = [ctypes.POINTER(ModelCfg), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(Tuning),
+                                           ctypes.POINTER(c_void_p)]
+    lib.avc_plan_ragged_out.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_long)]
+    lib.avc_forward_ragged.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_gather_segments.argtypes = [c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.avc_plan_destroy.argtypes = [c_void_p]
     lib.avc_plan_destroy.restype = None

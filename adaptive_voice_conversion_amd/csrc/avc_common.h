@@ -53,7 +53,25 @@ struct ConvGroup {
     const float* res;   // residual / gradient-join source (may be null)
     const float* mask;  // secondary = value * (mask > 0)      (ReLU backward)
     int KS, padL, padR, nchunk, CK;
-    int pad_[3];
+    int out_c0;         // ragged launches: first channel of this group's rows in the packed output buffer (the conv bank writes a slice of the concat buffer)
+    int pad_[2];
+};
+
+// Ragged forward launches (AE.inference over utterances of DIFFERENT lengths in one launch set; reference: inference.py:54-70,
+// model.py:387-391 -- the reference itself converts one utterance per call).  Every activation tensor is a PACKED buffer:
+// sample b owns a contiguous [channels][T_b] block that starts at element channels * off[b], off = prefix sums of the per-sample
+// lengths at that level of the network.  One column tile = 64 output frames of ONE sample; tile[2 i], tile[2 i + 1] = its sample
+// and first output frame.  All arrays are device pointers into the plan's workspace (uploaded by avc_forward_ragged).
+struct ConvRag {
+    const int* tile;      // null: uniform lengths (every other field unused)
+    const int* Tsrc;      // per-sample length of the source rows
+    const int* offsrc;    // ... and first frame of the sample in the packed source buffer
+    const int* Tout;      // per-sample conv output length
+    const int* offout;    // first frame of the sample in the packed OUTPUT buffer (its rows hold ops * Tout frames)
+    const int* Tres;      // residual rows
+    const int* offres;
+    int cx, cout, cres;   // channels per sample of the packed source / output / residual buffers
+    int ntiles;
 };
 
 struct ConvArgs {
@@ -72,6 +90,7 @@ struct ConvArgs {
     int ngroups;
     int dbg;  // ablation switches of the micro-benchmarks (0 in the product path)
     int bf16; // AVC_COMPUTE_*
+    ConvRag rag;
     int img;  // weight image g[0].wp points at: AVC_IMG_K4 (conv_gemm.hip) or AVC_IMG_X3 (conv_x3.hip)
     int par;  // stride-2 dgrad: columns of one parity per wave, each wave multiplies only the taps that meet non-zero
               // positions of the zero-upsampled dy (set by the launcher)
@@ -138,6 +157,22 @@ struct INFwdArgs {
     const float* res;   // residual rows [R][Tres] (contiguous) or null
     int res_mode, Tres;
     int R, C, T, relu;
+};
+
+// ragged InstanceNorm forward (ragged_rows.hip): packed [C][T_b] blocks, see ConvRag
+struct RagINArgs {
+    const float* y;
+    float* out;
+    const int* T;       // per-sample row length
+    const int* off;     // first frame of the sample in the packed y / out buffers
+    const float* cond;  // AdaIN affine [B][cond_sb] or null
+    long cond_sb;
+    int cond_off;
+    const float* res;   // packed residual buffer or null
+    const int* Tres;
+    const int* offres;
+    int res_mode;
+    int B, C;
 };
 
 struct INBwdArgs {

@@ -56,6 +56,10 @@ int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* 
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);
+int avc_launch_rag_in_fwd(const RagINArgs& a, hipStream_t s);
+int avc_launch_rag_copy_rows(const float* x, long xsc, long xst, const int* T, const int* off, int B, int M, int sumT, float* dst, int CC, int c0,
+                             hipStream_t s);
+int avc_launch_rag_timepool_fwd(const float* in, const int* T, const int* off, int B, int C, float* out, hipStream_t s);
 int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int M, int T, float* dst, long db, long dc,
                          hipStream_t s);
 int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hipStream_t s);

@@ -41,6 +41,11 @@
 // A tap is a 16-byte shift of the X address, so all KS taps are served from the one tile.
 // MIR: 0 = no mirror window, 1 = ONE mirror window per column (a column of a sample of >= 2 (padL + padR) + 2 frames is within
 // pad of at most one edge), 2 = both windows (very short samples)
+// upper bound of the LDS-DMA items of one chunk that one wave issues: ceil(KS GR WM / 2) weight pieces, NJ4 / 2 position groups
+static constexpr __host__ __device__ int conv_dma_items(int WM, int KSC, int GRC) {
+    return (KSC * GRC * WM + 1) / 2 > AVC_CONV_NJ4 / 2 ? (KSC * GRC * WM + 1) / 2 : AVC_CONV_NJ4 / 2;
+}
+
 template <int WM, int MIR>
 static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4& bv, const float* Ap, const float* Xp, int cb4, int cbl4, int cbr4) {
 #pragma unroll
@@ -69,13 +74,21 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM], const f3
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
 // TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
 // taps of a column meet the zeros of the zero-upsampled dy)
-template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0>
+// dma(i): issues the i-th LDS-DMA item of the NEXT chunk (conv_gemm_kernel).  The straight-line chunks call it between the
+// units' MFMAs: a wave's matrix instructions are one dependent chain (one accumulator), so the wave has ~64 idle issue cycles
+// behind every MFMA -- and since all workgroups of a launch run in lock step, DMA instructions issued together at the top of
+// a chunk are a phase in which NO wave of the SIMD feeds the matrix pipe (measured, scripts/conv_ablate.py: the k = 5, T = 128
+// forward layer takes 70.7 us, 55.4 without the DMA and 22.3 without the MFMAs: the two did not overlap at all).
+template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0, class DMA>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
-                                                      int a_lane4, int cb4, int cbl4, int cbr4) {
+                                                      int a_lane4, int cb4, int cbl4, int cbr4, DMA&& dma) {
     constexpr int BM4 = 64 * WM * 4;   // floats of one (tap, unit, h) plane of the A stage
     if constexpr (KSC > 0) {
         constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
         constexpr int U = NTAP * GRC;
+        constexpr int NI = conv_dma_items(WM, KSC, GRC);   // items a wave may own; those beyond the unit count go first
+#pragma unroll
+        for (int i = U; i < NI; ++i) dma(i);
         f32x4 av[2][WM], bv[2];
         auto unit_ptrs = [&](int u, const float*& Ap, const float*& Xp) {
             const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g8 = u % GRC;
@@ -91,6 +104,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
                 unit_ptrs(u + 1, Ap, Xp);
                 conv_load_unit<WM, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
             }
+            dma(u);
             conv_mma_unit<WM, BF>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
@@ -109,11 +123,18 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
     }
 }
 
+// (taps, chunk depth) pairs the grouped bank launch has straight-line chunks for
+static __device__ __forceinline__ bool conv_bank_case(int KS, int GR) {
+    return (KS == 1 && GR == 4) || ((KS == 2 || KS == 3) && GR == 2) || (KS >= 4 && KS <= 8 && GR == 1);
+}
+
 // KG > 1: intra-workgroup split-K for layers that cannot fill the chip (T_l <= 32: 128-256 tiles, each
 // wave a serial chain of 320 MFMAs).  KG groups of 4 waves work on the SAME output tile; group kg
 // runs its own double-buffered pipeline over chunks kg, kg+KG, ... and the groups' accumulators are
 // summed through LDS in a fixed order at the end (deterministic).
-template <int WM, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false>
+// RAG (forward only): ragged launch -- the tile's sample, first column and the sample's own lengths / packed-buffer bases come
+// from the ConvRag tables; everything else is the uniform kernel with one sample per tile.
+template <int WM, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false, bool RAG = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -129,8 +150,35 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     const int KS = g.KS, padL = g.padL, padR = g.padR, CK = g.CK, nchunk = g.nchunk;
     const int GR = CK >> 3;
-    const int Tout = a.Tout;
-    const ConvGeom q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
+    int Tout = a.Tout, Tsrc = a.Tsrc, Bv = a.B;
+    long xsb = a.x.sb, xsc = a.x.sc;
+    const float* xptr = a.x.ptr;
+    ConvEpi epi = conv_epi(a);
+    ConvGeom q;
+    if constexpr (RAG) {
+        const int rb_ = a.rag.tile[2 * blockIdx.x], rt0 = a.rag.tile[2 * blockIdx.x + 1];
+        Tsrc = a.rag.Tsrc[rb_];
+        Tout = a.rag.Tout[rb_];
+        Bv = 1;
+        xsb = 0;
+        xsc = a.x.sc < 0 ? Tsrc : a.x.sc;   // packed activations: channel rows of the sample's own length; (the packed input brings explicit strides)
+        xptr += (long)a.rag.cx * a.rag.offsrc[rb_];
+        q.b0 = 0; q.t0 = rt0; q.SPT = 1; q.ncols = BN;
+        q.SEG = (BN - 1) * a.stride + KS; q.seg_p0 = rt0 * a.stride;
+        q.ROWDATA = q.SEG; q.ROW = q.SEG + KS;
+        epi.Tout = Tout;
+        epi.ob = 0;
+        epi.oc = (long)a.ops * Tout;
+        epi.obase = (long)a.rag.cout * a.rag.offout[rb_] + (long)g.out_c0 * epi.oc;
+        if (a.res_mode != AVC_RES_NONE) {
+            epi.Tres = a.rag.Tres[rb_];
+            epi.rb = 0;
+            epi.rc = epi.Tres;
+            epi.rbase = (long)a.rag.cres * a.rag.offres[rb_];
+        }
+    } else {
+        q = conv_geom(a.mode, a.stride, Tout, KS, BN, blockIdx.x);
+    }
     const int ROW = q.ROW;
     const int m_tile0 = blockIdx.y * BM;
 
@@ -147,7 +195,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     // offsets (chunk-invariant): xo[jj] = element offset of the position inside a channel row plus the lane's channel
     // offset, or -1 where the tile holds a structural zero (halo / null window / masked / past the row).
     const int ul = lane & 3;
-    const long lu = (a.x.ps == 1) ? (long)(2 * ul) * a.x.sc : (long)ul * a.x.sc;   // channel 2u of the unit (ps = 2: pixel-unshuffled view, model.py:52-59)
+    const long lu = (a.x.ps == 1) ? (long)(2 * ul) * xsc : (long)ul * xsc;   // channel 2u of the unit (ps = 2: pixel-unshuffled view, model.py:52-59)
     const int jpar = wave >> 1;
     int xo[AVC_CONV_NJ4 / 2];
 #pragma unroll
@@ -158,16 +206,16 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             int seg = p / q.SEG, qq = p - seg * q.SEG;
             int b = q.b0 + seg;
             int pp = q.seg_p0 + qq;
-            if (b < a.B) {
+            if (b < Bv) {
                 if (a.mode == 0) {
                     int v = pp - padL;
-                    int r = avc_reflect(v, a.Tsrc);
-                    if (r >= 0 && r < a.Tsrc) sp = (int)(b * a.x.sb + (long)r * a.x.st + lu);
+                    int r = avc_reflect(v, Tsrc);
+                    if (r >= 0 && r < Tsrc) sp = (int)(b * xsb + (long)r * a.x.st + lu);
                 } else {
                     int v = pp - (KS - 1);
                     if (v >= 0) {
                         int vs = v / a.stride;
-                        if (vs * a.stride == v && vs < a.Tsrc) sp = (int)(b * a.x.sb + (long)vs * a.x.st + lu);
+                        if (vs * a.stride == v && vs < Tsrc) sp = (int)(b * xsb + (long)vs * a.x.st + lu);
                     }
                 }
             }
@@ -188,21 +236,21 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             if (Tout >= BN) {
                 bl = 0;
                 t = q.t0 + 2 * li + wave_n;
-                v = (t < Tout) && (q.b0 < a.B);
+                v = (t < Tout) && (q.b0 < Bv);
             } else {
                 const int halfT = Tout >> 1;
                 bl = li / halfT;
                 t = 2 * (li - bl * halfT) + wave_n;
-                v = (bl < q.SPT) && (q.b0 + bl < a.B);
+                v = (bl < q.SPT) && (q.b0 + bl < Bv);
             }
-        } else if (q.SPT == 1 && Tout >= BN) {
+        } else if (RAG || (q.SPT == 1 && Tout >= BN)) {
             bl = 0;
             t = q.t0 + n;
-            v = (t < Tout) && (q.b0 < a.B);
+            v = (t < Tout) && (q.b0 < Bv);
         } else {
             bl = n / Tout;
             t = n - bl * Tout;
-            v = (bl < q.SPT) && (q.b0 + bl < a.B);
+            v = (bl < q.SPT) && (q.b0 + bl < Bv);
         }
         colb = q.b0 + bl;
         colt = t;
@@ -262,18 +310,46 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         for (int pl = wave & 1; pl < 2 * GR; pl += 2) {
             const int c0 = c_chunk + 8 * (pl >> 1), hh = pl & 1;
             if (c0 >= a.Cred) break;   // channel padding of the last chunk: the weight image holds zeros there, the (finite) stale tile is harmless
-            const long pbase = (a.x.ps == 1) ? (long)(c0 + hh) * a.x.sc : (long)(c0 >> 1) * a.x.sc + hh;
+            const long pbase = (a.x.ps == 1) ? (long)(c0 + hh) * xsc : (long)(c0 >> 1) * xsc + hh;
             long fix = 0;   // a unit that straddles Cred: lanes past the last channel read the last valid one (times zero weights)
             if (c0 + 8 > a.Cred) {
                 int c = c0 + 2 * ul + hh;
                 c = c < a.Cred ? c : a.Cred - 1;
-                fix = ((a.x.ps == 1) ? (long)c * a.x.sc : (long)(c >> 1) * a.x.sc + (c & 1)) - (pbase + lu);
+                fix = ((a.x.ps == 1) ? (long)c * xsc : (long)(c >> 1) * xsc + (c & 1)) - (pbase + lu);
             }
-            const float* src = a.x.ptr + pbase + fix;
+            const float* src = xptr + pbase + fix;
             float* dst = Xd + pl * ROW * 4;
 #pragma unroll
             for (int jj = 0; jj < AVC_CONV_NJ4 / 2; ++jj)
                 if (jj < njw && xo[jj] >= 0) avc_glds4(src + xo[jj], dst + 128 * jj);
+        }
+    };
+
+    // the same work as load_a + load_x, one item at a time (item i = this wave's i-th weight piece and its i-th position group
+    // in each of its planes): what the straight-line chunks interleave with their MFMAs
+    auto dma_item = [&](int chunk, int buf, int i) {
+        const int piece = wave + 4 * i;
+        if (piece < npieces) {
+            const int plane = WM == 1 ? piece : piece >> 1, sub = WM == 1 ? 0 : piece & 1;
+            avc_glds16(g.wp + (long)chunk * KS * CK * a.Mp + (long)m_tile0 * 4 + lane * 4 + (long)plane * a.Mp * 4 + sub * 256, As + buf * AS + piece * 256);
+        }
+        if (i < njw) {
+            float* Xd = Xs + buf * XS + 64 * jpar + 128 * i;
+            const int c_chunk = chunk * CK;
+            for (int pl = wave & 1; pl < 2 * GR; pl += 2) {
+                const int c0 = c_chunk + 8 * (pl >> 1), hh = pl & 1;
+                if (c0 >= a.Cred) break;
+                const long pbase = (a.x.ps == 1) ? (long)(c0 + hh) * xsc : (long)(c0 >> 1) * xsc + hh;
+                long fix = 0;
+                if (c0 + 8 > a.Cred) {
+                    int c = c0 + 2 * ul + hh;
+                    c = c < a.Cred ? c : a.Cred - 1;
+                    fix = ((a.x.ps == 1) ? (long)c * xsc : (long)(c >> 1) * xsc + (c & 1)) - (pbase + lu);
+                }
+                // (xo[] is indexed by a compile-time item number at every call site)
+                const int o = i == 0 ? xo[0] : i == 1 ? xo[1] : i == 2 ? xo[2] : i == 3 ? xo[3] : xo[4];
+                if (o >= 0) avc_glds4(xptr + pbase + fix + o, Xd + pl * ROW * 4);
+            }
         }
     };
 
@@ -287,44 +363,51 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     const int nit = (nchunk + KG - 1) / KG;
     for (int it = 0; it < nit; ++it) {
         const int chunk = it * KG + kg;
-        const bool more = (chunk + KG < nchunk);
-        if (more && !((a.dbg & 1) && it >= 1)) {
-            load_a(chunk + KG, (it + 1) & 1);  // both land while this chunk is multiplied; drained at the barrier
+        const bool more = (chunk + KG < nchunk) && !((a.dbg & 1) && it >= 1);
+        // next chunk's operands land while this chunk is multiplied and are drained at the barrier: the straight-line chunk
+        // variants issue them item by item between their MFMAs, the run-time-taps loop (and skipped chunks) up front
+        const bool inline_dma = KSC != 0 && !(a.dbg & 2) && chunk < nchunk && !(KSC < 0 && !conv_bank_case(KS, GR));
+        if (more && !inline_dma) {
+            load_a(chunk + KG, (it + 1) & 1);
             load_x(chunk + KG, (it + 1) & 1);
         }
+        auto dma = [&](int i) {
+            if (more) dma_item(chunk + KG, (it + 1) & 1, i);
+        };
+        auto nodma = [](int) {};
         const float* Ab = As + (it & 1) * AS;
         const float* Xb = Xs + (it & 1) * XS;
         if ((a.dbg & 2) || chunk >= nchunk) {
         } else if constexpr (PAR) {   // even columns: taps 0, 2, 4; odd columns: taps 1, 3 (k = 5, padL = 2)
             if (wave_n == 0) {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
             } else {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
             }
         } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
         else if (MIRROR && use_mirror)
-            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
         else if constexpr (KSC < 0) {
             // grouped launch of layers with different tap counts (the conv bank, k = 1..8): the workgroup's (taps,
             // chunk depth) pair is uniform, so each pair gets its own straight-line chunk
             switch (KS * 8 + GR) {
-                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
+                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, nodma);
             }
         } else
-            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
         if (!(a.dbg & 4)) __syncthreads();
     }
 
@@ -352,7 +435,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     if (a.dbg & 8) return;
     if (!colv) return;
 #pragma unroll
-    for (int wm = 0; wm < WM; ++wm) conv_store_frag(a, g, acc[wm], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb, colt);
+    for (int wm = 0; wm < WM; ++wm) conv_store_frag(epi, g, acc[wm], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb, colt);
 }
 
 // --------------------------------------------------------------------------
@@ -489,6 +572,15 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
     return worst;
 }
 
+// ragged forward launches (inference): the straight-line instances the model uses + the generic one
+template <int WM, bool BF>
+static void conv_launch_rag(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 1, 1, BF, false, true>), grid, block, lds, stream, a);
+    else if (fast == -1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, -1, 0, 1, BF, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 1, 4, 1, BF, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 0, 0, 1, BF, false, true>), grid, block, lds, stream, a);
+}
+
 template <int WM, int KG, bool BF>
 static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
@@ -532,10 +624,12 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         if (q.ROW > 16 * AVC_CONV_NJ4) return -3;
     }
     size_t lds = conv_lds_bytes(a, BM, BN);
-    dim3 grid(conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
+    const bool rag = a.rag.tile != nullptr;
+    if (rag && (a.mode != 0 || a.Tout < BN || a.rag.ntiles < 1)) return -2;   // (ragged launches: forward only; the caller passes Tout >= 64 for the geometry)
+    dim3 grid(rag ? a.rag.ntiles : conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
     // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
     int kgroups = 1;
-    if (tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
+    if (!rag && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
     if (lds > 160 * 1024) return -5;
     dim3 block(AVC_THREADS * kgroups);
@@ -556,7 +650,11 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         if (bf) conv_launch_variant<WM_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
         else conv_launch_variant<WM_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
     } while (0)
-    if (a.par) {
+    if (rag) {
+        const int f = (fast == 1 || fast == -1 || fast == 14) ? fast : 0;
+        if (tile == 21) { if (bf) conv_launch_rag<2, true>(a, f, grid, block, lds, stream); else conv_launch_rag<2, false>(a, f, grid, block, lds, stream); }
+        else { if (bf) conv_launch_rag<1, true>(a, f, grid, block, lds, stream); else conv_launch_rag<1, false>(a, f, grid, block, lds, stream); }
+    } else if (a.par) {
         if (kgroups == 2) { if (bf) conv_launch_par<2, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<2, false>(a, mir, fast, grid, block, lds, stream); }
         else { if (bf) conv_launch_par<1, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<1, false>(a, mir, fast, grid, block, lds, stream); }
     } else if (tile == 21) AVC_LAUNCH_CONV(2, 1);

@@ -44,8 +44,23 @@ static inline __host__ __device__ ConvGeom conv_geom(int mode, int stride, int T
     return q;
 }
 
-static inline __device__ float conv_load_res(const ConvArgs& a, const float* res, int b, int m, int t) {
-    const float* base = res + (long)b * a.rb + (long)m * a.rc;
+// what the epilogue needs of a launch: the uniform-length form copies ConvArgs; a ragged tile (one sample) substitutes the
+// sample's own lengths and buffer bases (conv_gemm.hip)
+struct ConvEpi {
+    long ob, oc, rb, rc;
+    long obase, rbase;   // added to every output / residual index (ragged: the sample's block inside the packed buffers)
+    int ot, ops, rt, Tres, Tout, M, act, res_mode, res_to_primary;
+};
+static __device__ __forceinline__ ConvEpi conv_epi(const ConvArgs& a) {
+    ConvEpi e;
+    e.ob = a.ob; e.oc = a.oc; e.rb = a.rb; e.rc = a.rc; e.obase = 0; e.rbase = 0;
+    e.ot = a.ot; e.ops = a.ops; e.rt = a.rt; e.Tres = a.Tres; e.Tout = a.Tout; e.M = a.M; e.act = a.act;
+    e.res_mode = a.res_mode; e.res_to_primary = a.res_to_primary;
+    return e;
+}
+
+static inline __device__ float conv_load_res(const ConvEpi& a, const float* res, int b, int m, int t) {
+    const float* base = res + a.rbase + (long)b * a.rb + (long)m * a.rc;
     switch (a.res_mode) {
         case AVC_RES_IDENTITY:
             return base[(long)t * a.rt];
@@ -72,7 +87,7 @@ static inline __device__ float conv_load_res(const ConvArgs& a, const float* res
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): bias, ReLU, pixel-shuffle store index, residual /
 // gradient join, secondary output and ReLU mask of the backward pass.  m_base = first output row of the
 // fragment, (b, t) = the lane's column.
-static __device__ __forceinline__ void conv_store_frag(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, int m_base, int h,
+static __device__ __forceinline__ void conv_store_frag(const ConvEpi& a, const ConvGroup& g, const f32x16& acc, int m_base, int h,
                                                        int b, int t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -83,9 +98,9 @@ static __device__ __forceinline__ void conv_store_frag(const ConvArgs& a, const 
         if (a.act == 1) v = fmaxf(v, 0.f);
         long o;
         if (a.ops == 1)
-            o = (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
+            o = a.obase + (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
         else
-            o = (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
+            o = a.obase + (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
         float rr = 0.f;
         if (a.res_mode != AVC_RES_NONE) rr = conv_load_res(a, g.res, b, m, t);
         if (a.res_to_primary) v += rr;

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(AVC_THREADS) conv_x3_kernel(const ConvArgs a) 
     }
     if (v) {
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) conv_store_frag(a, g, acc[wm], m_tile0 + 32 * wm, h, q.b0 + bl, t);
+        for (int wm = 0; wm < WM; ++wm) conv_store_frag(conv_epi(a), g, acc[wm], m_tile0 + 32 * wm, h, q.b0 + bl, t);
     }
 }
 

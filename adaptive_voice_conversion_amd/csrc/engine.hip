@@ -120,6 +120,15 @@ struct avc_plan {
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
     int flags = 0;            // AVC_PLAN_*
+    // ragged inference plans (avc_plan_create_ragged): per-level length / offset / tile tables
+    struct RagLevel {
+        std::vector<int> T, off;   // per-sample frames, prefix sums (B + 1 entries)
+        int ntiles = 0;
+        long dT = -1, doff = -1, dtile = -1;   // workspace offsets (in floats == ints) of the device copies
+    };
+    std::vector<RagLevel> rl_spk, rl_enc, rl_dec;   // speaker / content encoder levels 0..n, decoder levels 0..n (rl_dec[0] == rl_enc[n])
+    std::vector<int> rag_host;                      // host image of all tables (uploaded by avc_forward_ragged)
+    long rag_tab = -1;
     avc_tuning tun;           // launch heuristics / diagnostic switches, captured at plan creation (the dry run sizes slabs and events with them)
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
@@ -1084,6 +1093,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
 extern "C" int avc_forward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
                            const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, void* stream) {
     if (!p || !params || !x || !ws) return fail(-1, "avc_forward: null argument");
+    if (p->flags & AVC_PLAN_RAGGED) return fail(-8, "avc_forward: ragged plans run through avc_forward_ragged");
     if (!x_cond) {
         x_cond = x; scb = sxb; scc = sxc; sct = sxt;
     }
@@ -1374,4 +1384,397 @@ extern "C" int avc_backward(const avc_plan* p, const float* params, const float*
     }
     return avc_backward_impl(p, params, x, sxb, sxc, sxt, x_cond, scb, scc, sct, eps, d_dec, d_muls_up, d_emb_up, lambda_kl,
                              grads, ws, (hipStream_t)stream, false, nullptr);
+}
+
+
+// --------------------------------------------------------------------------
+// ragged inference: utterances of different lengths in ONE launch set
+// --------------------------------------------------------------------------
+static void rag_level(avc_plan* p, avc_plan::RagLevel& L, const std::vector<int>& T) {
+    const int B = (int)T.size();
+    L.T = T;
+    L.off.assign(B + 1, 0);
+    for (int b = 0; b < B; ++b) L.off[b + 1] = L.off[b] + T[b];
+    std::vector<int> tiles;
+    for (int b = 0; b < B; ++b)
+        for (int t0 = 0; t0 < T[b]; t0 += 64) {
+            tiles.push_back(b);
+            tiles.push_back(t0);
+        }
+    L.ntiles = (int)tiles.size() / 2;
+    auto put = [&](const std::vector<int>& v) {
+        long o = (long)p->rag_host.size();
+        p->rag_host.insert(p->rag_host.end(), v.begin(), v.end());
+        while (p->rag_host.size() % 4) p->rag_host.push_back(0);
+        return o;
+    };
+    L.dT = put(L.T);
+    L.doff = put(L.off);
+    L.dtile = put(tiles);
+}
+
+extern "C" int avc_plan_create_ragged(const avc_model_cfg* cfg, int B, const int* T, const int* T_cond, const avc_tuning* tuning, avc_plan** out) {
+    if (!cfg || !out || !T || B < 1) return fail(-1, "avc_plan_create_ragged: bad arguments");
+    if (tuning && tuning->struct_size != (int)sizeof(avc_tuning)) return fail(-1, "avc_plan_create_ragged: avc_tuning of another library version (use avc_tuning_init)");
+    if (!T_cond) T_cond = T;
+    if (validate_enc(cfg->spk, true) || validate_enc(cfg->enc, false)) return fail(-2, "avc_plan_create_ragged: unsupported encoder config");
+    const avc_decoder_cfg& dc = cfg->dec;
+    if (dc.n_conv_blocks < 1 || dc.n_conv_blocks > AVC_MAX_BLOCKS || 2 * dc.n_conv_blocks > 12 || dc.kernel_size < 1 || dc.kernel_size > 8)
+        return fail(-2, "avc_plan_create_ragged: unsupported decoder config");
+    for (int l = 0; l < dc.n_conv_blocks; ++l)
+        if (dc.upsample[l] != 1 && dc.upsample[l] != 2) return fail(-2, "avc_plan_create_ragged: upsample must be 1 or 2");
+    if (cfg->spk.c_in != cfg->enc.c_in || cfg->enc.c_in != dc.c_out || dc.c_in != cfg->enc.c_out || dc.c_cond != cfg->spk.c_out)
+        return fail(-2, "avc_plan_create_ragged: inconsistent channel sizes between the three networks");
+
+    avc_plan* p = new avc_plan();
+    p->cfg = *cfg;
+    p->flags = AVC_PLAN_INFERENCE | AVC_PLAN_RAGGED;
+    p->tun = tuning ? *tuning : avc_default_tuning();
+    p->tun.ck16_wgs = -1;   // default chunk depths: the ragged launcher has the straight-line instances for those
+    p->tun.ck32_wgs = -1;
+    p->tun.conv_x3 = 0;
+    p->B = B;
+    p->M = cfg->enc.c_in;
+    p->T = p->Tc = 0;
+    for (int b = 0; b < B; ++b) {
+        if (T[b] < 1 || T_cond[b] < 1) { delete p; return fail(-1, "avc_plan_create_ragged: lengths must be positive"); }
+        p->T = T[b] > p->T ? T[b] : p->T;
+        p->Tc = T_cond[b] > p->Tc ? T_cond[b] : p->Tc;
+    }
+    build_enc_params(p, p->spk, cfg->spk, true);
+    build_enc_params(p, p->enc, cfg->enc, false);
+    DecNet& d = p->dec;
+    d.c = dc;
+    d.n = dc.n_conv_blocks;
+    p->dec_param_off = p->param_floats;
+    d.in_conv = add_layer(p, dc.c_h, dc.c_in, 1, 1, true);
+    for (int l = 0; l < d.n; ++l) d.c1.push_back(add_layer(p, dc.c_h, dc.c_h, dc.kernel_size, 1, true));
+    for (int l = 0; l < d.n; ++l) d.c2.push_back(add_layer(p, dc.c_h * dc.upsample[l], dc.c_h, dc.kernel_size, 1, true));
+    {
+        int a0 = add_layer(p, 2 * dc.c_h, dc.c_cond, 1, 1, false);
+        LayerP& L = p->layers[a0];
+        L.nsrc = 2 * d.n;
+        L.rows = 2 * dc.c_h;
+        L.Cout = 2 * dc.c_h * L.nsrc;
+        for (int i = 1; i < L.nsrc; ++i) {
+            L.w[i] = add_param(p, 2 * dc.c_h, dc.c_cond, 0);
+            L.b[i] = add_param(p, 2 * dc.c_h, 0, 0);
+        }
+        d.affine = a0;
+    }
+    d.out_conv = add_layer(p, dc.c_out, dc.c_h, 1, 1, true);
+
+    // ---- per-sample time schedules; the reference's reflect-pad rule per utterance
+    auto sched = [&](EncNet& e, const int* T0, std::vector<avc_plan::RagLevel>& lv) -> int {
+        std::vector<int> cur(T0, T0 + B);
+        lv.resize(e.n + 1);
+        for (int b = 0; b < B; ++b)
+            if (e.c.bank_size / 2 >= cur[b]) return -1;
+        for (int l = 0; l <= e.n; ++l) {
+            rag_level(p, lv[l], cur);
+            if (l == e.n) break;
+            for (int b = 0; b < B; ++b) {
+                if (e.c.kernel_size / 2 >= cur[b]) return -1;
+                cur[b] = avc_cdiv(cur[b], e.c.subsample[l]);
+            }
+        }
+        return 0;
+    };
+    bool bad = sched(p->spk, T_cond, p->rl_spk) != 0 || sched(p->enc, T, p->rl_enc) != 0;
+    if (!bad) {
+        std::vector<int> cur = p->rl_enc[p->enc.n].T;
+        p->rl_dec.resize(d.n + 1);
+        for (int l = 0; l <= d.n && !bad; ++l) {
+            rag_level(p, p->rl_dec[l], cur);
+            if (l == d.n) break;
+            for (int b = 0; b < B; ++b) {
+                if (dc.kernel_size / 2 >= cur[b]) bad = true;
+                cur[b] *= dc.upsample[l];
+            }
+        }
+    }
+    if (bad) {
+        delete p;
+        return fail(-6, "Padding size should be less than the corresponding input dimension");
+    }
+    p->Tb = 0;
+    p->Tout = 0;
+
+    // ---- packed weights (forward images only); tile heuristics see the launch's column-tile count as its batch
+    for (EncNet* e : {&p->spk, &p->enc}) {
+        const std::vector<avc_plan::RagLevel>& lv = (e == &p->spk) ? p->rl_spk : p->rl_enc;
+        for (int id : e->bank) finish_layer(p, p->layers[id], false, 0, lv[0].ntiles, 64, 64, e->nb);
+        finish_layer(p, p->layers[e->in_conv], false, 0, lv[0].ntiles, 64, 64);
+        for (int l = 0; l < e->n; ++l) {
+            finish_layer(p, p->layers[e->c1[l]], false, 0, lv[l].ntiles, 64, 64);
+            finish_layer(p, p->layers[e->c2[l]], false, 0, lv[l + 1].ntiles, 64, 64);
+        }
+    }
+    for (int l = 0; l < p->spk.nd; ++l) {
+        finish_layer(p, p->layers[p->spk.dn1[l]], false, 0, 1, B, B, 1, false);
+        finish_layer(p, p->layers[p->spk.dn2[l]], false, 0, 1, B, B, 1, false);
+    }
+    finish_layer(p, p->layers[p->spk.outl], false, 0, 1, B, B, 1, false);
+    finish_layer(p, p->layers[p->enc.heads], false, 0, p->rl_dec[0].ntiles, 64, 64);
+    finish_layer(p, p->layers[d.in_conv], false, 0, p->rl_dec[0].ntiles, 64, 64);
+    for (int l = 0; l < d.n; ++l) {
+        finish_layer(p, p->layers[d.c1[l]], false, 0, p->rl_dec[l].ntiles, 64, 64);
+        finish_layer(p, p->layers[d.c2[l]], false, 0, p->rl_dec[l].ntiles, 64, 64);
+    }
+    finish_layer(p, p->layers[d.affine], false, 0, 1, B, B);
+    finish_layer(p, p->layers[d.out_conv], false, 0, p->rl_dec[d.n].ntiles, 64, 64);
+
+    // ---- packed activation buffers: [channels][T_b] blocks back to back
+    const long Bl = B;
+    auto alloc_enc = [&](EncNet& e, const std::vector<avc_plan::RagLevel>& lv, bool spk) {
+        const long C = e.c.c_h;
+        e.cat = p->alloc((long)e.CC * lv[0].off[B]);
+        e.h0 = p->alloc(C * lv[0].off[B]);
+        e.out[0] = spk ? e.h0 : p->alloc(C * lv[0].off[B]);
+        for (int l = 0; l < e.n; ++l) {
+            e.a1[l] = p->alloc(C * lv[l].off[B]);
+            e.out[l + 1] = p->alloc(C * lv[l + 1].off[B]);
+            if (spk) {
+                e.a2[l] = p->alloc(C * lv[l + 1].off[B]);
+                e.y1[l] = e.y2[l] = -1;
+            } else {
+                e.a2[l] = -1;
+                e.y1[l] = p->alloc(C * lv[l].off[B]);
+                e.y2[l] = p->alloc(C * lv[l + 1].off[B]);
+            }
+        }
+        if (spk) {
+            e.pooled = p->alloc(C * Bl);
+            e.hd[0] = e.pooled;
+            for (int l = 0; l < e.nd; ++l) {
+                e.d1[l] = p->alloc(C * Bl);
+                e.d2[l] = p->alloc(C * Bl);
+                e.hd[l + 1] = p->alloc(C * Bl);
+            }
+        }
+    };
+    alloc_enc(p->spk, p->rl_spk, true);
+    const long Cz = dc.c_in, Cd = dc.c_h;
+    p->emb = p->alloc(Bl * dc.c_cond);
+    alloc_enc(p->enc, p->rl_enc, false);
+    p->muls = p->alloc(2 * Cz * p->rl_dec[0].off[B]);
+    d.cond = p->alloc(Bl * 2 * d.n * 2 * Cd);
+    d.y0 = p->alloc(Cd * p->rl_dec[0].off[B]);
+    d.out[0] = p->alloc(Cd * p->rl_dec[0].off[B]);
+    for (int l = 0; l < d.n; ++l) {
+        d.y1[l] = p->alloc(Cd * p->rl_dec[l].off[B]);
+        d.a1[l] = p->alloc(Cd * p->rl_dec[l].off[B]);
+        d.y2[l] = p->alloc(Cd * p->rl_dec[l + 1].off[B]);
+        d.out[l + 1] = p->alloc(Cd * p->rl_dec[l + 1].off[B]);
+    }
+    p->decb = p->alloc((long)p->M * p->rl_dec[d.n].off[B]);
+    p->rag_tab = p->alloc((long)p->rag_host.size());
+    p->named["emb"] = p->emb;
+    p->named["muls"] = p->muls;
+    p->named["dec"] = p->decb;
+    p->named["cond"] = d.cond;
+    plan_init_streams(p);
+    *out = p;
+    return 0;
+}
+
+extern "C" int avc_plan_ragged_out(const avc_plan* p, int* out_len, long* out_off) {
+    if (!p || !(p->flags & AVC_PLAN_RAGGED) || !out_len || !out_off) return fail(-1, "avc_plan_ragged_out: not a ragged plan");
+    const avc_plan::RagLevel& L = p->rl_dec[p->dec.n];
+    for (int b = 0; b < p->B; ++b) {
+        out_len[b] = L.T[b];
+        out_off[b] = p->decb + (long)p->M * L.off[b];
+    }
+    return 0;
+}
+
+static void set_rag(ConvArgs& a, const int* tab, const avc_plan::RagLevel& src, int cx, const avc_plan::RagLevel& outl, const avc_plan::RagLevel& convl,
+                    int cout) {
+    // src: level of the source rows; convl: level whose lengths are the conv's output lengths (tiles run over it); outl: level
+    // of the packed OUTPUT buffer (== convl unless the store pixel-shuffles)
+    a.rag.tile = tab + convl.dtile;
+    a.rag.ntiles = convl.ntiles;
+    a.rag.Tsrc = tab + src.dT;
+    a.rag.offsrc = tab + src.doff;
+    a.rag.Tout = tab + convl.dT;
+    a.rag.offout = tab + outl.doff;
+    a.rag.cx = cx;
+    a.rag.cout = cout;
+    a.Tout = 64;    // geometry of a one-sample column tile
+    a.Tsrc = 1 << 20;   // (per sample in the tables; the reflect-pad rule was checked per utterance at plan creation)
+    a.B = 1;
+    a.x.sb = 0;
+    a.ob = 0;
+}
+static void set_rag_res(ConvArgs& a, const int* tab, const float* res, int mode, const avc_plan::RagLevel& rl, int cres) {
+    a.g[0].res = res;
+    a.res_mode = mode;
+    a.rag.Tres = tab + rl.dT;
+    a.rag.offres = tab + rl.doff;
+    a.rag.cres = cres;
+    a.rt = 1;
+}
+
+static int rag_in(const avc_plan* p, const int* tab, const float* y, float* out, const avc_plan::RagLevel& lv, int C, const float* cond, long csb,
+                  int coff, const float* res, int res_mode, const avc_plan::RagLevel* rl, hipStream_t s) {
+    RagINArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y = y; a.out = out; a.T = tab + lv.dT; a.off = tab + lv.doff;
+    a.cond = cond; a.cond_sb = csb; a.cond_off = coff;
+    a.res = res; a.res_mode = res ? res_mode : 0;
+    if (res) { a.Tres = tab + rl->dT; a.offres = tab + rl->doff; }
+    a.B = p->B; a.C = C;
+    return avc_launch_rag_in_fwd(a, s);
+}
+
+static int rag_enc_front(const avc_plan* p, const EncNet& e, const std::vector<avc_plan::RagLevel>& lv, const int* tab, const float* params, float* ws,
+                         const float* x, hipStream_t s) {
+    // conv_bank (model.py:85-91) on the packed input [sum T][M] (frames as rows): channel stride 1, frame stride M
+    const int M = e.c.c_in;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x.ptr = x; a.x.sc = 1; a.x.st = M; a.x.ps = 1;
+    a.Cred = M; a.mode = 0; a.stride = 1; a.bf16 = p->compute;
+    a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128;
+    a.ot = 1; a.ops = 1; a.act = 1;
+    a.ngroups = e.nb;
+    a.img = AVC_IMG_K4;
+    for (int g = 0; g < e.nb; ++g) {
+        const LayerP& L = p->layers[e.bank[g]];
+        set_group(a.g[g], ws + L.wpf, p->par(params, L.b[0]), L.KS, L.CK, L.nchunk_f);
+        a.g[g].out = ws + e.cat;
+        a.g[g].out_c0 = g * e.c.c_bank;
+    }
+    set_rag(a, tab, lv[0], M, lv[0], lv[0], e.CC);
+    RUN(avc_launch_conv(a, s, 0, p->tun));
+    RUN(avc_launch_rag_copy_rows(x, 1, M, tab + lv[0].dT, tab + lv[0].doff, p->B, M, lv[0].off[p->B], ws + e.cat, e.CC, e.nb * e.c.c_bank, s));
+    return 0;
+}
+
+extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const float* x, const float* x_cond, float* ws, void* stream) {
+    if (!p || !params || !x || !ws) return fail(-1, "avc_forward_ragged: null argument");
+    if (!(p->flags & AVC_PLAN_RAGGED)) return fail(-8, "avc_forward_ragged: the plan was not created by avc_plan_create_ragged");
+    if (!x_cond) x_cond = x;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = p->B;
+    // tables -> workspace (a few KB; stream-ordered in front of everything that reads them)
+    RUN((int)hipMemcpyAsync(ws + p->rag_tab, p->rag_host.data(), p->rag_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    const int* tab = (const int*)(ws + p->rag_tab);
+    {   // weights -> LDS-image order
+        std::vector<PackArgs> all;
+        for (size_t i = 0; i < p->layers.size(); ++i)
+            if (p->layers[i].wpf >= 0) pack_layer(p, p->layers[i], params, ws, all);
+        RUN(avc_launch_pack_batch(all.data(), (int)all.size(), s));
+    }
+    // A conv on packed activations: source rows of the sample's own length (x.sc = -1), output block of `cout` channels.
+    auto conv = [&](const LayerP& L, const float* src, const avc_plan::RagLevel& sl, int cx, float* dst, const avc_plan::RagLevel& convl,
+                    const avc_plan::RagLevel& outl, int cout, int act, int ops) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x.ptr = src; a.x.sc = -1; a.x.st = 1; a.x.ps = 1;
+        a.Cred = L.Cin; a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
+        a.M = L.Cout; a.Mp = L.Mp_f;
+        a.ngroups = 1;
+        set_group(a.g[0], ws + L.wpf, layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
+        a.img = AVC_IMG_K4;
+        a.ot = 1; a.ops = ops; a.act = act;
+        a.g[0].out = dst;
+        set_rag(a, tab, sl, cx, outl, convl, cout);
+        return a;
+    };
+    const hipStream_t mainS = s;
+    const hipStream_t sideS = fork_side(p, mainS);
+    {   // ---------------- speaker encoder on the target utterances (model.py:265-277)
+        const hipStream_t s = sideS;
+        const EncNet& e = p->spk;
+        const std::vector<avc_plan::RagLevel>& lv = p->rl_spk;
+        const int C = e.c.c_h;
+        RUN(rag_enc_front(p, e, lv, tab, params, ws, x_cond, s));
+        {
+            ConvArgs a = conv(p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 1, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+        }
+        for (int l = 0; l < e.n; ++l) {
+            ConvArgs a = conv(p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.a1[l], lv[l], lv[l], C, 1, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            ConvArgs b = conv(p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.a2[l], lv[l + 1], lv[l + 1], C, 1, 1);
+            b.g[0].out2 = ws + e.out[l + 1];
+            set_rag_res(b, tab, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, lv[l], C);
+            RUN(avc_launch_conv(b, s, 0, p->tun));
+        }
+        RUN(avc_launch_rag_timepool_fwd(ws + e.out[e.n], tab + lv[e.n].dT, tab + lv[e.n].doff, B, C, ws + e.pooled, s));
+        DenseArgs da;
+        memset(&da, 0, sizeof(da));
+        da.nlayers = 2 * e.nd + 1;
+        da.B = B; da.C = C;
+        da.in = ws + e.hd[0];
+        da.emb = ws + p->emb;
+        for (int l = 0; l < da.nlayers; ++l) {
+            const bool last = (l == da.nlayers - 1);
+            const LayerP& L = p->layers[last ? e.outl : ((l & 1) ? e.dn2[l / 2] : e.dn1[l / 2])];
+            DenseLayer& D = da.layer[l];
+            D.wp = ws + L.wpf;
+            D.bias = p->par(params, L.b[0]);
+            D.Cin = L.Cin; D.Cout = L.Cout; D.Kp = L.nchunk_f * L.CK; D.Mp = L.Mp_f;
+            if (!last) {
+                D.act = ws + ((l & 1) ? e.d2[l / 2] : e.d1[l / 2]);
+                D.out2 = (l & 1) ? ws + e.hd[l / 2 + 1] : nullptr;
+            }
+            da.Kmax = D.Kp > da.Kmax ? D.Kp : da.Kmax;
+            da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
+        }
+        RUN(avc_launch_dense(da, 0, s));
+    }
+    {   // ---------------- content encoder on the source utterances (model.py:301-323)
+        const EncNet& e = p->enc;
+        const std::vector<avc_plan::RagLevel>& lv = p->rl_enc;
+        const int C = e.c.c_h;
+        RUN(rag_enc_front(p, e, lv, tab, params, ws, x, s));
+        {
+            ConvArgs a = conv(p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 0, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + e.h0, ws + e.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+        }
+        for (int l = 0; l < e.n; ++l) {
+            ConvArgs a = conv(p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.y1[l], lv[l], lv[l], C, 0, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + e.y1[l], ws + e.a1[l], lv[l], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+            ConvArgs b = conv(p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.y2[l], lv[l + 1], lv[l + 1], C, 0, 1);
+            RUN(avc_launch_conv(b, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + e.y2[l], ws + e.out[l + 1], lv[l + 1], C, nullptr, 0, 0, ws + e.out[l],
+                       e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, &lv[l], s));
+        }
+        ConvArgs h = conv(p->layers[e.heads], ws + e.out[e.n], lv[e.n], C, ws + p->muls, lv[e.n], lv[e.n], 2 * e.c.c_out, 0, 1);
+        RUN(avc_launch_conv(h, s, 0, p->tun));
+    }
+    join_side(p, mainS, sideS);
+    {   // ---------------- decoder(mu, emb) (model.py:347-371, :387-391: no noise)
+        const DecNet& d = p->dec;
+        const std::vector<avc_plan::RagLevel>& lv = p->rl_dec;
+        const int C = d.c.c_h, Cz = d.c.c_in;
+        const long csb = (long)2 * d.n * 2 * C;
+        {   // all 2n AdaIN affine Linears as ONE GEMM on emb (uniform: one row per utterance)
+            ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+        }
+        {   // z = mu: the first Cz channels of every sample's (mu | log_sigma) block
+            ConvArgs a = conv(p->layers[d.in_conv], ws + p->muls, lv[0], 2 * Cz, ws + d.y0, lv[0], lv[0], C, 0, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + d.y0, ws + d.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+        }
+        for (int l = 0; l < d.n; ++l) {
+            const int up = d.c.upsample[l];
+            ConvArgs a = conv(p->layers[d.c1[l]], ws + d.out[l], lv[l], C, ws + d.y1[l], lv[l], lv[l], C, 0, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + d.y1[l], ws + d.a1[l], lv[l], C, ws + d.cond, csb, (2 * l) * 2 * C, nullptr, 0, nullptr, s));
+            // second conv: C * up channels, pixel-shuffled on store into the level-(l+1) buffer (model.py:359-361)
+            ConvArgs b = conv(p->layers[d.c2[l]], ws + d.a1[l], lv[l], C, ws + d.y2[l], lv[l], lv[l + 1], C, 0, up);
+            RUN(avc_launch_conv(b, s, 0, p->tun));
+            RUN(rag_in(p, tab, ws + d.y2[l], ws + d.out[l + 1], lv[l + 1], C, ws + d.cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l],
+                       up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, &lv[l], s));
+        }
+        ConvArgs o = conv(p->layers[d.out_conv], ws + d.out[d.n], lv[d.n], C, ws + p->decb, lv[d.n], lv[d.n], p->M, 0, 1);
+        RUN(avc_launch_conv(o, s, 0, p->tun));
+    }
+    return 0;
 }

@@ -204,3 +204,64 @@ class Plan:
             self._chk(self.lib.avc_backward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
                                             xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(d_dec), _ptr(d_muls),
                                             _ptr(d_emb), float(lambda_kl), _ptr(grads), _ptr(ws), _stream(ws)))
+
+
+class RaggedPlan:
+    """Launch plan of ONE forward-only pass over B (source, target) utterance pairs of DIFFERENT lengths
+    (avc_plan_create_ragged): the batched form of ``Inferencer.inference_one_utterance`` (inference.py:54-70).  Nothing is
+    padded; result b equals ``AE.inference(x_b, x_cond_b)`` (model.py:387-391)."""
+
+    def __init__(self, config, T, T_cond=None, lib=None, compute_dtype="fp32", device=None, tuning=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self.cfg = cfg_from_dict(config)
+        self.T = [int(t) for t in T]
+        self.T_cond = [int(t) for t in (T_cond if T_cond is not None else T)]
+        if len(self.T) != len(self.T_cond) or not self.T:
+            raise ValueError("T and T_cond must be equally long, non-empty lists")
+        self.B = len(self.T)
+        key = str(compute_dtype).lower()
+        if key not in ("fp32", "float32", "f32", "bf16", "bfloat16"):
+            raise ValueError("ragged plans compute in fp32 or bf16")
+        h = ctypes.c_void_p()
+        tun = _lib.make_tuning(self.lib, tuning)
+        arr = ctypes.c_int * self.B
+        dev = torch.device(device) if device is not None else None
+        with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
+            rc = self.lib.avc_plan_create_ragged(ctypes.byref(self.cfg), self.B, arr(*self.T), arr(*self.T_cond), ctypes.byref(tun), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
+        self.h = h
+        bf = key in ("bf16", "bfloat16")
+        self.compute_dtype = "bf16" if bf else "fp32"
+        if self.lib.avc_plan_set_compute_dtype(h, 1 if bf else 0) != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
+        self.param_floats = self.lib.avc_plan_param_floats(h)
+        self.workspace_floats = self.lib.avc_plan_workspace_floats(h)
+        self.num_params = self.lib.avc_plan_num_params(h)
+        self.param_info = []
+        for i in range(self.num_params):
+            off, n, dims = ctypes.c_long(), ctypes.c_long(), (ctypes.c_int * 3)()
+            self.lib.avc_plan_param_info(h, i, ctypes.byref(off), ctypes.byref(n), ctypes.byref(dims))
+            self.param_info.append((off.value, n.value, tuple(d for d in dims if d > 0)))
+        lens, offs = (ctypes.c_int * self.B)(), (ctypes.c_long * self.B)()
+        if self.lib.avc_plan_ragged_out(h, lens, offs) != 0:
+            raise RuntimeError(self.lib.avc_last_error().decode())
+        self.out_len, self.out_off = list(lens), list(offs)
+        self.n_mels = int(self.cfg.enc.c_in)
+
+    close = Plan.close
+    __del__ = Plan.__del__
+    _chk = Plan._chk
+
+    def forward(self, params, x, x_cond, ws):
+        """x / x_cond: the utterances back to back as rows of frames, [sum T, M] contiguous fp32 (x_cond None = x)."""
+        if x.dim() != 2 or x.shape[0] != sum(self.T) or x.shape[1] != self.n_mels or not x.is_contiguous():
+            raise ValueError(f"x must be a contiguous [{sum(self.T)}, {self.n_mels}] tensor")
+        if x_cond is not None and (x_cond.dim() != 2 or x_cond.shape[0] != sum(self.T_cond) or x_cond.shape[1] != self.n_mels or not x_cond.is_contiguous()):
+            raise ValueError(f"x_cond must be a contiguous [{sum(self.T_cond)}, {self.n_mels}] tensor")
+        with _on(ws):
+            self._chk(self.lib.avc_forward_ragged(self.h, _ptr(params), _ptr(x), _ptr(x_cond), _ptr(ws), _stream(ws)))
+
+    def outputs(self, ws):
+        """list of [M, out_len[b]] views of the converted utterances in the workspace"""
+        return [ws[o:o + self.n_mels * n].view(self.n_mels, n) for o, n in zip(self.out_off, self.out_len)]

@@ -141,6 +141,7 @@ void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"
  * (tuning->conv_x3 = 1, wgrad_x3 = 1 unless the caller's tuning already asks for more). */
 #define AVC_PLAN_X3 4
+#define AVC_PLAN_RAGGED 8   /* set by avc_plan_create_ragged (reported by avc_plan_flags) */
 int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out);
 /* profiling aid on an existing plan: 1 = every kernel of this plan on the caller's stream */
 int avc_plan_set_single_stream(avc_plan* p, int on);
@@ -158,6 +159,17 @@ int avc_plan_compute_dtype(const avc_plan* p);
  * Results are left in the workspace regions "muls", "emb", "dec". */
 int avc_forward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
                 const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, void* stream);
+
+/* ---- ragged inference: B (source, target) pairs of DIFFERENT lengths in ONE launch set (the batched generalisation of
+ * Inferencer.inference_one_utterance, inference.py:54-70; the reference converts one utterance per call).  Nothing is padded --
+ * reflect padding, ceil-mode pooling and the InstanceNorm statistics all see each utterance's true length -- so result b equals
+ * AE.inference(x_b, x_cond_b) (model.py:387-391).  T[b] / T_cond[b]: frames of source / target utterance b (host arrays).
+ * x, x_cond: the utterances back to back as rows of frames, [sum T][M] fp32 (mel bins contiguous: the [T, M] arrays the
+ * reference's utt_make_frames views).  Result: ws["dec"] holds the converted utterances back to back, utterance b as a
+ * [M][out_len[b]] block (frames contiguous) at float offset out_off[b]; out_len[b] = 8 ceil(T[b] / 8) for the stock config. */
+int avc_plan_create_ragged(const avc_model_cfg* cfg, int B, const int* T, const int* T_cond, const avc_tuning* tuning, avc_plan** out);
+int avc_plan_ragged_out(const avc_plan* p, int* out_len, long* out_off);
+int avc_forward_ragged(const avc_plan* p, const float* params, const float* x, const float* x_cond, float* ws, void* stream);
 
 /* L1 + KL losses of solver.py:84-86 -> ws["losses"] = {loss_rec, loss_kl}; writes
  * d(lambda_rec*loss_rec)/d(dec) into ws["d_dec"] for avc_backward. */

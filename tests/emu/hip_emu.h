@@ -39,6 +39,7 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
+#define hipMemcpyHostToDevice 1
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };

@@ -78,3 +78,35 @@ def test_inferencer_matches_oracle_and_buckets(kind, tmp_path):
     assert wav is None
     ref = O.ae_inference(pairs[0][0].t()[None], pairs[0][1].t()[None], sd, cfg)[0].t().numpy() * attr["std"] + attr["mean"]
     np.testing.assert_allclose(mel, ref, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("kind,cfgname,n,lo,hi", [("emu", "tiny", 7, 17, 90), pytest.param("gpu", "m80", 32, 17, 600, marks=pytest.mark.gpu)])
+def test_ragged_plan_converts_utterances_of_different_lengths_in_one_launch_set(kind, cfgname, n, lo, hi):
+    """avc_plan_create_ragged / avc_forward_ragged: n (source, target) pairs of random, unequal
+    lengths -- incl. the shortest legal one (17), lengths that are not multiples of 8 or of the 64-column tile -- in ONE launch
+    set; every result against the oracle's AE.inference of that pair alone (model.py:387-391) at the forward tolerance."""
+    from adaptive_voice_conversion_amd.engine import RaggedPlan
+    from tests.test_engine import flat_params, get_cfg
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    M = cfg["ContentEncoder"]["c_in"]
+    sd = O.make_state_dict(cfg, 21)
+    rng = np.random.RandomState(5)
+    T = [lo] + [int(v) for v in rng.randint(lo, hi + 1, size=n - 1)]
+    Tc = [int(v) for v in rng.randint(lo, hi + 1, size=n - 1)] + [lo]
+    T[1], Tc[1] = 64, 65          # exactly one tile / one frame into the second
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(t, M, generator=g) for t in T]
+    cs = [torch.randn(t, M, generator=g) for t in Tc]
+    plan = RaggedPlan(cfg, T, Tc, lib=lib)
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    plan.forward(params, torch.cat(xs).to(dev), torch.cat(cs).to(dev), ws)
+    outs = plan.outputs(ws)
+    assert len(outs) == n
+    for b in range(n):
+        ref = O.ae_inference(xs[b].t()[None], cs[b].t()[None], sd, cfg)[0]
+        assert tuple(outs[b].shape) == tuple(ref.shape), (b, T[b], outs[b].shape, ref.shape)   # T' = 8 ceil(T / 8) for the stock config
+        torch.testing.assert_close(outs[b].cpu(), ref, rtol=1e-4, atol=2e-5, msg=lambda m: f"pair {b} (T={T[b]}, T_cond={Tc[b]}): {m}")
+    with pytest.raises(RuntimeError, match="Padding size should be less"):
+        RaggedPlan(cfg, [40, 2], [40, 40], lib=lib)
