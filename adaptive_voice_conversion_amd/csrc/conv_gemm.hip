@@ -41,9 +41,44 @@
 // A tap is a 16-byte shift of the X address, so all KS taps are served from the one tile.
 // MIR: 0 = no mirror window, 1 = ONE mirror window per column (a column of a sample of >= 2 (padL + padR) + 2 frames is within
 // pad of at most one edge), 2 = both windows (very short samples)
-// upper bound of the LDS-DMA items of one chunk that one wave issues: ceil(KS GR WM / 2) weight pieces, NJ4 / 2 position groups
-static constexpr __host__ __device__ int conv_dma_items(int WM, int KSC, int GRC) {
-    return (KSC * GRC * WM + 1) / 2 > AVC_CONV_NJ4 / 2 ? (KSC * GRC * WM + 1) / 2 : AVC_CONV_NJ4 / 2;
+// LDS stages per operand: 2 = the next chunk is issued while this one multiplies (the product build); 3 = prefetch distance two with a
+// partial s_waitcnt vmcnt(n) + bare s_barrier -- built, correct, and measured SLOWER on MI355X (k = 5, T = 128 forward layer 71.9 vs 67.5 us,
+// train step 6.93 vs 6.51 ms, profiles/r03_conv_ablate.log): the cost of the LDS-DMA stream is not exposed latency.
+#ifndef AVC_CONV_STAGES
+#define AVC_CONV_STAGES 2
+#endif
+
+// s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (here: LDS-DMA loads, which complete in issue order)
+// still outstanding; lgkmcnt / expcnt untouched.  gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0].
+static __device__ __forceinline__ void conv_wait_dma(int n) {
+#define AVC_WAIT_VM(k) __builtin_amdgcn_s_waitcnt(((k) & 15) | (((k) >> 4) << 14) | (7 << 4) | (15 << 8))
+    switch (n) {
+        case 0: AVC_WAIT_VM(0); break;
+        case 1: AVC_WAIT_VM(1); break;
+        case 2: AVC_WAIT_VM(2); break;
+        case 3: AVC_WAIT_VM(3); break;
+        case 4: AVC_WAIT_VM(4); break;
+        case 5: AVC_WAIT_VM(5); break;
+        case 6: AVC_WAIT_VM(6); break;
+        case 7: AVC_WAIT_VM(7); break;
+        case 8: AVC_WAIT_VM(8); break;
+        case 9: AVC_WAIT_VM(9); break;
+        case 10: AVC_WAIT_VM(10); break;
+        case 11: AVC_WAIT_VM(11); break;
+        case 12: AVC_WAIT_VM(12); break;
+        default: AVC_WAIT_VM(12); break;   // (more were issued: waiting for all but 12 is stricter than needed, still correct)
+    }
+#undef AVC_WAIT_VM
+}
+// workgroup barrier WITHOUT draining the vector-memory counter: __syncthreads() (and the compiler's own handling of s_barrier on
+// gfx9) waits for vmcnt(0), i.e. for the chunk that was issued a moment ago.  LDS is written only by the DMAs (vmcnt) and read
+// by ds_read (consumed by the MFMAs before this point), so conv_wait_dma + a bare s_barrier is the complete synchronisation.
+static __device__ __forceinline__ void conv_bare_barrier() {
+#ifdef AVC_EMU
+    emu::block_barrier();
+#else
+    asm volatile("s_barrier" ::: "memory");
+#endif
 }
 
 template <int WM, int MIR>
@@ -74,21 +109,13 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM], const f3
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
 // TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
 // taps of a column meet the zeros of the zero-upsampled dy)
-// dma(i): issues the i-th LDS-DMA item of the NEXT chunk (conv_gemm_kernel).  The straight-line chunks call it between the
-// units' MFMAs: a wave's matrix instructions are one dependent chain (one accumulator), so the wave has ~64 idle issue cycles
-// behind every MFMA -- and since all workgroups of a launch run in lock step, DMA instructions issued together at the top of
-// a chunk are a phase in which NO wave of the SIMD feeds the matrix pipe (measured, scripts/conv_ablate.py: the k = 5, T = 128
-// forward layer takes 70.7 us, 55.4 without the DMA and 22.3 without the MFMAs: the two did not overlap at all).
-template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0, class DMA>
+template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
-                                                      int a_lane4, int cb4, int cbl4, int cbr4, DMA&& dma) {
+                                                      int a_lane4, int cb4, int cbl4, int cbr4) {
     constexpr int BM4 = 64 * WM * 4;   // floats of one (tap, unit, h) plane of the A stage
     if constexpr (KSC > 0) {
         constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
         constexpr int U = NTAP * GRC;
-        constexpr int NI = conv_dma_items(WM, KSC, GRC);   // items a wave may own; those beyond the unit count go first
-#pragma unroll
-        for (int i = U; i < NI; ++i) dma(i);
         f32x4 av[2][WM], bv[2];
         auto unit_ptrs = [&](int u, const float*& Ap, const float*& Xp) {
             const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g8 = u % GRC;
@@ -104,7 +131,6 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
                 unit_ptrs(u + 1, Ap, Xp);
                 conv_load_unit<WM, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
             }
-            dma(u);
             conv_mma_unit<WM, BF>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
@@ -121,11 +147,6 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
             }
         }
     }
-}
-
-// (taps, chunk depth) pairs the grouped bank launch has straight-line chunks for
-static __device__ __forceinline__ bool conv_bank_case(int KS, int GR) {
-    return (KS == 1 && GR == 4) || ((KS == 2 || KS == 3) && GR == 2) || (KS >= 4 && KS <= 8 && GR == 1);
 }
 
 // KG > 1: intra-workgroup split-K for layers that cannot fill the chip (T_l <= 32: 128-256 tiles, each
@@ -184,8 +205,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     const int AS = KS * CK * BM;  // floats per A stage
     const int XS = CK * ROW;      // floats per X stage
-    float* As = smem + kg * 2 * AS;                 // this group's two A stages
-    float* Xs = smem + KG * 2 * AS + kg * 2 * XS;   // ... and X stages
+    constexpr int NS = AVC_CONV_STAGES;              // chunk c + 2 is in flight while chunk c multiplies (see the main loop)
+    float* As = smem + kg * NS * AS;                 // this group's A stages
+    float* Xs = smem + KG * NS * AS + kg * NS * XS;  // ... and X stages
 
     // ---- per-lane source descriptors of the X tile.  One dword LDS-DMA instruction fills 64 consecutive floats of an
     // (unit, h) plane = 16 positions x 4 k-steps: lane l fetches position 16 j + (l >> 2) of reduction channel
@@ -222,8 +244,8 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         }
         xo[jj] = sp;
     }
-    // both X stages start as zeros; structural zeros are never overwritten afterwards
-    for (int e = tid; e < KG * 2 * XS; e += NTHREADS) smem[KG * 2 * AS + e] = 0.f;
+    // the X stages start as zeros; structural zeros are never overwritten afterwards
+    for (int e = tid; e < KG * NS * XS; e += NTHREADS) smem[KG * NS * AS + e] = 0.f;
 
     // ---- this lane's column (float index of its position inside an X plane = 4 x position)
     int cb4, cbl4, cbr4, colb, colt;
@@ -325,90 +347,82 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         }
     };
 
-    // the same work as load_a + load_x, one item at a time (item i = this wave's i-th weight piece and its i-th position group
-    // in each of its planes): what the straight-line chunks interleave with their MFMAs
-    auto dma_item = [&](int chunk, int buf, int i) {
-        const int piece = wave + 4 * i;
-        if (piece < npieces) {
-            const int plane = WM == 1 ? piece : piece >> 1, sub = WM == 1 ? 0 : piece & 1;
-            avc_glds16(g.wp + (long)chunk * KS * CK * a.Mp + (long)m_tile0 * 4 + lane * 4 + (long)plane * a.Mp * 4 + sub * 256, As + buf * AS + piece * 256);
-        }
-        if (i < njw) {
-            float* Xd = Xs + buf * XS + 64 * jpar + 128 * i;
-            const int c_chunk = chunk * CK;
-            for (int pl = wave & 1; pl < 2 * GR; pl += 2) {
-                const int c0 = c_chunk + 8 * (pl >> 1), hh = pl & 1;
-                if (c0 >= a.Cred) break;
-                const long pbase = (a.x.ps == 1) ? (long)(c0 + hh) * xsc : (long)(c0 >> 1) * xsc + hh;
-                long fix = 0;
-                if (c0 + 8 > a.Cred) {
-                    int c = c0 + 2 * ul + hh;
-                    c = c < a.Cred ? c : a.Cred - 1;
-                    fix = ((a.x.ps == 1) ? (long)c * xsc : (long)(c >> 1) * xsc + (c & 1)) - (pbase + lu);
-                }
-                // (xo[] is indexed by a compile-time item number at every call site)
-                const int o = i == 0 ? xo[0] : i == 1 ? xo[1] : i == 2 ? xo[2] : i == 3 ? xo[3] : xo[4];
-                if (o >= 0) avc_glds4(xptr + pbase + fix + o, Xd + pl * ROW * 4);
-            }
-        }
+    // LDS-DMA instructions one chunk costs THIS wave (a lower bound is what the partial wait below needs): its weight
+    // pieces + its position groups that have at least one active lane, per plane of the chunk that holds real channels
+    const int na_w = (npieces - wave + 3) >> 2;
+    int nx_w = 0;
+#pragma unroll
+    for (int jj = 0; jj < AVC_CONV_NJ4 / 2; ++jj) nx_w += (jj < njw && __any(xo[jj] >= 0)) ? 1 : 0;
+    auto dma_count = [&](int chunk) {
+        int planes = 0;
+        for (int pl = wave & 1; pl < 2 * GR; pl += 2) planes += (chunk * CK + 8 * (pl >> 1) < a.Cred) ? 1 : 0;
+        return na_w + nx_w * planes;
     };
 
+    constexpr int DIST = NS - 1;   // prefetch distance in chunks
     if (kg < nchunk) {
         load_a(kg, 0);
         load_x(kg, 0);
+    }
+    if (DIST == 2 && kg + KG < nchunk && !(a.dbg & 1)) {
+        load_a(kg + KG, 1);
+        load_x(kg + KG, 1);
     }
     __syncthreads();
 
     const int a_lane4 = (wave_m * (32 * WM) + li) * 4;
     const int nit = (nchunk + KG - 1) / KG;
+    int st = 0;   // stage of the chunk being multiplied (it % NS)
     for (int it = 0; it < nit; ++it) {
         const int chunk = it * KG + kg;
-        const bool more = (chunk + KG < nchunk) && !((a.dbg & 1) && it >= 1);
-        // next chunk's operands land while this chunk is multiplied and are drained at the barrier: the straight-line chunk
-        // variants issue them item by item between their MFMAs, the run-time-taps loop (and skipped chunks) up front
-        const bool inline_dma = KSC != 0 && !(a.dbg & 2) && chunk < nchunk && !(KSC < 0 && !conv_bank_case(KS, GR));
-        if (more && !inline_dma) {
-            load_a(chunk + KG, (it + 1) & 1);
-            load_x(chunk + KG, (it + 1) & 1);
+        // chunk c + DIST is issued now and lands while chunks c .. c + DIST - 1 are multiplied; chunk c + 1 must have landed by the
+        // barrier at the end of this iteration (DIST == 1: that is everything outstanding)
+        const bool more = (chunk + DIST * KG < nchunk) && !((a.dbg & 1) && (DIST == 2 || it >= 1));
+        int issued = 0;
+        if (more) {
+            const int stn = (st + DIST) % NS;   // last read during chunk c - 1, free since that chunk's barrier
+            load_a(chunk + DIST * KG, stn);
+            load_x(chunk + DIST * KG, stn);
+            if (DIST == 2) issued = dma_count(chunk + DIST * KG);
         }
-        auto dma = [&](int i) {
-            if (more) dma_item(chunk + KG, (it + 1) & 1, i);
-        };
-        auto nodma = [](int) {};
-        const float* Ab = As + (it & 1) * AS;
-        const float* Xb = Xs + (it & 1) * XS;
+        const float* Ab = As + st * AS;
+        const float* Xb = Xs + st * XS;
         if ((a.dbg & 2) || chunk >= nchunk) {
         } else if constexpr (PAR) {   // even columns: taps 0, 2, 4; odd columns: taps 1, 3 (k = 5, padL = 2)
             if (wave_n == 0) {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             } else {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if (MIRROR && use_mirror)
-            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
+            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if constexpr (KSC < 0) {
             // grouped launch of layers with different tap counts (the conv bank, k = 1..8): the workgroup's (taps,
             // chunk depth) pair is uniform, so each pair gets its own straight-line chunk
             switch (KS * 8 + GR) {
-                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma); break;
-                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, nodma);
+                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else
-            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4, dma);
-        if (!(a.dbg & 4)) __syncthreads();
+            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+        if (!(a.dbg & 4)) {
+            conv_wait_dma(issued);   // everything but the DMA instructions issued in THIS iteration has landed
+            conv_bare_barrier();
+        }
+        st = st == NS - 1 ? 0 : st + 1;
     }
 
     if (KG > 1) {  // fixed-order sum of the groups' partial tiles through the (now free) stage memory
@@ -529,6 +543,11 @@ int avc_conv_pick_tile(const avc_tuning& tun, int Mp, int B, int Tout, int ngrou
     // workgroups (their cost is the epilogue: more, smaller workgroups overlap it better); the k = 5, 128-channel convs
     // switch to 128x64 beyond ~4k (B = 1024 inference: 7.54 vs 7.66 ms)
     const long thr11 = (ngroups > 1 || (Kred > 0 && Kred <= 256)) ? tun.tile_thr11 : (tun.tile_thr11 < 4095 ? tun.tile_thr11 : 4095);
+    // r3 (profiles/r03_conv_micro.log): a deep 1x1 reduction (the 1104 -> 128 in_conv: 35 chunks of 32 channels) moves 8 KiB of
+    // weights per chunk per 64 rows; with 128-row tiles the source tile is fetched once for twice the rows: 111.7 vs 131.5 us
+    // forward, 138.5 vs 153.3 us input gradient at B = 256
+    if (ngroups == 1 && Kred >= 1024 && Mp >= 128 && t11 >= 512) return 21;
+    if (ngroups == 1 && Mp >= 1024 && t11 >= 4096) return 21;   // ... and its input gradient (1024 rows): 138.5 vs 153.3 us
     return t11 <= thr11 ? 11 : 21;
 }
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups) {
@@ -546,7 +565,7 @@ int avc_conv_ck_for(const avc_tuning& tun, int KS, long wgs, int mode, int strid
         // at most one workgroup per CU: the forward kernel gains another ~6 % from four chunks of 32
         // (r1 sweep: T_l = 16/32 forward 26.0 -> 24.5 us; the dgrad variant does not move)
         int BM = (tile / 10 == 1) ? 64 : 128;
-        if (KS == 5 && mode == 0 && wgs <= tun.ck32_wgs && tile != 11 && q.ROW <= 16 * AVC_CONV_NJ4 && 2 * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
+        if (KS == 5 && mode == 0 && wgs <= tun.ck32_wgs && tile != 11 && q.ROW <= 16 * AVC_CONV_NJ4 && AVC_CONV_STAGES * (size_t)(KS * 32 * BM + 32 * q.ROW) * 4 <= 144 * 1024) ck = 32;
     }
     return ck;
 }
@@ -556,7 +575,7 @@ static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         size_t AS = (size_t)a.g[gi].KS * a.g[gi].CK * BM, XS = (size_t)a.g[gi].CK * q.ROW;
-        size_t bytes = (2 * AS + 2 * XS) * 4;
+        size_t bytes = (size_t)AVC_CONV_STAGES * (AS + XS) * 4;
         worst = bytes > worst ? bytes : worst;
     }
     return worst + 16;

