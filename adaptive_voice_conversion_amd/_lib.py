@@ -17,12 +17,12 @@ GRADS_ALL, GRADS_DECODER, GRADS_ENCODERS = 0, 1, 2
 
 class EncoderCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("c_in", "c_h", "c_out", "kernel_size", "bank_size", "bank_scale", "c_bank",
-                                            "n_conv_blocks", "n_dense_blocks")] + [("subsample", ctypes.c_int * MAX_BLOCKS)]
+                                            "n_conv_blocks", "n_dense_blocks")] + [("subsample", ctypes.c_int * MAX_BLOCKS), ("act", ctypes.c_int)]
 
 
 class DecoderCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("c_in", "c_cond", "c_h", "c_out", "kernel_size", "n_conv_blocks")] + \
-               [("upsample", ctypes.c_int * MAX_BLOCKS)]
+               [("upsample", ctypes.c_int * MAX_BLOCKS), ("act", ctypes.c_int)]
 
 
 class ModelCfg(ctypes.Structure):

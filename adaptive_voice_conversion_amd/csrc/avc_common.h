@@ -83,7 +83,8 @@ struct ConvArgs {
     int M, Mp, Tout;
     long ob, oc;
     int ot, ops;  // output strides (+ pixel-shuffle store factor), shared by out/out2/mask
-    int act;      // 0 none, 1 relu
+    int act;      // 0 none, 1 relu / leaky relu (slope)
+    float slope;  // 0: ReLU; AVC_LRELU_SLOPE: LeakyReLU -- also the slope the `mask` of a dgrad launch applies to masked-out elements
     int res_mode, res_to_primary;
     long rb, rc;
     int rt, Tres;
@@ -144,6 +145,7 @@ struct DenseArgs {
     const float* in2;   // backward: optional upstream d(emb) [B][c_out] row-major, added to `in`
     float* emb;         // forward output [B][c_out]
     float* dpooled;     // backward output [C][B]
+    float slope;        // activation slope (0 = ReLU)
 };
 
 struct INFwdArgs {
@@ -157,6 +159,7 @@ struct INFwdArgs {
     const float* res;   // residual rows [R][Tres] (contiguous) or null
     int res_mode, Tres;
     int R, C, T, relu;
+    float slope;
 };
 
 // ragged InstanceNorm forward (ragged_rows.hip): packed [C][T_b] blocks, see ConvRag
@@ -173,6 +176,7 @@ struct RagINArgs {
     const int* offres;
     int res_mode;
     int B, C;
+    float slope;
 };
 
 struct INBwdArgs {
@@ -188,6 +192,7 @@ struct INBwdArgs {
     long dcond_sb;
     int dcond_off;
     int R, C, T, relu;
+    float slope;
 };
 
 struct AdamArgs {
@@ -236,6 +241,12 @@ static __device__ __forceinline__ void avc_glds16_s(const float* sbase, unsigned
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// nn.ReLU / nn.LeakyReLU(0.01) (model.py:93-99 get_act): slope = 0 -> ReLU (bit-identical to fmaxf), 0.01 -> 'lrelu'.
+// The backward masks are (stored activation > 0) either way: a positive slope keeps the sign of the pre-activation.
+#define AVC_LRELU_SLOPE 0.01f
+static __device__ __forceinline__ float avc_act(float v, float slope) { return slope == 0.f ? fmaxf(v, 0.f) : (v > 0.f ? v : v * slope); }
+static __device__ __forceinline__ float avc_act_grad(float g, bool positive, float slope) { return positive ? g : (slope == 0.f ? 0.f : g * slope); }
 
 #define AVC_IN_EPS 1e-5f
 // x_hat and the ReLU pre-activation of the InstanceNorm family are computed by the SAME explicitly

@@ -63,7 +63,7 @@ int avc_launch_rag_timepool_fwd(const float* in, const int* T, const int* off, i
 int avc_launch_copy_rows(const float* x, long sxb, long sxc, int sxt, int B, int M, int T, float* dst, long db, long dc,
                          hipStream_t s);
 int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hipStream_t s);
-int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, hipStream_t s);
+int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, float slope, hipStream_t s);
 int avc_launch_reparam_fwd(const float* muls, const float* eps, int B, int C, int Tb, float* z, hipStream_t s);
 int avc_launch_latent_bwd(const float* muls, const float* eps, const float* dz, const float* dmuls_up, int B, int C,
                           int Tb, float lambda_kl_over_n, float* dmuls, hipStream_t s);

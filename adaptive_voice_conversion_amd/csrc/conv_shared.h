@@ -50,12 +50,14 @@ struct ConvEpi {
     long ob, oc, rb, rc;
     long obase, rbase;   // added to every output / residual index (ragged: the sample's block inside the packed buffers)
     int ot, ops, rt, Tres, Tout, M, act, res_mode, res_to_primary;
+    float slope;
 };
 static __device__ __forceinline__ ConvEpi conv_epi(const ConvArgs& a) {
     ConvEpi e;
     e.ob = a.ob; e.oc = a.oc; e.rb = a.rb; e.rc = a.rc; e.obase = 0; e.rbase = 0;
     e.ot = a.ot; e.ops = a.ops; e.rt = a.rt; e.Tres = a.Tres; e.Tout = a.Tout; e.M = a.M; e.act = a.act;
     e.res_mode = a.res_mode; e.res_to_primary = a.res_to_primary;
+    e.slope = a.slope;
     return e;
 }
 
@@ -95,7 +97,7 @@ static __device__ __forceinline__ void conv_store_frag(const ConvEpi& a, const C
         if (m >= a.M) continue;
         float v = acc[r];
         if (g.bias) v += g.bias[m];
-        if (a.act == 1) v = fmaxf(v, 0.f);
+        if (a.act == 1) v = avc_act(v, a.slope);
         long o;
         if (a.ops == 1)
             o = a.obase + (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
@@ -107,7 +109,7 @@ static __device__ __forceinline__ void conv_store_frag(const ConvEpi& a, const C
         if (g.out) g.out[o] = v;
         if (g.out2) {
             float v2 = a.res_to_primary ? v : v + rr;
-            if (g.mask) v2 = (g.mask[o] > 0.f) ? v2 : 0.f;
+            if (g.mask) v2 = avc_act_grad(v2, g.mask[o] > 0.f, a.slope);
             g.out2[o] = v2;
         }
     }

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(AVC_THREADS) dense_stack_fwd_kernel(const Dens
                 if (last) {
                     if (b < a.B) a.emb[(long)b * L.Cout + m] = v;  // emb [B][c_out] row-major
                 } else {
-                    v = fmaxf(v, 0.f);
+                    v = avc_act(v, a.slope);
                     if (b < a.B) L.act[(long)m * a.B + b] = v;      // d1 / d2 (ReLU outputs, masks of the backward)
                     if (second) {
                         v += Hres[m * DS_NS + n];
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(AVC_THREADS) dense_stack_bwd_kernel(const Dens
                         // gradient entering the second Linear of the previous block: dH * [d2 > 0]
                         const DenseLayer Lp = a.layer[l - 1];
                         float mk = ok ? Lp.act[(long)m * a.B + b] : 0.f;
-                        float dz = mk > 0.f ? v : 0.f;
+                        float dz = ok ? avc_act_grad(v, mk > 0.f, a.slope) : 0.f;
                         if (ok) Lp.dz[(long)m * a.B + b] = dz;
                         Xout[m * DS_NS + n] = dz;
                     }
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(AVC_THREADS) dense_stack_bwd_kernel(const Dens
                     // SECOND Linear: v = W2^T dz2 -> dz1 = v * [d1 > 0]
                     const DenseLayer Lp = a.layer[l - 1];
                     float mk = ok ? Lp.act[(long)m * a.B + b] : 0.f;
-                    float dz = mk > 0.f ? v : 0.f;
+                    float dz = ok ? avc_act_grad(v, mk > 0.f, a.slope) : 0.f;
                     if (ok) Lp.dz[(long)m * a.B + b] = dz;
                     Xout[m * DS_NS + n] = dz;
                 }

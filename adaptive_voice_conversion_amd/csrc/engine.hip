@@ -63,6 +63,7 @@ struct LayerP {
 
 struct EncNet {
     avc_encoder_cfg c;
+    float slope = 0.f;   // activation slope of this network (0 = ReLU, AVC_LRELU_SLOPE = 'lrelu')
     int nb = 0, CC = 0, n = 0, nd = 0;
     int T[AVC_MAX_BLOCKS + 1];
     std::vector<int> bank, c1, c2, dn1, dn2;
@@ -77,6 +78,7 @@ struct EncNet {
 
 struct DecNet {
     avc_decoder_cfg c;
+    float slope = 0.f;
     int n = 0;
     int T[AVC_MAX_BLOCKS + 1];
     std::vector<int> c1, c2;
@@ -199,6 +201,7 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
 static int validate_enc(const avc_encoder_cfg& c, bool spk) {
     if (c.c_in < 1 || c.c_h < 1 || c.c_out < 1 || c.c_bank < 1) return -1;
     if (c.kernel_size < 1 || c.kernel_size > 8) return -1;
+    if (c.act != 0 && c.act != 1) return -1;
     if (c.bank_scale < 1 || c.bank_size < c.bank_scale || c.bank_size > 8) return -1;
     if (c.bank_size / c.bank_scale > AVC_MAX_GROUPS) return -1;
     if (c.n_conv_blocks < 1 || c.n_conv_blocks > AVC_MAX_BLOCKS) return -1;
@@ -210,6 +213,7 @@ static int validate_enc(const avc_encoder_cfg& c, bool spk) {
 
 static void build_enc_params(avc_plan* p, EncNet& e, const avc_encoder_cfg& c, bool spk) {
     e.c = c;
+    e.slope = c.act == 1 ? AVC_LRELU_SLOPE : 0.f;
     e.n = c.n_conv_blocks;
     e.nd = spk ? c.n_dense_blocks : 0;
     for (int k = c.bank_scale; k <= c.bank_size; k += c.bank_scale) e.bank.push_back(add_layer(p, c.c_bank, c.c_in, k, 1, true));
@@ -284,6 +288,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     build_enc_params(p, p->enc, cfg->enc, false);
     DecNet& d = p->dec;
     d.c = dc;
+    d.slope = dc.act == 1 ? AVC_LRELU_SLOPE : 0.f;
     d.n = dc.n_conv_blocks;
     p->dec_param_off = p->param_floats;
     d.in_conv = add_layer(p, dc.c_h, dc.c_in, 1, 1, true);
@@ -666,7 +671,7 @@ static const float* layer_bias(const avc_plan* p, const LayerP& L, const float* 
 }
 
 // forward conv of layer L on a source view; caller fills epilogue extras afterwards
-static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, const float* ws, const float* x, long sb,
+static ConvArgs mk_fwd(const avc_plan* p, float slope, const LayerP& L, const float* params, const float* ws, const float* x, long sb,
                        long sc, int st, int Bn, int Tsrc, float* out, long ob, long oc, int ot, int act) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -680,11 +685,12 @@ static ConvArgs mk_fwd(const avc_plan* p, const LayerP& L, const float* params, 
     a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.act = act;
+    a.slope = slope;
     a.g[0].out = out;
     return a;
 }
 
-static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long sb, long sc, int st, int ps, int Bn,
+static ConvArgs mk_dgrad(float slope, const LayerP& L, const float* ws, const float* dy, long sb, long sc, int st, int ps, int Bn,
                          int Tdy, int Tin, float* dx, long ob, long oc, int ot) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -694,6 +700,7 @@ static ConvArgs mk_dgrad(const LayerP& L, const float* ws, const float* dy, long
     a.M = L.dgM; a.Mp = L.Mp_d; a.Tout = Tin;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.res_to_primary = 1;
+    a.slope = slope;   // (applied where the launch masks by a ReLU output)
     a.ngroups = 1;
     set_group(a.g[0], ws + (L.x3_d ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
     a.img = L.x3_d ? AVC_IMG_X3 : AVC_IMG_K4;
@@ -878,7 +885,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     }
 }
 
-static int in_fwd(const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
+static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
                   int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0) {
     // stats = [mean[Bfull*C] | rstd[Bfull*C]]; a sub-batch launch (b0, Bn) of a Bfull-sample tensor passes
     // y/out/res/cond already offset to sample b0
@@ -887,17 +894,17 @@ static int in_fwd(const float* y, int Bn, int C, int T, const float* cond, long 
     a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope;
     return avc_launch_in_fwd(a, s);
 }
 
-static int in_bwd(const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
+static int in_bwd(float slope, const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
                   long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s) {
     INBwdArgs a;
     a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope;
     return avc_launch_in_bwd(a, s);
 }
 
@@ -908,6 +915,7 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
                      long sxc, int sxt, hipStream_t s) {
     // conv_bank (model.py:85-91): all bank members in ONE grouped launch writing the concat buffer in place
     const int B = p->B, T0 = e.T[0];
+    const float SL = e.slope;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
@@ -916,6 +924,7 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
     a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128; a.Tout = T0;
     a.ob = (long)e.CC * T0; a.oc = T0; a.ot = 1; a.ops = 1;
     a.act = 1;
+    a.slope = SL;
     a.ngroups = e.nb;
     a.img = AVC_IMG_K4;
     for (int g = 0; g < e.nb; ++g) {
@@ -963,19 +972,20 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     {
         const hipStream_t s = sideS;
         const EncNet& e = p->spk;
+        const float SL = e.slope;
         const int C = e.c.c_h;
         RUN(enc_front(p, e, params, ws, xc, scb, scc, sct, s));
         {
             const LayerP& L = p->layers[e.in_conv];
-            ConvArgs a = mk_fwd(p, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
+            ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
-            ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
+            ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a2[l], (long)C * To, To, 1, 1);
+            ConvArgs b = mk_fwd(p, SL, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a2[l], (long)C * To, To, 1, 1);
             b.g[0].out2 = ws + e.out[l + 1];
             set_res(b, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, (long)C * Ti, Ti, 1, Ti);
             RUN(avc_launch_conv(b, s, 0, p->tun));
@@ -987,7 +997,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             DenseArgs da;
             memset(&da, 0, sizeof(da));
             da.nlayers = 2 * e.nd + 1;
-            da.B = B; da.C = C;
+            da.B = B; da.C = C; da.slope = SL;
             da.in = ws + e.hd[0];
             da.emb = ws + p->emb;
             for (int l = 0; l < da.nlayers; ++l) {
@@ -1012,26 +1022,27 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     const bool spk_only = (p->flags & AVC_PLAN_SPEAKER_ONLY) != 0;  // AE.get_speaker_embeddings (model.py:393-395)
     if (!spk_only) {
         const EncNet& e = p->enc;
+        const float SL = e.slope;
         const int C = e.c.c_h;
         RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
         {
-            ConvArgs a = mk_fwd(p, p->layers[e.in_conv], params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
+            ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
+            RUN(in_fwd(SL, ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
-            ConvArgs a = mk_fwd(p, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
+            ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
-            ConvArgs b = mk_fwd(p, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
+            RUN(in_fwd(SL, ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
+            ConvArgs b = mk_fwd(p, SL, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
             const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
             RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(in_fwd(ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
+            RUN(in_fwd(SL, ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
         }
         const int Tb = p->Tb;
-        ConvArgs h = mk_fwd(p, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
+        ConvArgs h = mk_fwd(p, SL, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
         RUN(avc_launch_conv(h, s, 0, p->tun));
     }
 
@@ -1039,11 +1050,12 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     // ---------------- reparameterisation (model.py:383-384) + decoder (model.py:347-371)
     if (!spk_only) {
         const DecNet& d = p->dec;
+        const float SL = d.slope;
         const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb;
         RUN(avc_launch_reparam_fwd(ws + p->muls, eps, B, Cz, Tb, ws + d.z, s));
         const long csb = (long)2 * d.n * 2 * C;
         {   // all 2n AdaIN affine Linears as ONE GEMM on emb (they share their input)
-            ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
+            ConvArgs a = mk_fwd(p, SL, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         // The decoder is one serial chain of ~40 small kernels (T_l = 16..128): alone on the GPU it leaves
@@ -1054,25 +1066,25 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             const long oz = (long)b0 * Cz * Tb, ob0 = (long)b0 * C * Tb;
             const float* cond = ws + d.cond + (long)b0 * csb;
             {
-                ConvArgs a = mk_fwd(p, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
+                ConvArgs a = mk_fwd(p, SL, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
+                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
             }
             for (int l = 0; l < d.n; ++l) {
                 const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
                 const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
-                ConvArgs a = mk_fwd(p, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
+                ConvArgs a = mk_fwd(p, SL, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
+                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
                 // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
-                ConvArgs b = mk_fwd(p, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
+                ConvArgs b = mk_fwd(p, SL, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
                 b.ops = up;
                 RUN(avc_launch_conv(b, s, 0, p->tun));
-                RUN(in_fwd(ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
                                     ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
             }
             const int To = p->Tout;
-            ConvArgs o = mk_fwd(p, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
+            ConvArgs o = mk_fwd(p, SL, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
                                 ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
             RUN(avc_launch_conv(o, s, 0, p->tun));
             return 0;
@@ -1116,12 +1128,13 @@ static int enc_back_front(BwdCtx& c, const EncNet& e, const float* x, long sxb, 
     // dy_in: gradient wrt the in_conv output [B, C, T0]
     const avc_plan* p = c.p;
     const int B = p->B, C = e.c.c_h, T0 = e.T[0];
+    const float SL = e.slope;
     float* ws = c.ws;
     const LayerP& L = p->layers[e.in_conv];
     RUN(wgrad_layer(c, L, ws + e.cat, (long)e.CC * T0, T0, 1, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0));
     if (!c.dry) {
         // d(cat) for the bank channels only, masked by the bank ReLU (cat > 0)
-        ConvArgs a = mk_dgrad(L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, (long)e.CC * T0, T0, 1);
+        ConvArgs a = mk_dgrad(SL, L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, (long)e.CC * T0, T0, 1);
         a.g[0].out2 = ws + e.dcat;
         a.g[0].mask = ws + e.cat;
         RUN(avc_launch_conv(a, c.s, 0, p->tun));
@@ -1154,13 +1167,14 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     // ---------------- decoder
     {
         const DecNet& d = p->dec;
+        const float SL = d.slope;
         const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb, To = p->Tout;
         const long csb = (long)2 * d.n * 2 * C;
         const float* ddec = d_dec ? d_dec : ws + p->ddec;
         const LayerP& Lo = p->layers[d.out_conv];
         RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
         if (!dry) {
-            ConvArgs a = mk_dgrad(Lo, ws, ddec, (long)p->M * To, To, 1, 1, B, To, To, gA, (long)C * To, To, 1);
+            ConvArgs a = mk_dgrad(SL, Lo, ws, ddec, (long)p->M * To, To, 1, 1, B, To, To, gA, (long)C * To, To, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = d.n - 1; l >= 0; --l) {
@@ -1168,17 +1182,17 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const LayerP& L1 = p->layers[d.c1[l]];
             const LayerP& L2 = p->layers[d.c2[l]];
             dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(gA, ws + d.y2[l], ws + d.st2[l], B, C, T2, ws + d.cond, csb, (2 * l + 1) * 2 * C, dyA, ws + d.dcond, s));
+            if (!dry) RUN(in_bwd(SL, gA, ws + d.y2[l], ws + d.st2[l], B, C, T2, ws + d.cond, csb, (2 * l + 1) * 2 * C, dyA, ws + d.dcond, s));
             // dyA is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
             if (!dry) {
-                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, up, up, B, Ti, Ti, gB, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, up, up, B, Ti, Ti, gB, (long)C * Ti, Ti, 1);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + d.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, up, up, B, Ti, Ti));
             dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(gB, ws + d.y1[l], ws + d.st1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, dyB, ws + d.dcond, s));
+            if (!dry) RUN(in_bwd(SL, gB, ws + d.y1[l], ws + d.st1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, dyB, ws + d.dcond, s));
             if (!dry) {
-                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
@@ -1187,10 +1201,10 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
         const LayerP& Li = p->layers[d.in_conv];
         dyA = c.fresh((long)B * C * Tb);
-        if (!dry) RUN(in_bwd(gA, ws + d.y0, ws + d.st0, B, C, Tb, nullptr, 0, 0, dyA, nullptr, s));
+        if (!dry) RUN(in_bwd(SL, gA, ws + d.y0, ws + d.st0, B, C, Tb, nullptr, 0, 0, dyA, nullptr, s));
         RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
-            ConvArgs a = mk_dgrad(Li, ws, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb, ws + p->dz, (long)Cz * Tb, Tb, 1);
+            ConvArgs a = mk_dgrad(SL, Li, ws, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb, ws + p->dz, (long)Cz * Tb, Tb, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
@@ -1245,6 +1259,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
         auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
         const EncNet& e = p->spk;
+        const float SL = e.slope;
         const int C = e.c.c_h;
         float* dhA = ws + p->dhA;
         const LayerP& Lo = p->layers[e.outl];
@@ -1254,7 +1269,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             DenseArgs da;
             memset(&da, 0, sizeof(da));
             da.nlayers = 2 * e.nd + 1;
-            da.B = B; da.C = C;
+            da.B = B; da.C = C; da.slope = SL;
             da.in = ws + p->demb;      // [c_out][B] channel-major
             da.in2 = nullptr;           // (upstream d_emb is already folded into demb above)
             da.dpooled = dhA;
@@ -1289,7 +1304,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
         dyA = c.fresh((long)B * C * Tn);
-        if (!dry) RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, C, Tn, gA, dyA, s));
+        if (!dry) RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, C, Tn, gA, dyA, SL, s));
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
             const LayerP& L1 = p->layers[e.c1[l]];
@@ -1297,7 +1312,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             // dyA = G_{l+1} * (a2 > 0)
             dyB = c.fresh((long)B * C * Ti);
             if (!dry) {
-                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, nullptr, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, nullptr, (long)C * Ti, Ti, 1);
                 a.g[0].out2 = dyB;
                 a.g[0].mask = ws + e.a1[l];
                 RUN(avc_launch_conv(a, s, 0, p->tun));
@@ -1305,7 +1320,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
             dyA = c.fresh((long)B * C * Ti);  // (the wgrad of conv2 above still reads the previous dyA)
             if (!dry) {
-                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
                 a.g[0].out2 = dyA;  // next: dy2 of block l-1, or d(in_conv out) for l == 0
                 a.g[0].mask = (l > 0) ? ws + e.a2[l - 1] : ws + e.h0;
@@ -1322,11 +1337,12 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     // ---------------- content encoder
     {
         const EncNet& e = p->enc;
+        const float SL = e.slope;
         const int C = e.c.c_h, Tb = p->Tb, Co2 = 2 * e.c.c_out;
         const LayerP& Lh = p->layers[e.heads];
         RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
-            ConvArgs a = mk_dgrad(Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
+            ConvArgs a = mk_dgrad(SL, Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = e.n - 1; l >= 0; --l) {
@@ -1334,16 +1350,16 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const LayerP& L1 = p->layers[e.c1[l]];
             const LayerP& L2 = p->layers[e.c2[l]];
             dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
+            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
             if (!dry) {
-                ConvArgs a = mk_dgrad(L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
             dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
+            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
             if (!dry) {
-                ConvArgs a = mk_dgrad(L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
@@ -1351,7 +1367,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         dyA = c.fresh((long)B * C * e.T[0]);
-        if (!dry) RUN(in_bwd(gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
+        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
         RUN(flush_wgrads(c));
     }
@@ -1445,6 +1461,7 @@ extern "C" int avc_plan_create_ragged(const avc_model_cfg* cfg, int B, const int
     build_enc_params(p, p->enc, cfg->enc, false);
     DecNet& d = p->dec;
     d.c = dc;
+    d.slope = dc.act == 1 ? AVC_LRELU_SLOPE : 0.f;
     d.n = dc.n_conv_blocks;
     p->dec_param_off = p->param_floats;
     d.in_conv = add_layer(p, dc.c_h, dc.c_in, 1, 1, true);
@@ -1615,7 +1632,7 @@ static void set_rag_res(ConvArgs& a, const int* tab, const float* res, int mode,
     a.rt = 1;
 }
 
-static int rag_in(const avc_plan* p, const int* tab, const float* y, float* out, const avc_plan::RagLevel& lv, int C, const float* cond, long csb,
+static int rag_in(const avc_plan* p, float slope, const int* tab, const float* y, float* out, const avc_plan::RagLevel& lv, int C, const float* cond, long csb,
                   int coff, const float* res, int res_mode, const avc_plan::RagLevel* rl, hipStream_t s) {
     RagINArgs a;
     memset(&a, 0, sizeof(a));
@@ -1623,7 +1640,7 @@ static int rag_in(const avc_plan* p, const int* tab, const float* y, float* out,
     a.cond = cond; a.cond_sb = csb; a.cond_off = coff;
     a.res = res; a.res_mode = res ? res_mode : 0;
     if (res) { a.Tres = tab + rl->dT; a.offres = tab + rl->doff; }
-    a.B = p->B; a.C = C;
+    a.B = p->B; a.C = C; a.slope = slope;
     return avc_launch_rag_in_fwd(a, s);
 }
 
@@ -1631,12 +1648,13 @@ static int rag_enc_front(const avc_plan* p, const EncNet& e, const std::vector<a
                          const float* x, hipStream_t s) {
     // conv_bank (model.py:85-91) on the packed input [sum T][M] (frames as rows): channel stride 1, frame stride M
     const int M = e.c.c_in;
+    const float SL = e.slope;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sc = 1; a.x.st = M; a.x.ps = 1;
     a.Cred = M; a.mode = 0; a.stride = 1; a.bf16 = p->compute;
     a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128;
-    a.ot = 1; a.ops = 1; a.act = 1;
+    a.ot = 1; a.ops = 1; a.act = 1; a.slope = SL;
     a.ngroups = e.nb;
     a.img = AVC_IMG_K4;
     for (int g = 0; g < e.nb; ++g) {
@@ -1667,7 +1685,7 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
         RUN(avc_launch_pack_batch(all.data(), (int)all.size(), s));
     }
     // A conv on packed activations: source rows of the sample's own length (x.sc = -1), output block of `cout` channels.
-    auto conv = [&](const LayerP& L, const float* src, const avc_plan::RagLevel& sl, int cx, float* dst, const avc_plan::RagLevel& convl,
+    auto conv = [&](float slope, const LayerP& L, const float* src, const avc_plan::RagLevel& sl, int cx, float* dst, const avc_plan::RagLevel& convl,
                     const avc_plan::RagLevel& outl, int cout, int act, int ops) {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -1677,7 +1695,7 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
         a.ngroups = 1;
         set_group(a.g[0], ws + L.wpf, layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
         a.img = AVC_IMG_K4;
-        a.ot = 1; a.ops = ops; a.act = act;
+        a.ot = 1; a.ops = ops; a.act = act; a.slope = slope;
         a.g[0].out = dst;
         set_rag(a, tab, sl, cx, outl, convl, cout);
         return a;
@@ -1687,17 +1705,18 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
     {   // ---------------- speaker encoder on the target utterances (model.py:265-277)
         const hipStream_t s = sideS;
         const EncNet& e = p->spk;
+        const float SL = e.slope;
         const std::vector<avc_plan::RagLevel>& lv = p->rl_spk;
         const int C = e.c.c_h;
         RUN(rag_enc_front(p, e, lv, tab, params, ws, x_cond, s));
         {
-            ConvArgs a = conv(p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 1, 1);
+            ConvArgs a = conv(SL, p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = 0; l < e.n; ++l) {
-            ConvArgs a = conv(p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.a1[l], lv[l], lv[l], C, 1, 1);
+            ConvArgs a = conv(SL, p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.a1[l], lv[l], lv[l], C, 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            ConvArgs b = conv(p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.a2[l], lv[l + 1], lv[l + 1], C, 1, 1);
+            ConvArgs b = conv(SL, p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.a2[l], lv[l + 1], lv[l + 1], C, 1, 1);
             b.g[0].out2 = ws + e.out[l + 1];
             set_rag_res(b, tab, ws + e.out[l], e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, lv[l], C);
             RUN(avc_launch_conv(b, s, 0, p->tun));
@@ -1706,7 +1725,7 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
         DenseArgs da;
         memset(&da, 0, sizeof(da));
         da.nlayers = 2 * e.nd + 1;
-        da.B = B; da.C = C;
+        da.B = B; da.C = C; da.slope = SL;
         da.in = ws + e.hd[0];
         da.emb = ws + p->emb;
         for (int l = 0; l < da.nlayers; ++l) {
@@ -1727,53 +1746,55 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
     }
     {   // ---------------- content encoder on the source utterances (model.py:301-323)
         const EncNet& e = p->enc;
+        const float SL = e.slope;
         const std::vector<avc_plan::RagLevel>& lv = p->rl_enc;
         const int C = e.c.c_h;
         RUN(rag_enc_front(p, e, lv, tab, params, ws, x, s));
         {
-            ConvArgs a = conv(p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 0, 1);
+            ConvArgs a = conv(SL, p->layers[e.in_conv], ws + e.cat, lv[0], e.CC, ws + e.h0, lv[0], lv[0], C, 0, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + e.h0, ws + e.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+            RUN(rag_in(p, SL, tab, ws + e.h0, ws + e.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
         }
         for (int l = 0; l < e.n; ++l) {
-            ConvArgs a = conv(p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.y1[l], lv[l], lv[l], C, 0, 1);
+            ConvArgs a = conv(SL, p->layers[e.c1[l]], ws + e.out[l], lv[l], C, ws + e.y1[l], lv[l], lv[l], C, 0, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + e.y1[l], ws + e.a1[l], lv[l], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
-            ConvArgs b = conv(p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.y2[l], lv[l + 1], lv[l + 1], C, 0, 1);
+            RUN(rag_in(p, SL, tab, ws + e.y1[l], ws + e.a1[l], lv[l], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+            ConvArgs b = conv(SL, p->layers[e.c2[l]], ws + e.a1[l], lv[l], C, ws + e.y2[l], lv[l + 1], lv[l + 1], C, 0, 1);
             RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + e.y2[l], ws + e.out[l + 1], lv[l + 1], C, nullptr, 0, 0, ws + e.out[l],
+            RUN(rag_in(p, SL, tab, ws + e.y2[l], ws + e.out[l + 1], lv[l + 1], C, nullptr, 0, 0, ws + e.out[l],
                        e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY, &lv[l], s));
         }
-        ConvArgs h = conv(p->layers[e.heads], ws + e.out[e.n], lv[e.n], C, ws + p->muls, lv[e.n], lv[e.n], 2 * e.c.c_out, 0, 1);
+        ConvArgs h = conv(SL, p->layers[e.heads], ws + e.out[e.n], lv[e.n], C, ws + p->muls, lv[e.n], lv[e.n], 2 * e.c.c_out, 0, 1);
         RUN(avc_launch_conv(h, s, 0, p->tun));
     }
     join_side(p, mainS, sideS);
     {   // ---------------- decoder(mu, emb) (model.py:347-371, :387-391: no noise)
         const DecNet& d = p->dec;
+        const float SL = d.slope;
         const std::vector<avc_plan::RagLevel>& lv = p->rl_dec;
         const int C = d.c.c_h, Cz = d.c.c_in;
         const long csb = (long)2 * d.n * 2 * C;
         {   // all 2n AdaIN affine Linears as ONE GEMM on emb (uniform: one row per utterance)
-            ConvArgs a = mk_fwd(p, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
+            ConvArgs a = mk_fwd(p, SL, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         {   // z = mu: the first Cz channels of every sample's (mu | log_sigma) block
-            ConvArgs a = conv(p->layers[d.in_conv], ws + p->muls, lv[0], 2 * Cz, ws + d.y0, lv[0], lv[0], C, 0, 1);
+            ConvArgs a = conv(SL, p->layers[d.in_conv], ws + p->muls, lv[0], 2 * Cz, ws + d.y0, lv[0], lv[0], C, 0, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + d.y0, ws + d.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
+            RUN(rag_in(p, SL, tab, ws + d.y0, ws + d.out[0], lv[0], C, nullptr, 0, 0, nullptr, 0, nullptr, s));
         }
         for (int l = 0; l < d.n; ++l) {
             const int up = d.c.upsample[l];
-            ConvArgs a = conv(p->layers[d.c1[l]], ws + d.out[l], lv[l], C, ws + d.y1[l], lv[l], lv[l], C, 0, 1);
+            ConvArgs a = conv(SL, p->layers[d.c1[l]], ws + d.out[l], lv[l], C, ws + d.y1[l], lv[l], lv[l], C, 0, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + d.y1[l], ws + d.a1[l], lv[l], C, ws + d.cond, csb, (2 * l) * 2 * C, nullptr, 0, nullptr, s));
+            RUN(rag_in(p, SL, tab, ws + d.y1[l], ws + d.a1[l], lv[l], C, ws + d.cond, csb, (2 * l) * 2 * C, nullptr, 0, nullptr, s));
             // second conv: C * up channels, pixel-shuffled on store into the level-(l+1) buffer (model.py:359-361)
-            ConvArgs b = conv(p->layers[d.c2[l]], ws + d.a1[l], lv[l], C, ws + d.y2[l], lv[l], lv[l + 1], C, 0, up);
+            ConvArgs b = conv(SL, p->layers[d.c2[l]], ws + d.a1[l], lv[l], C, ws + d.y2[l], lv[l], lv[l + 1], C, 0, up);
             RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(rag_in(p, tab, ws + d.y2[l], ws + d.out[l + 1], lv[l + 1], C, ws + d.cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l],
+            RUN(rag_in(p, SL, tab, ws + d.y2[l], ws + d.out[l + 1], lv[l + 1], C, ws + d.cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l],
                        up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, &lv[l], s));
         }
-        ConvArgs o = conv(p->layers[d.out_conv], ws + d.out[d.n], lv[d.n], C, ws + p->decb, lv[d.n], lv[d.n], p->M, 0, 1);
+        ConvArgs o = conv(SL, p->layers[d.out_conv], ws + d.out[d.n], lv[d.n], C, ws + p->decb, lv[d.n], lv[d.n], p->M, 0, 1);
         RUN(avc_launch_conv(o, s, 0, p->tun));
     }
     return 0;

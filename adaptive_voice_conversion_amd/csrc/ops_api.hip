@@ -123,7 +123,8 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.M = Cout; a.Mp = avc_cdiv(Cout, 128) * 128;
     a.Tout = (Tin + padL + padR - KS) / stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = ops;
-    a.act = act;
+    a.act = act ? 1 : 0;
+    a.slope = act == 2 ? AVC_LRELU_SLOPE : 0.f;
     a.res_mode = res_mode; a.res_to_primary = 0;
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
     a.ngroups = 1;
@@ -202,7 +203,8 @@ int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, lon
     a.y = y; a.out = out; a.mean = mean; a.rstd = rstd;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = B * C; a.C = C; a.T = T; a.relu = relu;
+    a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     return avc_launch_in_fwd(a, (hipStream_t)stream);
 }
 
@@ -213,7 +215,8 @@ int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const fl
     a.g = g; a.y = y; a.mean = mean; a.rstd = rstd;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = dcond_sb; a.dcond_off = dcond_off;
-    a.R = B * C; a.C = C; a.T = T; a.relu = relu;
+    a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     return avc_launch_in_bwd(a, (hipStream_t)stream);
 }
 

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(AVC_THREADS) rag_instnorm_fwd_kernel(const Rag
         rrow = a.res + (long)a.C * a.offres[b] + (long)c * Tres;
     }
     for (int t = l; t < T; t += 64) {
-        float w = fmaxf(in_preact(in_xhat(yrow[t], mean, rstd), gamma, beta), 0.f);
+        float w = avc_act(in_preact(in_xhat(yrow[t], mean, rstd), gamma, beta), a.slope);
         if (rrow) {
             if (a.res_mode == AVC_RES_IDENTITY)
                 w += rrow[t];

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdAr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float w = in_preact(in_xhat(o[e], mean, rstd), gamma, beta);
-                o[e] = a.relu ? fmaxf(w, 0.f) : w;
+                o[e] = a.relu ? avc_act(w, a.slope) : w;
             }
             if (rrow) {
                 float4 r = res4(rrow, a.res_mode, 4 * i4, a.Tres);
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_generic_kernel(const
     const float* rrow = a.res ? a.res + (long)row * a.Tres : nullptr;
     for (int t = l; t < a.T; t += 64) {
         float w = in_preact(in_xhat(yrow[t], mean, rstd), gamma, beta);
-        w = a.relu ? fmaxf(w, 0.f) : w;
+        w = a.relu ? avc_act(w, a.slope) : w;
         if (rrow) {
             if (a.res_mode == AVC_RES_IDENTITY)
                 w += rrow[t];
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_kernel(const INBwdAr
             for (int e = 0; e < 4; ++e) {
                 float h = in_xhat(xx[e], mean, rstd);
                 float w = in_preact(h, gamma, beta);
-                float gme = (!a.relu || w > 0.f) ? gg[e] : 0.f;
+                float gme = avc_act_grad(gg[e], !a.relu || w > 0.f, a.slope);
                 xx[e] = h;
                 gg[e] = gme;
                 s1 += gme;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_generic_kernel(const
     for (int t = l; t < a.T; t += 64) {
         float h = in_xhat(yrow[t], mean, rstd);
         float w = in_preact(h, gamma, beta);
-        float gme = (!a.relu || w > 0.f) ? grow[t] : 0.f;
+        float gme = avc_act_grad(grow[t], !a.relu || w > 0.f, a.slope);
         s1 += gme;
         s2 += gme * h;
     }
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_generic_kernel(const
     for (int t = l; t < a.T; t += 64) {
         float h = in_xhat(yrow[t], mean, rstd);
         float w = in_preact(h, gamma, beta);
-        float gme = (!a.relu || w > 0.f) ? grow[t] : 0.f;
+        float gme = avc_act_grad(grow[t], !a.relu || w > 0.f, a.slope);
         drow[t] = rstd * (gme * gamma - m1 - h * m2);
     }
 }
@@ -353,14 +353,14 @@ __global__ void __launch_bounds__(AVC_THREADS) timepool_fwd_kernel(const float* 
 
 // backward of the pooling + ReLU mask of the producing block: G = dP/T ; dy = G * (a > 0)
 __global__ void __launch_bounds__(AVC_THREADS)
-timepool_bwd_kernel(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy) {
+timepool_bwd_kernel(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, float slope) {
     long n = (long)B * C * T;
     for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < n; e += (long)gridDim.x * AVC_THREADS) {
         long r = e / T;
         int b = (int)(r / C), c = (int)(r - (long)b * C);
         float gv = dP[(long)c * B + b] / (float)T;
         if (G) G[e] = gv;
-        if (dy) dy[e] = (amask[e] > 0.f) ? gv : 0.f;
+        if (dy) dy[e] = avc_act_grad(gv, amask[e] > 0.f, slope);
     }
 }
 
@@ -585,10 +585,10 @@ int avc_launch_timepool_fwd(const float* in, int B, int C, int T, float* out, hi
     hipLaunchKernelGGL(timepool_fwd_kernel, dim3(avc_cdiv(B * C, AVC_THREADS)), dim3(AVC_THREADS), 0, s, in, B, C, T, out);
     return (int)hipGetLastError();
 }
-int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, hipStream_t s) {
+int avc_launch_timepool_bwd(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, float slope, hipStream_t s) {
     ProfScope ps(AVC_K_MISC, 0.0, 0.0, s);
     hipLaunchKernelGGL(timepool_bwd_kernel, dim3(ew_blocks((long)B * C * T)), dim3(AVC_THREADS), 0, s, dP, amask, B, C, T,
-                       G, dy);
+                       G, dy, slope);
     return (int)hipGetLastError();
 }
 int avc_launch_reparam_fwd(const float* muls, const float* eps, int B, int C, int Tb, float* z, hipStream_t s) {

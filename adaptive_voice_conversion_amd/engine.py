@@ -12,9 +12,12 @@ from . import _lib
 from ._lib import DecoderCfg, EncoderCfg, ModelCfg
 
 
+ACTS = {"relu": 0, "lrelu": 1}   # model.py:93-99 get_act: nn.ReLU / nn.LeakyReLU (slope 0.01)
+
+
 def _check_common(name, c):
-    if c.get("act", "relu") != "relu":
-        raise NotImplementedError(f"{name}.act={c['act']!r}: only 'relu' (config.yaml default) is implemented")
+    if c.get("act", "relu") not in ACTS:
+        raise NotImplementedError(f"{name}.act={c['act']!r}: 'relu' or 'lrelu' (model.py:93-99)")
     if float(c.get("dropout_rate", 0)) != 0.0:
         raise NotImplementedError(f"{name}.dropout_rate={c['dropout_rate']}: only 0 (config.yaml default) is implemented")
 
@@ -28,6 +31,7 @@ def cfg_from_dict(config) -> ModelCfg:
         for f in ("c_in", "c_h", "c_out", "kernel_size", "bank_size", "bank_scale", "c_bank", "n_conv_blocks"):
             setattr(dst, f, int(c[f]))
         dst.n_dense_blocks = int(c["n_dense_blocks"]) if dense else 0
+        dst.act = ACTS[c.get("act", "relu")]
         if dst.n_conv_blocks > _lib.MAX_BLOCKS:
             raise NotImplementedError("more than 8 conv blocks")
         for i, s in enumerate(list(c["subsample"])[: dst.n_conv_blocks]):
@@ -38,6 +42,7 @@ def cfg_from_dict(config) -> ModelCfg:
         raise NotImplementedError("Decoder.sn=True (spectral norm) is not implemented; config.yaml default is False")
     for f in ("c_in", "c_cond", "c_h", "c_out", "kernel_size", "n_conv_blocks"):
         setattr(m.dec, f, int(d[f]))
+    m.dec.act = ACTS[d.get("act", "relu")]
     for i, s in enumerate(list(d["upsample"])[: m.dec.n_conv_blocks]):
         m.dec.upsample[i] = int(s)
     return m

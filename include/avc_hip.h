@@ -46,12 +46,14 @@ extern "C" {
 typedef struct avc_encoder_cfg {
     int c_in, c_h, c_out, kernel_size, bank_size, bank_scale, c_bank, n_conv_blocks, n_dense_blocks;
     int subsample[AVC_MAX_BLOCKS];
+    int act; /* config.yaml `act` (model.py:93-99 get_act): 0 = relu, 1 = lrelu (nn.LeakyReLU, slope 0.01) */
 } avc_encoder_cfg;
 
 /* config.yaml:25-36 (Decoder) */
 typedef struct avc_decoder_cfg {
     int c_in, c_cond, c_h, c_out, kernel_size, n_conv_blocks;
     int upsample[AVC_MAX_BLOCKS];
+    int act; /* 0 = relu, 1 = lrelu */
 } avc_decoder_cfg;
 
 typedef struct avc_model_cfg {
@@ -261,7 +263,7 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
  * default engine multiplies in exact fp32). */
 long avc_packed_weight_floats_x3(int Cout, int Cin, int KS, int dgrad);
 int avc_pack_weight_x3(const float* w, int Cout, int Cin, int KS, int dgrad, float* dst, void* stream);
-/* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b); ops = pixel_shuffle_1d factor of the store
+/* pad_layer (model.py:21-32): y = act(conv1d(reflect_pad(x), W) + b) (act: 0 none, 1 ReLU, 2 LeakyReLU(0.01)); ops = pixel_shuffle_1d factor of the store
  * (model.py:52-59); res/res_mode: y2 = y + resmap(res) (1 identity, 2 avg_pool1d(2, ceil_mode) model.py:248) */
 int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp,
                    const float* bias, int Cout, int KS, int stride, int act, float* out, long ob, long oc, int ot,
@@ -279,6 +281,7 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
                      void* stream);
 /* nn.InstanceNorm1d(affine=False) (model.py:296,341) [+ append_cond model.py:77-83] [+ ReLU] [+ residual:
  * 1 identity, 2 avg-pool(ceil), 5 nearest x2]; cond row b: beta = cond[b*cond_sb + cond_off + c], gamma = [.. + C + c] */
+/* relu: 0 = no activation, 1 = ReLU, 2 = LeakyReLU(0.01) */
 int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu,
                      const float* res, int res_mode, int Tres, float* out, float* mean, float* rstd, void* stream);
 int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const float* rstd, int B, int C, int T,

@@ -29,6 +29,7 @@ REF = "/root/reference"
 # 400 seeds: that fixture records the reference's decisions instead, see run_case.)  run_case asserts the margins.
 M80_FULL_SEED, M80_FULL_MARGIN = 19, 4e-6
 TINY_B2_SEED, TINY_MARGIN = 5, 2e-5
+TINY_LRELU_SEED = 3
 OUT_DIR = os.path.join(ROOT, "tests", "golden")
 
 
@@ -68,7 +69,7 @@ class ReluRecorder:
 
     def __init__(self, ref):
         self.pre, self.on = [], False
-        self.handles = [m.register_forward_pre_hook(self._hook) for m in ref.modules() if isinstance(m, torch.nn.ReLU)]
+        self.handles = [m.register_forward_pre_hook(self._hook) for m in ref.modules() if isinstance(m, (torch.nn.ReLU, torch.nn.LeakyReLU))]
 
     def _hook(self, mod, inp):
         if self.on:
@@ -224,6 +225,9 @@ def main(out_dir=None):
     run_case(model_mod, "train_m512_t128_b1", O.stock_config(512), B=1, T=128, seed=3, n_steps=1, full_outputs=False)
     run_case(model_mod, "train_tiny_t32_b2", O.tiny_config(), B=2, T=32, seed=TINY_B2_SEED, n_steps=3, full_grads="all", relu_record=True, margin=TINY_MARGIN)
     run_case(model_mod, "train_tiny_t24_b3", O.tiny_config(), B=3, T=24, seed=5, n_steps=1)
+    # act: lrelu (config-legal, model.py:93-99): every tensor of the tiny net, a margin seed again
+    run_case(model_mod, "train_tiny_lrelu_t32_b2", O.tiny_config(act="lrelu"), B=2, T=32, seed=TINY_LRELU_SEED, n_steps=1, full_grads="all",
+             relu_record=True, margin=TINY_MARGIN)
     run_inference_case(model_mod, "infer_m80_t100_c77", c80, Ts=100, Tc=77, seed=6)
     run_inference_case(model_mod, "infer_tiny_t37_c19", O.tiny_config(), Ts=37, Tc=19, seed=7)
     make_init_golden(model_mod)
@@ -233,6 +237,7 @@ if __name__ == "__main__" and "--find-seed" in sys.argv:
     mm = import_reference()
     print("m80 B=1 T=64:", find_margin_seed(mm, O.stock_config(80), 1, 64, M80_FULL_MARGIN, tries=3000))
     print("tiny B=2 T=32:", find_margin_seed(mm, O.tiny_config(), 2, 32, TINY_MARGIN, first=4))
+    print("tiny lrelu B=2 T=32:", find_margin_seed(mm, O.tiny_config(act="lrelu"), 2, 32, TINY_MARGIN))
     sys.exit(0)
 
 if __name__ == "__main__":

@@ -253,7 +253,9 @@ def test_inference_from_path_wav_to_wav(kind, tmp_path):
     wavs, mels = inf.convert_batch_to_wav(pairs)
     assert len(wavs) == 3 and np.array_equal(wavs[0], wavs[1]) and wavs[2].shape != wavs[0].shape
     np.testing.assert_allclose(mels[0], mel, rtol=1e-4, atol=1e-4)
-    assert wavs[0].shape == wav.shape and np.allclose(wavs[0], wav, atol=1e-5 * np.abs(wav).max())
+    # (the batch goes through the ragged plan, whose InstanceNorm rows reduce in another order than the uniform plan's: the mels agree
+    # to 1e-6, three Griffin-Lim iterations later the waveforms to ~1e-5 of the peak)
+    assert wavs[0].shape == wav.shape and np.allclose(wavs[0], wav, atol=1e-4 * np.abs(wav).max())
     ref = D.melspectrogram2wav(dec, hp)
     assert abs(len(wav) - len(ref)) <= 512                # (trim picks whole 512-sample hops: a borderline frame may flip)
     n = min(len(wav), len(ref))

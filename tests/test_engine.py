@@ -82,6 +82,8 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
+    ("emu", "tiny_lrelu", 3, 40, False),   # act: lrelu in all three networks
+    pytest.param("gpu", "tiny_lrelu", 5, 64, False, marks=GPU),
     ("emu", "tiny128", 2, 40, False),   # 128 hidden channels
     ("emu", "tiny128x3", 2, 40, False), # ... + tuning conv_x3 = 2: the split-bf16 conv kernel in every eligible layer of the plan
     pytest.param("gpu", "m80x3", 8, 128, False, marks=GPU),   # split-bf16 kernel, every eligible layer
@@ -96,7 +98,7 @@ CASES = [
 
 
 def get_cfg(name):
-    return {"tiny": O.tiny_config, "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -170,12 +172,16 @@ def test_short_input_rejected_like_reference(kind):
         Plan(O.stock_config(80), 1, 16, lib=lib)
 
 
+X3 = dict(compute_dtype="fp32x3", tuning={"conv_x3": 2})   # opt-in split-bf16 products in EVERY eligible conv layer + the weight gradients
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("compute", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("name,cfgname", [("train_m80_t128_b2", "m80"), ("train_m80_t128_b4_s1", "m80"), ("train_m80_t64_b1_full", "m80"),
                                           ("train_m80_t256_b1", "m80"), ("train_m512_t128_b1", "m512"),
                                           ("train_tiny_t32_b2", "tiny"), ("train_tiny_t24_b3", "tiny")])
-def test_gpu_matches_reference_goldens(name, cfgname, golden_dir):
-    """HIP path vs fixtures produced by the REAL reference (oracle/make_golden.py)."""
+def test_gpu_matches_reference_goldens(name, cfgname, compute, golden_dir):
+    """HIP path vs fixtures produced by the REAL reference (oracle/make_golden.py); the opt-in fp32x3 mode against the same bars."""
     from oracle.make_golden import tensor_stats
     lib, dev = backend("gpu")
     g = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -183,7 +189,7 @@ def test_gpu_matches_reference_goldens(name, cfgname, golden_dir):
     B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
     sd = O.make_state_dict(cfg, seed)
     x, eps = O.make_inputs(cfg, B, T, seed)
-    plan = Plan(cfg, B, T, lib=lib)
+    plan = Plan(cfg, B, T, lib=lib, **(X3 if compute == "fp32x3" else {}))
     params = flat_params(plan, sd, dev)
     ws = torch.zeros(plan.workspace_floats, device=dev)
     xd, ed = x.to(dev), eps.to(dev)
@@ -218,11 +224,15 @@ def test_gpu_matches_reference_goldens(name, cfgname, golden_dir):
     assert total == pytest.approx(float(g["grad_norm_0"]), rel=1e-4 if strict else 5e-3)
 
 
-@pytest.mark.parametrize("kind,name,cfgname", [("emu", "train_tiny_t32_b2", "tiny"),
-                                               pytest.param("gpu", "train_tiny_t32_b2", "tiny", marks=GPU),
-                                               pytest.param("gpu", "train_m80_t64_b1_full", "m80", marks=GPU),
-                                               pytest.param("gpu", "train_m80_t128_b2", "m80", marks=GPU)])
-def test_complete_gradient_tensors_vs_reference_golden(kind, name, cfgname, golden_dir):
+@pytest.mark.parametrize("kind,name,cfgname,compute", [("emu", "train_tiny_t32_b2", "tiny", "fp32"),
+                                                       ("emu", "train_tiny_lrelu_t32_b2", "tiny_lrelu", "fp32"),   # act: lrelu (model.py:93-99), every tensor vs the REAL reference
+                                                       pytest.param("gpu", "train_tiny_lrelu_t32_b2", "tiny_lrelu", "fp32", marks=GPU),
+                                                       pytest.param("gpu", "train_tiny_t32_b2", "tiny", "fp32", marks=GPU),
+                                                       pytest.param("gpu", "train_m80_t64_b1_full", "m80", "fp32", marks=GPU),
+                                                       pytest.param("gpu", "train_m80_t128_b2", "m80", "fp32", marks=GPU),
+                                                       pytest.param("gpu", "train_m80_t64_b1_full", "m80", "fp32x3", marks=GPU),
+                                                       pytest.param("gpu", "train_m80_t128_b2", "m80", "fp32x3", marks=GPU)])
+def test_complete_gradient_tensors_vs_reference_golden(kind, name, cfgname, compute, golden_dir):
     """Strict pin that takes NOTHING from the engine to drive a checker: the fixture holds complete gradient tensors
     produced by the REAL reference (every bias + one block of each network; every tensor of the tiny net) and the
     reference's own 0/1 ReLU decisions.  The margin fixtures were generated from seeds whose forward pass keeps every
@@ -236,7 +246,7 @@ def test_complete_gradient_tensors_vs_reference_golden(kind, name, cfgname, gold
     B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
     sd = O.make_state_dict(cfg, seed)
     x, eps = O.make_inputs(cfg, B, T, seed)
-    plan = Plan(cfg, B, T, lib=lib)
+    plan = Plan(cfg, B, T, lib=lib, **(X3 if compute == "fp32x3" else {}))
     params = flat_params(plan, sd, dev)
     ws = torch.zeros(plan.workspace_floats, device=dev)
     xd, ed = x.to(dev), eps.to(dev)
@@ -271,7 +281,7 @@ def test_complete_gradient_tensors_vs_reference_golden(kind, name, cfgname, gold
             assert e < tol, (k, e, diff.size)
         checked += 1
     assert checked >= 60
-    print(f"[{kind}/{name}] {checked} complete gradient tensors vs the REAL reference, no branch matching: worst rel-L2 {worst:.2e} "
+    print(f"[{kind}/{name}/{compute}] {checked} complete gradient tensors vs the REAL reference, no branch matching: worst rel-L2 {worst:.2e} "
           f"(bar {tol:g}); ReLU decisions differing from the reference's: {diff.size} of {n} (closest recorded site {float(g['relu_margin']):.1e})")
 
 

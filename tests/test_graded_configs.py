@@ -105,7 +105,8 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
     assert errs[len(errs) // 2] < 1e-4
 
 
-@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU), pytest.param("gpu", "m80", 4, 1024, marks=GPU)])
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU), pytest.param("gpu", "m80", 4, 1024, marks=GPU),
+                                              pytest.param("gpu", "m80", 64, 1024, marks=GPU)])
 def test_fp32x3_mode_meets_the_same_bars(kind, cfgname, B, T):
     """compute_dtype "fp32x3" (opt-in: the big conv and weight-gradient products from three bf16 terms per operand on the bf16
     matrix core): the SAME forward / loss / gradient bars as the exact-fp32 engine at the graded shapes -- per tensor at
@@ -207,8 +208,9 @@ def test_relu_branches_agree_with_the_oracle_without_engine_masks(kind, cfgname,
     assert worst < 1e-5, worst
 
 
-@pytest.mark.parametrize("kind,cfgname,B,T,rows", [("emu", "tiny", 9, 32, 3), pytest.param("gpu", "m80", 1024, 128, 16, marks=GPU)])
-def test_inference_batch_matches_oracle_on_random_rows(kind, cfgname, B, T, rows):
+@pytest.mark.parametrize("kind,cfgname,B,T,rows,compute", [("emu", "tiny", 9, 32, 3, "fp32"), pytest.param("gpu", "m80", 1024, 128, 16, "fp32", marks=GPU),
+                                                           pytest.param("gpu", "m80", 1024, 128, 16, "fp32x3", marks=GPU)])
+def test_inference_batch_matches_oracle_on_random_rows(kind, cfgname, B, T, rows, compute):
     """BASELINE configs[3]: batch-1024 one-shot conversion through an inference plan.  Samples are
     independent (no batch statistics anywhere), so `rows` random rows are compared with the
     oracle run on those rows alone."""
@@ -217,8 +219,8 @@ def test_inference_batch_matches_oracle_on_random_rows(kind, cfgname, B, T, rows
     sd = O.make_state_dict(cfg, 11)
     x, _ = O.make_inputs(cfg, B, T, 11)
     xc, _ = O.make_inputs(cfg, B, T, 12)
-    plan = Plan(cfg, B, T, T, lib=lib, mode="inference")
-    train_plan = Plan(cfg, B, T, T, lib=lib)
+    plan = Plan(cfg, B, T, T, lib=lib, mode="inference", compute_dtype=compute)
+    train_plan = Plan(cfg, B, T, T, lib=lib, compute_dtype=compute)
     assert plan.workspace_floats < 0.7 * train_plan.workspace_floats      # no gradient / slab / dy buffers
     params = flat_params(plan, sd, dev)
     ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)

@@ -27,6 +27,7 @@ CASES = [
     ("train_m512_t128_b1", lambda: O.stock_config(512)),
     ("train_tiny_t32_b2", O.tiny_config),
     ("train_tiny_t24_b3", O.tiny_config),
+    ("train_tiny_lrelu_t32_b2", lambda: O.tiny_config(act="lrelu")),
 ]
 
 
@@ -95,7 +96,7 @@ def test_unclipped_gradients_match_reference(golden_dir):
 
 
 @pytest.mark.parametrize("name,cfgf", [("train_m80_t64_b1_full", lambda: O.stock_config(80)), ("train_tiny_t32_b2", O.tiny_config),
-                                       ("train_m80_t128_b2", lambda: O.stock_config(80))])
+                                       ("train_m80_t128_b2", lambda: O.stock_config(80)), ("train_tiny_lrelu_t32_b2", lambda: O.tiny_config(act="lrelu"))])
 def test_complete_gradient_tensors_and_relu_decisions_match_reference(name, cfgf, golden_dir):
     """The fixtures with a ReLU record hold COMPLETE gradient tensors of the reference (every bias + one block of each
     network; everything for the tiny net) and its 0/1 ReLU decisions.  The two margin fixtures (no pre-activation
