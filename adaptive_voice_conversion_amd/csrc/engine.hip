@@ -1172,41 +1172,78 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         const long csb = (long)2 * d.n * 2 * C;
         const float* ddec = d_dec ? d_dec : ws + p->ddec;
         const LayerP& Lo = p->layers[d.out_conv];
-        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(SL, Lo, ws, ddec, (long)p->M * To, To, 1, 1, B, To, To, gA, (long)C * To, To, 1);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
+        const LayerP& Li = p->layers[d.in_conv];
+        // every dy a weight-gradient launch reads gets its own buffer (the launches run later, beside the encoders' backward)
+        float* dy2[AVC_MAX_BLOCKS];
+        float* dy1[AVC_MAX_BLOCKS];
+        for (int l = d.n - 1; l >= 0; --l) {
+            dy2[l] = c.fresh((long)B * C * d.T[l + 1]);
+            dy1[l] = c.fresh((long)B * C * d.T[l]);
         }
+        float* dy0 = c.fresh((long)B * C * Tb);
+        // The decoder's backward is one serial chain of ~26 small kernels (T_l = 128 .. 16) that runs ALONE on the GPU -- nothing
+        // else is ready before d(emb) and d(muls) exist (traced: 0.7 ms with one kernel in flight).  Like the forward pass it is
+        // issued as two half-batch chains on two streams for B >= dec_split_min: every tensor is [B, ...], a half is a pointer
+        // offset, and InstanceNorm / AdaIN statistics and d(cond) rows are per sample.
+        auto chain = [&](int b0, int Bn, hipStream_t s) -> int {
+            float* gA = ws + p->gA;
+            float* gB = ws + p->gB;
+            float* gC = ws + p->gC;
+            auto half_in_bwd = [&](const float* g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy) -> int {
+                INBwdArgs a;
+                a.g = g + off; a.y = ws + yoff + off;
+                a.mean = ws + stoff + (long)b0 * C; a.rstd = ws + stoff + (long)B * C + (long)b0 * C;
+                a.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.cond_sb = csb; a.cond_off = coff;
+                a.dy = dy + off; a.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.dcond_sb = csb; a.dcond_off = coff;
+                a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = SL;
+                return avc_launch_in_bwd(a, s);
+            };
+            {
+                const long oi = (long)b0 * p->M * To, oo = (long)b0 * C * To;
+                ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, (long)p->M * To, To, 1, 1, Bn, To, To, gA + oo, (long)C * To, To, 1);
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+            }
+            for (int l = d.n - 1; l >= 0; --l) {
+                const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
+                const long o2 = (long)b0 * C * T2, o1 = (long)b0 * C * Ti;
+                RUN(half_in_bwd(gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * C, true, dy2[l]));
+                {   // dy2 is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
+                    ConvArgs a = mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1);
+                    RUN(avc_launch_conv(a, s, 0, p->tun));
+                }
+                RUN(half_in_bwd(gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * C, true, dy1[l]));
+                {
+                    ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, gC + o1, (long)C * Ti, Ti, 1);
+                    set_res(a, gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                    RUN(avc_launch_conv(a, s, 0, p->tun));
+                }
+                float* t = gA; gA = gC; gC = t;
+            }
+            const long ob = (long)b0 * C * Tb;
+            RUN(half_in_bwd(gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
+            ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Cz * Tb, (long)Cz * Tb, Tb, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+            return 0;
+        };
+        if (!dry) {
+            if (B >= p->tun.dec_split_min && side_ready(p)) {
+                const int Bh = B / 2;
+                const hipStream_t s2 = fork_side(p, s);
+                RUN(chain(0, Bh, s));
+                RUN(chain(Bh, B - Bh, s2));
+                join_side(p, s, s2);
+            } else {
+                RUN(chain(0, B, s));
+            }
+        }
+        // the weight gradients of the decoder (recorded; launched in batches on the wgrad stream, flush_wgrads)
+        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
         for (int l = d.n - 1; l >= 0; --l) {
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
-            const LayerP& L1 = p->layers[d.c1[l]];
-            const LayerP& L2 = p->layers[d.c2[l]];
-            dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(SL, gA, ws + d.y2[l], ws + d.st2[l], B, C, T2, ws + d.cond, csb, (2 * l + 1) * 2 * C, dyA, ws + d.dcond, s));
-            // dyA is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
-            if (!dry) {
-                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, up, up, B, Ti, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-            }
-            RUN(wgrad_layer(c, L2, ws + d.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, up, up, B, Ti, Ti));
-            dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(SL, gB, ws + d.y1[l], ws + d.st1[l], B, C, Ti, ws + d.cond, csb, (2 * l) * 2 * C, dyB, ws + d.dcond, s));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
-                set_res(a, gA, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-            }
-            RUN(wgrad_layer(c, L1, ws + d.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
-            rot();
+            RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, T2, up, up, B, Ti, Ti));
+            RUN(wgrad_layer(c, p->layers[d.c1[l]], ws + d.out[l], (long)C * Ti, Ti, 1, dy1[l], (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
         }
-        const LayerP& Li = p->layers[d.in_conv];
-        dyA = c.fresh((long)B * C * Tb);
-        if (!dry) RUN(in_bwd(SL, gA, ws + d.y0, ws + d.st0, B, C, Tb, nullptr, 0, 0, dyA, nullptr, s));
-        RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(SL, Li, ws, dyA, (long)C * Tb, Tb, 1, 1, B, Tb, Tb, ws + p->dz, (long)Cz * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
-        }
+        RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dy0, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
         // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
         const LayerP& La = p->layers[d.affine];
         RUN(wgrad_layer(c, La, ws + p->emb, 0, 1, d.c.c_cond, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B));
