@@ -124,7 +124,7 @@ int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream);
 typedef struct avc_tuning {
     int struct_size;        /* sizeof(avc_tuning) of the caller (set by avc_tuning_init; a mismatch is refused) */
     int single_stream;      /* 1: every kernel on the caller's stream (profiling / per-class event brackets) */
-    int dec_split_min;      /* smallest batch whose decoder forward runs as two half-batch chains on two streams (32) */
+    int dec_split_min;      /* smallest batch whose decoder forward AND backward run as two half-batch chains on two streams (128) */
     int conv_x3;            /* 1: split-bf16 conv kernel (csrc/conv_x3.hip) for the k = 5 layers that fill the chip; 2: every eligible layer */
     int wgrad_x3;           /* 1: split-bf16 products in the whole-chunk weight-gradient launches */
     int dgrad_par;          /* 0: stride-2 dgrad multiplies all taps of the zero-upsampled dy (default 1: one column parity per wave) */

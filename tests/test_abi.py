@@ -41,3 +41,36 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_tuning_is_plan_scoped_or_thread_local_never_process_wide():
+    """include/avc_hip.h: "the library has NO process-wide mutable state".  avc_set_tuning edits the CALLING thread's op-level
+    copy only; a plan captures its own avc_tuning at creation (host-only calls: no GPU needed)."""
+    import threading
+    from adaptive_voice_conversion_amd import _lib
+    from adaptive_voice_conversion_amd.engine import Plan
+    from oracle import avc_oracle as O
+    lib = _lib.load()
+    base = _lib.Tuning()
+    lib.avc_get_op_tuning(ctypes.byref(base))
+    assert base.struct_size == ctypes.sizeof(_lib.Tuning) and base.conv_ck5 == 8 and base.wgrad_batch == 12
+    assert lib.avc_set_tuning(b"no_such_knob", 1) == -1
+    seen = {}
+
+    def other():
+        assert lib.avc_set_tuning(b"conv_ck5", 16) == 0 and lib.avc_set_tuning(b"conv_x3", 2) == 0
+        t = _lib.Tuning()
+        lib.avc_get_op_tuning(ctypes.byref(t))
+        seen["other"] = (t.conv_ck5, t.conv_x3)
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    mine = _lib.Tuning()
+    lib.avc_get_op_tuning(ctypes.byref(mine))
+    assert seen["other"] == (16, 2) and (mine.conv_ck5, mine.conv_x3) == (8, 0)      # the other thread's edits stayed there
+    cfg = O.tiny_config(c_h=128, c_bank=32)
+    plain, x3 = Plan(cfg, 2, 40, lib=lib), Plan(cfg, 2, 40, lib=lib, tuning={"conv_x3": 2})
+    assert x3.workspace_floats > plain.workspace_floats                                # the x3 plan carries its own weight images
+    assert Plan(cfg, 2, 40, lib=lib).workspace_floats == plain.workspace_floats        # ... and left no trace for the next plan
+    with pytest.raises(KeyError):
+        Plan(cfg, 2, 40, lib=lib, tuning={"conv_rs": 1})
