@@ -81,27 +81,39 @@ static __device__ __forceinline__ void conv_bare_barrier() {
 #endif
 }
 
-template <int WM, int MIR>
-static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4& bv, const float* Ap, const float* Xp, int cb4, int cbl4, int cbr4) {
+template <int WM, int WN, int MIR>
+static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4 (&bv)[WN], const float* Ap, const float* Xp, const int (&cb4)[WN],
+                                                      const int (&cbl4)[WN], const int (&cbr4)[WN]) {
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) av[wm] = *(const f32x4*)(Ap + wm * 128);
-    f32x4 v = *(const f32x4*)(Xp + cb4);
-    if (MIR >= 1) v += *(const f32x4*)(Xp + cbl4);
-    if (MIR == 2) v += *(const f32x4*)(Xp + cbr4);
-    bv = v;
-}
-template <int WM, bool BF>
-static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM], const f32x4 (&av)[WM], const f32x4& bv) {
-    if constexpr (BF) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
-        const avc_s16x4 bp = avc_pack_bf16x4(bv[0], bv[1], bv[2], bv[3]);
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) acc[wm] = avc_mfma_bf16(avc_pack_bf16x4(av[wm][0], av[wm][1], av[wm][2], av[wm][3]), bp, acc[wm]);
+    for (int wn = 0; wn < WN; ++wn) {
+        f32x4 v = *(const f32x4*)(Xp + cb4[wn]);
+        if (MIR >= 1) v += *(const f32x4*)(Xp + cbl4[wn]);
+        if (MIR == 2) v += *(const f32x4*)(Xp + cbr4[wn]);
+        bv[wn] = v;
+    }
+}
+template <int WM, int WN, bool BF>
+static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const f32x4 (&av)[WM], const f32x4 (&bv)[WN]) {
+    if constexpr (BF) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
+        avc_s16x4 bp[WN];
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) bp[wn] = avc_pack_bf16x4(bv[wn][0], bv[wn][1], bv[wn][2], bv[wn][3]);
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const avc_s16x4 ap = avc_pack_bf16x4(av[wm][0], av[wm][1], av[wm][2], av[wm][3]);
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) acc[wm][wn] = avc_mfma_bf16(ap, bp[wn], acc[wm][wn]);
+        }
         return;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) acc[wm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm][u], bv[u], acc[wm], 0, 0, 0);
+        for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm][u], bv[wn][u], acc[wm][wn], 0, 0, 0);
 }
 
 // KSC > 0: tap count and chunk depth are compile-time (GRC = CK/8), the chunk is one straight-line
@@ -109,14 +121,14 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM], const f3
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
 // TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
 // taps of a column meet the zeros of the zero-upsampled dy)
-template <int WM, int MIR, int KSC, int GRC, bool BF, int TS = 0>
-static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
-                                                      int a_lane4, int cb4, int cbl4, int cbr4) {
+template <int WM, int WN, int MIR, int KSC, int GRC, bool BF, int TS = 0>
+static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
+                                                      int a_lane4, const int (&cb4)[WN], const int (&cbl4)[WN], const int (&cbr4)[WN]) {
     constexpr int BM4 = 64 * WM * 4;   // floats of one (tap, unit, h) plane of the A stage
     if constexpr (KSC > 0) {
         constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
         constexpr int U = NTAP * GRC;
-        f32x4 av[2][WM], bv[2];
+        f32x4 av[2][WM], bv[2][WN];
         auto unit_ptrs = [&](int u, const float*& Ap, const float*& Xp) {
             const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g8 = u % GRC;
             Ap = Ab + ((tap * GRC + g8) * 2 + h) * BM4 + a_lane4;
@@ -124,14 +136,14 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
         };
         const float *Ap, *Xp;
         unit_ptrs(0, Ap, Xp);
-        conv_load_unit<WM, MIR>(av[0], bv[0], Ap, Xp, cb4, cbl4, cbr4);
+        conv_load_unit<WM, WN, MIR>(av[0], bv[0], Ap, Xp, cb4, cbl4, cbr4);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u + 1 < U) {
                 unit_ptrs(u + 1, Ap, Xp);
-                conv_load_unit<WM, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
+                conv_load_unit<WM, WN, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
             }
-            conv_mma_unit<WM, BF>(acc, av[u & 1], bv[u & 1]);
+            conv_mma_unit<WM, WN, BF>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
         const int groups = CK >> 3;
@@ -139,9 +151,9 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
             const float* Ap = Ab + (tap * groups * 2 + h) * BM4 + a_lane4;
             const float* Xp = Xb + (h * ROW + tap) * 4;
             for (int g8 = 0; g8 < groups; ++g8) {
-                f32x4 av[WM], bv;
-                conv_load_unit<WM, MIR>(av, bv, Ap, Xp, cb4, cbl4, cbr4);
-                conv_mma_unit<WM, BF>(acc, av, bv);
+                f32x4 av[WM], bv[WN];
+                conv_load_unit<WM, WN, MIR>(av, bv, Ap, Xp, cb4, cbl4, cbr4);
+                conv_mma_unit<WM, WN, BF>(acc, av, bv);
                 Ap += 2 * BM4;
                 Xp += 2 * ROW * 4;
             }
@@ -155,9 +167,11 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM], const f
 // summed through LDS in a fixed order at the end (deterministic).
 // RAG (forward only): ragged launch -- the tile's sample, first column and the sample's own lengths / packed-buffer bases come
 // from the ConvRag tables; everything else is the uniform kernel with one sample per tile.
-template <int WM, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false, bool RAG = false>
+// WN = 2 (64 x 128 and 128 x 128 tiles; uniform stride-1 launches): two 32-column fragments per wave share every weight fragment --
+// the weight image is 80 % of a chunk's LDS-DMA bytes and it is re-read by every column tile (section 3.1 of DESIGN.md).
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false, bool RAG = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
-    constexpr int BM = 64 * WM, BN = 64;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvGroup g = a.g[blockIdx.z];
@@ -247,14 +261,15 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     // the X stages start as zeros; structural zeros are never overwritten afterwards
     for (int e = tid; e < KG * NS * XS; e += NTHREADS) smem[KG * NS * AS + e] = 0.f;
 
-    // ---- this lane's column (float index of its position inside an X plane = 4 x position)
-    int cb4, cbl4, cbr4, colb, colt;
-    bool colv;
-    {
-        int n = wave_n * 32 + li;
+    // ---- this lane's columns (float index of a position inside an X plane = 4 x position)
+    int cb4[WN], cbl4[WN], cbr4[WN], colb[WN], colt[WN];
+    bool colv[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        int n = wave_n * (32 * WN) + wn * 32 + li;
         int bl, t;
         bool v;
-        if (PAR) {   // wave_n = parity of the wave's columns, li = slot inside the parity class
+        if (PAR) {   // (WN == 1) wave_n = parity of the wave's columns, li = slot inside the parity class
             if (Tout >= BN) {
                 bl = 0;
                 t = q.t0 + 2 * li + wave_n;
@@ -274,9 +289,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             t = n - bl * Tout;
             v = (bl < q.SPT) && (q.b0 + bl < Bv);
         }
-        colb = q.b0 + bl;
-        colt = t;
-        colv = v;
+        colb[wn] = q.b0 + bl;
+        colt[wn] = t;
+        colv[wn] = v;
         int base = q.ROWDATA, bL = q.ROWDATA, bR = q.ROWDATA;
         if (v) {
             if (a.mode == 0) {
@@ -289,16 +304,18 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
                 }
             }
         }
-        cb4 = 4 * base;
-        cbl4 = 4 * bL;
-        cbr4 = 4 * bR;
+        cb4[wn] = 4 * base;
+        cbl4[wn] = 4 * bL;
+        cbr4[wn] = 4 * bR;
     }
 
-    f32x16 acc[WM];
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[wm][r] = 0.f;
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
     const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
     const int nj = (ROW + 15) >> 4;
@@ -307,8 +324,12 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     bool use_mirror = false;
     const bool one_window = Tout >= 2 * (padL + padR) + 2;   // left-edge columns [1, padL] and right-edge columns [Tout-1-padR, Tout-2] are disjoint
     if (MIRROR) {
-        const bool mine = (cbl4 != 4 * q.ROWDATA) || (cbr4 != 4 * q.ROWDATA);
-        if (one_window && cbl4 == 4 * q.ROWDATA) cbl4 = cbr4;   // the column's only mirror window
+        bool mine = false;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            mine |= (cbl4[wn] != 4 * q.ROWDATA) || (cbr4[wn] != 4 * q.ROWDATA);
+            if (one_window && cbl4[wn] == 4 * q.ROWDATA) cbl4[wn] = cbr4[wn];   // the column's only mirror window
+        }
         use_mirror = __any(mine);
     }
 
@@ -390,34 +411,34 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         if ((a.dbg & 2) || chunk >= nchunk) {
         } else if constexpr (PAR) {   // even columns: taps 0, 2, 4; odd columns: taps 1, 3 (k = 5, padL = 2)
             if (wave_n == 0) {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 1>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             } else {
-                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else if (MIRROR && use_mirror) conv_chunk_mma<WM, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-                else conv_chunk_mma<WM, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                if (MIRROR && use_mirror && one_window) conv_chunk_mma<WM, WN, 1, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else if (MIRROR && use_mirror) conv_chunk_mma<WM, WN, 2, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                else conv_chunk_mma<WM, WN, 0, KSC, GRC, BF, 2>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else if (MIRROR && use_mirror && one_window)   // wave-uniform: only waves owning a column within pad of a sample edge
-            conv_chunk_mma<WM, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, WN, 1, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if (MIRROR && use_mirror)
-            conv_chunk_mma<WM, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, WN, 2, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         else if constexpr (KSC < 0) {
             // grouped launch of layers with different tap counts (the conv bank, k = 1..8): the workgroup's (taps,
             // chunk depth) pair is uniform, so each pair gets its own straight-line chunk
             switch (KS * 8 + GR) {
-                case 1 * 8 + 4: conv_chunk_mma<WM, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 2 * 8 + 2: conv_chunk_mma<WM, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 3 * 8 + 2: conv_chunk_mma<WM, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 4 * 8 + 1: conv_chunk_mma<WM, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 5 * 8 + 1: conv_chunk_mma<WM, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 6 * 8 + 1: conv_chunk_mma<WM, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 7 * 8 + 1: conv_chunk_mma<WM, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                case 8 * 8 + 1: conv_chunk_mma<WM, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
-                default: conv_chunk_mma<WM, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+                case 1 * 8 + 4: conv_chunk_mma<WM, WN, 0, 1, 4, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 2 * 8 + 2: conv_chunk_mma<WM, WN, 0, 2, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 3 * 8 + 2: conv_chunk_mma<WM, WN, 0, 3, 2, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 4 * 8 + 1: conv_chunk_mma<WM, WN, 0, 4, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 5 * 8 + 1: conv_chunk_mma<WM, WN, 0, 5, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 6 * 8 + 1: conv_chunk_mma<WM, WN, 0, 6, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 7 * 8 + 1: conv_chunk_mma<WM, WN, 0, 7, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                case 8 * 8 + 1: conv_chunk_mma<WM, WN, 0, 8, 1, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4); break;
+                default: conv_chunk_mma<WM, WN, 0, 0, 0, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
             }
         } else
-            conv_chunk_mma<WM, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
+            conv_chunk_mma<WM, WN, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
         if (!(a.dbg & 4)) {
             conv_wait_dma(issued);   // everything but the DMA instructions issued in THIS iteration has landed
             conv_bare_barrier();
@@ -426,30 +447,37 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     }
 
     if (KG > 1) {  // fixed-order sum of the groups' partial tiles through the (now free) stage memory
-        float* red = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (WM * 16 * 64) + lane;
+        float* red = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (WM * WN * 16 * 64) + lane;
         if (kg > 0) {
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(wm * 16 + r) * 64] = acc[wm][r];
+                for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wm * WN + wn) * 16 + r) * 64] = acc[wm][wn][r];
         }
         __syncthreads();
         if (kg > 0) return;
 #pragma unroll
         for (int k2 = 1; k2 < KG; ++k2) {
-            const float* rk = smem + ((k2 - 1) * 4 + wave) * (WM * 16 * 64) + lane;
+            const float* rk = smem + ((k2 - 1) * 4 + wave) * (WM * WN * 16 * 64) + lane;
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[wm][r] += rk[(wm * 16 + r) * 64];
+                for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[wm][wn][r] += rk[((wm * WN + wn) * 16 + r) * 64];
         }
     }
 
     // ---- epilogue
     if (a.dbg & 8) return;
-    if (!colv) return;
 #pragma unroll
-    for (int wm = 0; wm < WM; ++wm) conv_store_frag(epi, g, acc[wm], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb, colt);
+    for (int wn = 0; wn < WN; ++wn) {
+        if (!colv[wn]) continue;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) conv_store_frag(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -594,32 +622,39 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
 // ragged forward launches (inference): the straight-line instances the model uses + the generic one
 template <int WM, bool BF>
 static void conv_launch_rag(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 1, 1, BF, false, true>), grid, block, lds, stream, a);
-    else if (fast == -1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, -1, 0, 1, BF, false, true>), grid, block, lds, stream, a);
-    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 1, 4, 1, BF, false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 0, 0, 1, BF, false, true>), grid, block, lds, stream, a);
+    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 5, 1, 1, BF, false, true>), grid, block, lds, stream, a);
+    else if (fast == -1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, -1, 0, 1, BF, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 1, 4, 1, BF, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 0, 0, 1, BF, false, true>), grid, block, lds, stream, a);
 }
 
 template <int WM, int KG, bool BF>
 static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
-    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
-    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM, true, 0, 0, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
-    else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
-    else if (fast == -1 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, -1, 0, 1, BF>), grid, block, lds, stream, a);
-    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 1, 4, KG, BF>), grid, block, lds, stream, a);   // 1x1, 32-channel chunks
-    else hipLaunchKernelGGL((conv_gemm_kernel<WM, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, true, 0, 0, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 5, 1, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 5, 2, KG, BF>), grid, block, lds, stream, a);
+    else if (fast == 4 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 5, 4, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == -1 && KG == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, -1, 0, 1, BF>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 1, 4, KG, BF>), grid, block, lds, stream, a);   // 1x1, 32-channel chunks
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
+}
+
+// 64 x 128 tiles (WN = 2): the k = 5 straight-line chunk, forward and mirrored input gradient
+template <bool BF>
+static void conv_launch_wide(const ConvArgs& a, bool mir, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, true, 5, 1, 1, BF>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 2, false, 5, 1, 1, BF>), grid, block, lds, stream, a);
 }
 
 // stride-2 dgrad with one column parity per wave (half the MFMAs of the zero-upsampled correlation)
 template <int KG, bool BF>
 static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, true, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
-    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, true, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
-    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
+    if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
+    else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
 }
 
 // returns 0 on success, negative on unsupported geometry
@@ -632,11 +667,20 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     if (a.x.ps != 1 && a.x.ps != 2) return -2;   // (pixel-unshuffled dy views of the decoder: upsample factors are 1 or 2)
     for (int gi = 0; gi < a.ngroups; ++gi)
         if (a.mode == 0 && (a.g[gi].padL >= a.Tsrc || a.g[gi].padR >= a.Tsrc)) return -6;  // reference: "Padding size should be less than ..."
-    int tile = (force_tile == 12 || force_tile == 22) ? 21 : force_tile;  // (64x128 / 128x128 tiles were measured no better and dropped)
+    int tile = force_tile == 22 ? 21 : force_tile;  // (the 128x128 tile was measured no better and dropped)
     if (tile == 98) return -8;   // (round 2's one-shot short-row kernel; gone)
-    if (tile == 0) tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
-    if (tile != 11 && tile != 21) return -2;
-    const int BM = (tile == 11) ? 64 : 128, BN = 64;
+    const bool wide_ok = a.ngroups == 1 && a.g[0].KS == 5 && a.g[0].CK == 8 && a.stride == 1 && a.Tout >= 64 && !a.rag.tile && a.x.ps == 1;
+    if (tile == 0) {
+        tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
+        // 64 x 128: half the weight-image traffic per column; only while the launch keeps the chip full
+        if (tile == 11 && wide_ok && tun.tile12_wgs > 0) {
+            const long ntn = a.Tout >= 128 ? (long)a.B * avc_cdiv(a.Tout, 128) : (long)avc_cdiv(a.B, 128 / a.Tout);
+            if ((long)(a.Mp / 64) * ntn >= tun.tile12_wgs) tile = 12;
+        }
+    }
+    if (tile == 12 && !wide_ok) return -2;
+    if (tile != 11 && tile != 21 && tile != 12) return -2;
+    const int BM = (tile == 21) ? 128 : 64, BN = (tile == 12) ? 128 : 64;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         if (a.g[gi].CK % 8 != 0) return -2;
@@ -676,6 +720,8 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     } else if (a.par) {
         if (kgroups == 2) { if (bf) conv_launch_par<2, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<2, false>(a, mir, fast, grid, block, lds, stream); }
         else { if (bf) conv_launch_par<1, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<1, false>(a, mir, fast, grid, block, lds, stream); }
+    } else if (tile == 12) {
+        if (bf) conv_launch_wide<true>(a, mir, grid, block, lds, stream); else conv_launch_wide<false>(a, mir, grid, block, lds, stream);
     } else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
     else if (kgroups == 2) AVC_LAUNCH_CONV(1, 2);
     else AVC_LAUNCH_CONV(1, 1);

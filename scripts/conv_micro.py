@@ -88,8 +88,10 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s2":
 
 if __name__ == "__main__" and len(sys.argv) > 0 and sys.argv[0] != "x":
     B = 256
-    run(B, 128, 128, 128, 5, 1, tiles=(21, 11))
-    run(B, 128, 128, 64, 5, 1, tiles=(21, 11))
+    run(B, 128, 128, 128, 5, 1, tiles=(21, 11, 12))
+    run(B, 128, 128, 64, 5, 1, tiles=(21, 11, 12))
+    run(1024, 128, 128, 128, 5, 1, tiles=(21, 11, 12), which="fd")
+    run(1024, 128, 128, 64, 5, 1, tiles=(21, 11, 12), which="fd")
     run(B, 128, 128, 32, 5, 1, tiles=(11,))
     run(B, 128, 128, 16, 5, 1, tiles=(11,))
     run(B, 128, 128, 128, 5, 2, tiles=(21, 11))

@@ -54,6 +54,8 @@ FWD = [
     (1, 40, 32, 33, 1, 1, 11),    # 1x1
     (2, 16, 130, 64, 3, 1, 21),   # 128x64 tile, 2 M tiles
     (1, 16, 128, 130, 5, 1, 21),  # 128-row tile, three column tiles, ragged last one
+    (1, 16, 64, 200, 5, 1, 12),   # 64 x 128 tile (two column fragments per wave), ragged second tile
+    (3, 24, 40, 64, 5, 1, 12),    # ... two whole samples per tile, odd batch
     (2, 20, 32, 32, 5, 1, 11),    # reduction channels not a multiple of 8: the last 8-channel unit straddles Cin
     (2, 44, 32, 24, 3, 1, 11),    # ... with 16-channel chunks: a whole padded unit + a straddling one
     (5, 16, 32, 3, 5, 1, 11),     # bottleneck-sized rows
@@ -63,6 +65,7 @@ FWD = [
     (5, 128, 40, 16, 5, 1, 0),    # short rows, launcher's own choice of tile / chunk depth / split-K groups
     (9, 128, 128, 32, 5, 1, 0),
     pytest.param(8, 128, 128, 128, 5, 1, 0, marks=GPU),
+    pytest.param(8, 128, 128, 128, 5, 1, 12, marks=GPU),
     pytest.param(8, 128, 128, 128, 5, 2, 0, marks=GPU),
     pytest.param(8, 128, 256, 64, 5, 1, 0, marks=GPU),
     pytest.param(64, 128, 128, 16, 5, 1, 0, marks=GPU),
@@ -126,6 +129,8 @@ DG = [
     (5, 16, 32, 3, 5, 1, 11),
     (1, 16, 128, 130, 5, 1, 21),
     (2, 16, 32, 66, 5, 1, 21),
+    (1, 16, 32, 200, 5, 1, 12),   # 64 x 128 tile: mirror windows in both column fragments
+    (3, 16, 32, 64, 5, 1, 12),
     (2, 20, 32, 32, 5, 1, 11),    # reduction channels (Cout here) not a multiple of 8
     (5, 40, 128, 16, 5, 1, 0),    # mirror windows of 4 samples per tile
     (3, 16, 32, 32, 5, 2, 11),    # stride 2 with one column parity per wave (even taps / odd taps): two samples per tile
