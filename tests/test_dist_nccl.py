@@ -63,7 +63,8 @@ def test_two_rank_nccl_step_equals_global_batch_step(tmp_path):
     params, metas = _single(8, 2)
     assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
     diff = (params - r0["params"]).abs()
-    assert (diff > 2e-6).float().mean().item() < 5e-3
+    assert diff.max().item() < 4 * 5e-4 * 2                      # (see the gloo variant below: kink flips in step 2)
+    assert (diff > 2e-6).float().mean().item() < 5e-2
 
 
 @pytest.mark.gpu
@@ -81,6 +82,12 @@ def test_two_ranks_on_one_gpu_over_gloo_equal_the_global_batch_step(tmp_path):
     params, metas = _single(8, 2)
     assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
     diff = (params - r0["params"]).abs()
-    assert (diff > 2e-6).float().mean().item() < 5e-3
+    # Two steps from the same init: the shards are summed in another order than the global batch, so an activation that sits
+    # on its kink can take the other branch in step 2 (tests/test_engine.py::branch_matched_oracle) -- that moves every element
+    # of the tensors behind it by ~1e-2 relative, i.e. a few 1e-6 after the lr-scaled update (measured: 0.1 % ... 1.5 % of the
+    # 4.9 M parameters differ by more than 2e-6, depending on the run).  What must hold: no element moved by more than two
+    # sign-flipped Adam updates, and the bulk agrees.
+    assert diff.max().item() < 4 * 5e-4 * 2
+    assert (diff > 2e-6).float().mean().item() < 5e-2
     sd = torch.load(tmp_path / "ckpt.ckpt", map_location="cpu")
     assert len(sd) == 166 and not list(tmp_path.glob("*.tmp.*"))

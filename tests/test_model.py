@@ -42,9 +42,16 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         AE(cfg, lib=lib)
     cfg = O.tiny_config()
-    cfg["ContentEncoder"]["act"] = "lrelu"
+    cfg["ContentEncoder"]["act"] = "gelu"        # get_act (model.py:93-99) knows 'relu' and 'lrelu' only
     with pytest.raises(NotImplementedError):
         AE(cfg, lib=lib)
+    cfg = O.tiny_config()
+    cfg["ContentEncoder"]["dropout_rate"] = 0.1
+    with pytest.raises(NotImplementedError):
+        AE(cfg, lib=lib)
+    cfg = O.tiny_config()
+    cfg["ContentEncoder"]["act"] = "lrelu"       # implemented since round 3
+    AE(cfg, lib=lib)
 
 
 @pytest.mark.parametrize("kind", KINDS)
