@@ -12,7 +12,7 @@ _lib = None
 
 MAX_BLOCKS = 8
 PLAN_INFERENCE, PLAN_SPEAKER_ONLY = 1, 2
-GRADS_ALL, GRADS_DECODER, GRADS_ENCODERS = 0, 1, 2
+GRADS_ALL, GRADS_DECODER, GRADS_ENCODERS, GRADS_SPEAKER, GRADS_CONTENT = 0, 1, 2, 3, 4
 
 
 class EncoderCfg(ctypes.Structure):

@@ -119,6 +119,7 @@ struct avc_plan {
     mutable hipEvent_t wjoin[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_pack[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_dec_grads = nullptr;   // recorded when the decoder's parameter gradients are final
+    mutable hipEvent_t ev_spk_grads = nullptr;   // ... the speaker encoder's
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
     int flags = 0;            // AVC_PLAN_*
@@ -134,6 +135,7 @@ struct avc_plan {
     avc_tuning tun;           // launch heuristics / diagnostic switches, captured at plan creation (the dry run sizes slabs and events with them)
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
+    long enc_param_off = 0;   // first float of the content encoder's (the speaker encoder's are the head)
 
     long alloc(long n) {
         long o = ws_top;
@@ -285,6 +287,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
 
     // ---- parameters in reference registration order
     build_enc_params(p, p->spk, cfg->spk, true);
+    p->enc_param_off = p->param_floats;
     build_enc_params(p, p->enc, cfg->enc, false);
     DecNet& d = p->dec;
     d.c = dc;
@@ -549,6 +552,7 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
     for (hipEvent_t e : p->wev)
         if (e) hipEventDestroy(e);
     if (p->ev_dec_grads) hipEventDestroy(p->ev_dec_grads);
+    if (p->ev_spk_grads) hipEventDestroy(p->ev_spk_grads);
     if (p->ev_all_grads) hipEventDestroy(p->ev_all_grads);
     delete p;
 }
@@ -577,6 +581,7 @@ static void plan_init_streams(avc_plan* p) {
     bool ok = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_dec_grads, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_spk_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
@@ -632,6 +637,12 @@ extern "C" int avc_plan_param_range(const avc_plan* p, int part, long* offset, l
     } else if (part == AVC_GRADS_ENCODERS) {
         *offset = 0;
         *numel = p->dec_param_off;
+    } else if (part == AVC_GRADS_SPEAKER) {
+        *offset = 0;
+        *numel = p->enc_param_off;
+    } else if (part == AVC_GRADS_CONTENT) {
+        *offset = p->enc_param_off;
+        *numel = p->dec_param_off - p->enc_param_off;
     } else if (part == AVC_GRADS_ALL) {
         *offset = 0;
         *numel = p->param_floats;
@@ -646,7 +657,7 @@ extern "C" int avc_plan_param_range(const avc_plan* p, int part, long* offset, l
 extern "C" int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream) {
     if (!p || (p->flags & AVC_PLAN_INFERENCE)) return fail(-1, "avc_plan_stream_wait_grads: not a training plan");
     if (p->side_state != 1) return fail(-9, "avc_plan_stream_wait_grads: the plan has no helper streams / events (order on the stream avc_backward ran on)");
-    hipEvent_t e = (part == AVC_GRADS_DECODER) ? p->ev_dec_grads : p->ev_all_grads;
+    hipEvent_t e = (part == AVC_GRADS_DECODER) ? p->ev_dec_grads : (part == AVC_GRADS_SPEAKER ? p->ev_spk_grads : p->ev_all_grads);
     return (int)hipStreamWaitEvent((hipStream_t)stream, e, 0);
 }
 extern "C" int avc_plan_out_len(const avc_plan* p) { return p->Tout; }
@@ -1368,6 +1379,9 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
         RUN(flush_wgrads(c));
+        // the speaker encoder's gradients (head of the flat buffer) are final once its wgrad stream drains: a data-parallel caller
+        // reduces them under the content encoder's longer branch (avc_plan_stream_wait_grads(AVC_GRADS_SPEAKER))
+        if (!dry && p->side_state == 1) hipEventRecord(p->ev_spk_grads, c.wstream);
         c.s = mainS;
         c.wstream = overlap ? p->wstream[0] : mainS;
     }
@@ -1495,6 +1509,7 @@ extern "C" int avc_plan_create_ragged(const avc_model_cfg* cfg, int B, const int
         p->Tc = T_cond[b] > p->Tc ? T_cond[b] : p->Tc;
     }
     build_enc_params(p, p->spk, cfg->spk, true);
+    p->enc_param_off = p->param_floats;
     build_enc_params(p, p->enc, cfg->enc, false);
     DecNet& d = p->dec;
     d.c = dc;

@@ -130,9 +130,9 @@ class Solver(object):
 
     def _allreduce_grads(self, d, plan, grads):
         """SUM over ranks of the flat gradient buffer (RCCL over xGMI when the backend is "nccl"); the 1/W of the
-        mean is folded into the optimizer kernel.  The decoder's range -- final long before the encoders'
-        (avc_backward walks decoder -> encoders) -- is reduced on a communication stream under the rest of the
-        backward pass; the encoders' range follows on the same stream once the whole backward is done."""
+        mean is folded into the optimizer kernel.  Three buckets in the order avc_backward finishes them: the decoder's range
+        and the speaker encoder's range are reduced on a communication stream under the rest of the backward pass
+        (avc_plan_stream_wait_grads), the content encoder's range once the whole backward is done."""
         from . import _lib
         # compute_dtype bf16 (BASELINE configs[2]: "bf16 compute, fp32 master and optimizer state"): the bucket travels as
         # bf16 too -- 9.8 MB instead of 19.6 MB per step over xGMI (SURVEY §8e); `allreduce_dtype: fp32` in the config keeps
@@ -147,26 +147,30 @@ class Solver(object):
             wire.copy_(seg)            # persistent bf16 bucket: no per-step allocation
             d.all_reduce(wire)
             seg.copy_(wire)
-        (do, dn), (eo, en) = plan.param_range(_lib.GRADS_DECODER), plan.param_range(_lib.GRADS_ENCODERS)
-        wd = we = None
+        parts = [plan.param_range(k) for k in (_lib.GRADS_DECODER, _lib.GRADS_SPEAKER, _lib.GRADS_CONTENT)]
+        wires = [None, None, None]
         if wire_bf16:
             if self._wire is None or self._wire.device != grads.device or self._wire.numel() != grads.numel():
                 self._wire = torch.empty(grads.numel(), dtype=torch.bfloat16, device=grads.device)
-            wd, we = self._wire[do:do + dn], self._wire[eo:eo + en]
+            wires = [self._wire[o:o + n] for o, n in parts]
         if not grads.is_cuda:
-            reduce(grads[do:do + dn], wd)
-            reduce(grads[eo:eo + en], we)
+            for (o, n), w in zip(parts, wires):
+                reduce(grads[o:o + n], w)
             return
         if self._comm_stream is None or self._comm_stream.device != grads.device:
             self._comm_stream = torch.cuda.Stream(device=grads.device)
         cs, main = self._comm_stream, torch.cuda.current_stream(grads.device)
-        if not plan.stream_wait_grads(_lib.GRADS_DECODER, cs):
-            cs.wait_stream(main)                   # a plan without helper streams / events: order behind the whole backward
-        with torch.cuda.stream(cs):
-            reduce(grads[do:do + dn], wd)
+        # Three buckets in the order the backward pass finishes them (avc_backward: decoder -> speaker encoder's branch -> content
+        # encoder's longer branch): the first two are reduced on the communication stream UNDER the rest of the backward, only the
+        # content encoder's 7 MB start after it.
+        for k, ((o, n), w) in zip((_lib.GRADS_DECODER, _lib.GRADS_SPEAKER), zip(parts[:2], wires[:2])):
+            if not plan.stream_wait_grads(k, cs):
+                cs.wait_stream(main)               # a plan without helper streams / events: order behind the whole backward
+            with torch.cuda.stream(cs):
+                reduce(grads[o:o + n], w)
         cs.wait_stream(main)                       # the whole backward (avc_backward joins its helper streams into main)
         with torch.cuda.stream(cs):
-            reduce(grads[eo:eo + en], we)
+            reduce(grads[parts[2][0]:parts[2][0] + parts[2][1]], wires[2])
         main.wait_stream(cs)
 
     def ae_step(self, data, lambda_kl, eps=None, sync=True):

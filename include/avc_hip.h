@@ -115,6 +115,8 @@ int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
 #define AVC_GRADS_ALL 0
 #define AVC_GRADS_DECODER 1
 #define AVC_GRADS_ENCODERS 2
+#define AVC_GRADS_SPEAKER 3   /* the speaker encoder's parameters (head of the flat buffer): final when its branch of the backward ends, */
+#define AVC_GRADS_CONTENT 4   /* ... well before the content encoder's (the longer branch, InstanceNorm kernels in its chain) */
 int avc_plan_param_range(const avc_plan* p, int part, long* offset, long* numel);
 int avc_plan_stream_wait_grads(const avc_plan* p, int part, void* stream);
 
