@@ -125,6 +125,12 @@ def declare(lib):
                                      c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_instnorm_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int,
                                      c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]
+    # bf16 pair rows
+    lib.avc_instnorm_fwd_pairs.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_instnorm_bwd_pairs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_long, c_int, c_void_p]
+    lib.avc_to_pairs.argtypes = [c_void_p, c_long, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p]
     # mel <-> waveform DSP
     lib.avc_dsp_num_frames.argtypes = [c_long, c_int]
     lib.avc_dsp_basis_floats.argtypes = [c_int, c_int, c_int]

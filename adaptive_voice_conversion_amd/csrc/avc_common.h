@@ -18,6 +18,8 @@ enum {
     AVC_COMPUTE_BF16 = 1,  // operands rounded to bf16 (RNE) at fragment time, fp32 accumulate: v_mfma_f32_32x32x8_bf16
     AVC_COMPUTE_F32X3 = 2, // (weight-gradient launches) every operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product
                            // block: fp32-level accuracy (conv_x3_shared.h); instances it is not built for run AVC_COMPUTE_F32
+    AVC_COMPUTE_BF16S = 3, // bf16 STORAGE (bf16_pairs.h): operand tensors are bf16 channel pairs [B][C/2][T] in HBM and LDS, weight images
+                           // bf16 pairs (AVC_IMG_K4H), v_mfma_f32_32x32x16_bf16, fp32 accumulate
 };
 
 // ---- residual / gradient-join modes used by conv epilogues and row kernels
@@ -36,6 +38,8 @@ enum {
     AVC_IMG_X3 = 2,     // split-bf16 image of conv_x3.hip
     AVC_IMG_K4 = 3,     // [chunk][tap][unit][h][Mp][u]: reduction channel = chunk CK + 8 unit + 2 u + h; the four k-steps u of a lane are
                         // 16 contiguous bytes (one ds_read_b128 per four MFMAs) -- conv_gemm.hip
+    AVC_IMG_K4H = 4,    // the same image over DWORD channels of bf16 pairs: dword (.., m, u) = bf16 weights of reduction channels 2 dc, 2 dc + 1,
+                        // dc = chunk CK + 8 unit + 2 u + h: a lane's 16 bytes are its 8 k-values of one v_mfma_f32_32x32x16_bf16
 };
 
 struct ConvSrc {
@@ -93,6 +97,8 @@ struct ConvArgs {
     int bf16; // AVC_COMPUTE_*
     ConvRag rag;
     int img;  // weight image g[0].wp points at: AVC_IMG_K4 (conv_gemm.hip) or AVC_IMG_X3 (conv_x3.hip)
+    int pairs; // outputs / residual / mask are bf16 pair tensors (bf16_pairs.h; strides in dwords).  0 with AVC_COMPUTE_BF16S: fp32 outputs
+               // from bf16 operands (the heads, the decoder's last conv)
     int par;  // stride-2 dgrad: columns of one parity per wave, each wave multiplies only the taps that meet non-zero
               // positions of the zero-upsampled dy (set by the launcher)
     ConvGroup g[AVC_MAX_GROUPS];
@@ -160,6 +166,7 @@ struct INFwdArgs {
     int res_mode, Tres;
     int R, C, T, relu;
     float slope;
+    int planar;         // pair kernels (rowops_pairs.hip): y rows are natural bf16 rows (the output of a pixel-shuffling conv)
 };
 
 // ragged InstanceNorm forward (ragged_rows.hip): packed [C][T_b] blocks, see ConvRag
@@ -193,6 +200,7 @@ struct INBwdArgs {
     int dcond_off;
     int R, C, T, relu;
     float slope;
+    int planar;       // pair kernels: y and dy rows are natural bf16 rows
 };
 
 struct AdamArgs {

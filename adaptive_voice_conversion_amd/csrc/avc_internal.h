@@ -56,6 +56,13 @@ int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* 
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);
+// bf16 pair rows (rowops_pairs.hip): a.R = B * C / 2 dword rows
+int avc_launch_in_fwd_pairs(const INFwdArgs& a, hipStream_t s);
+int avc_launch_in_bwd_pairs(const INBwdArgs& a, hipStream_t s);
+int avc_launch_to_pairs(const float* x, long sxb, long sxc, long sxt, int B, int C, int T, float* dst, long db, long dc, hipStream_t s);
+int avc_launch_reparam_fwd_pairs(const float* muls, const float* eps, int B, int C, int Tb, float* z, hipStream_t s);
+int avc_launch_timepool_fwd_pairs(const float* in, int B, int C, int T, float* out, hipStream_t s);
+int avc_launch_timepool_bwd_pairs(const float* dP, const float* amask, int B, int C, int T, float* G, float* dy, float slope, hipStream_t s);
 int avc_launch_rag_in_fwd(const RagINArgs& a, hipStream_t s);
 int avc_launch_rag_copy_rows(const float* x, long xsc, long xst, const int* T, const int* off, int B, int M, int sumT, float* dst, int CC, int c0,
                              hipStream_t s);

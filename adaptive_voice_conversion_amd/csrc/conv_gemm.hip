@@ -81,22 +81,50 @@ static __device__ __forceinline__ void conv_bare_barrier() {
 #endif
 }
 
-template <int WM, int WN, int MIR>
-static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4 (&bv)[WN], const float* Ap, const float* Xp, const int (&cb4)[WN],
-                                                      const int (&cbl4)[WN], const int (&cbr4)[WN]) {
+// BF: 0 = exact fp32, 1 = fp32 storage with operands rounded to bf16 here, 2 = bf16 PAIR storage (bf16_pairs.h): the 16 bytes a lane
+// reads ARE its 8 k-values of one v_mfma_f32_32x32x16_bf16 (dword u = the bf16 pair of reduction channels 2 dc, 2 dc + 1, dc = 8 unit +
+// 2 u + h).  The reflect-adjoint windows of the input gradient cannot be summed as packed pairs, so with BF == 2 each active window is
+// one more MFMA against the same weight fragment (NW operand slots per column fragment).
+template <int MIR, int BF>
+struct ConvNW {
+    static constexpr int value = (BF == 2) ? 1 + MIR : 1;
+};
+template <int WM, int WN, int MIR, int BF, int NB>   // NB = WN * NW (deduced)
+static __device__ __forceinline__ void conv_load_unit(f32x4 (&av)[WM], f32x4 (&bv)[NB], const float* Ap, const float* Xp,
+                                                      const int (&cb4)[WN], const int (&cbl4)[WN], const int (&cbr4)[WN]) {
+    constexpr int NW = ConvNW<MIR, BF>::value;
+    static_assert(NB == WN * NW, "operand slots");
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) av[wm] = *(const f32x4*)(Ap + wm * 128);
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         f32x4 v = *(const f32x4*)(Xp + cb4[wn]);
-        if (MIR >= 1) v += *(const f32x4*)(Xp + cbl4[wn]);
-        if (MIR == 2) v += *(const f32x4*)(Xp + cbr4[wn]);
-        bv[wn] = v;
+        if constexpr (BF == 2) {
+            bv[wn * NW] = v;
+            if (MIR >= 1) bv[wn * NW + 1] = *(const f32x4*)(Xp + cbl4[wn]);
+            if (MIR == 2) bv[wn * NW + 2] = *(const f32x4*)(Xp + cbr4[wn]);
+        } else {
+            if (MIR >= 1) v += *(const f32x4*)(Xp + cbl4[wn]);
+            if (MIR == 2) v += *(const f32x4*)(Xp + cbr4[wn]);
+            bv[wn] = v;
+        }
     }
 }
-template <int WM, int WN, bool BF>
-static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const f32x4 (&av)[WM], const f32x4 (&bv)[WN]) {
-    if constexpr (BF) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
+template <int WM, int WN, int BF, int NW, int NB>
+static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], const f32x4 (&av)[WM], const f32x4 (&bv)[NB]) {
+    static_assert(NB == WN * NW, "operand slots");
+    if constexpr (BF == 2) {
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const avc_u32x4 ap = __builtin_bit_cast(avc_u32x4, av[wm]);
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc[wm][wn] = avc_mfma_bf16x8(ap, __builtin_bit_cast(avc_u32x4, bv[wn * NW + w]), acc[wm][wn]);
+        }
+        return;
+    }
+    if constexpr (BF == 1) {  // the unit's 8 reduction channels in ONE v_mfma_f32_32x32x8_bf16 (operands rounded here)
         avc_s16x4 bp[WN];
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) bp[wn] = avc_pack_bf16x4(bv[wn][0], bv[wn][1], bv[wn][2], bv[wn][3]);
@@ -121,14 +149,15 @@ static __device__ __forceinline__ void conv_mma_unit(f32x16 (&acc)[WM][WN], cons
 // (register double buffering) so that a lone wave per SIMD does not stall on LDS latency.
 // TS (straight-line chunks only): 0 = all taps, 1 = taps 0, 2, 4, ..., 2 = taps 1, 3, ... (stride-2 dgrad: the other
 // taps of a column meet the zeros of the zero-upsampled dy)
-template <int WM, int WN, int MIR, int KSC, int GRC, bool BF, int TS = 0>
+template <int WM, int WN, int MIR, int KSC, int GRC, int BF, int TS = 0>
 static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], const float* Ab, const float* Xb, int KS, int CK, int ROW, int h,
                                                       int a_lane4, const int (&cb4)[WN], const int (&cbl4)[WN], const int (&cbr4)[WN]) {
     constexpr int BM4 = 64 * WM * 4;   // floats of one (tap, unit, h) plane of the A stage
+    constexpr int NW = ConvNW<MIR, BF>::value;
     if constexpr (KSC > 0) {
         constexpr int NTAP = TS == 0 ? KSC : (TS == 1 ? (KSC + 1) / 2 : KSC / 2);
         constexpr int U = NTAP * GRC;
-        f32x4 av[2][WM], bv[2][WN];
+        f32x4 av[2][WM], bv[2][WN * NW];
         auto unit_ptrs = [&](int u, const float*& Ap, const float*& Xp) {
             const int tap = TS == 0 ? u / GRC : 2 * (u / GRC) + (TS == 2 ? 1 : 0), g8 = u % GRC;
             Ap = Ab + ((tap * GRC + g8) * 2 + h) * BM4 + a_lane4;
@@ -136,14 +165,14 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
         };
         const float *Ap, *Xp;
         unit_ptrs(0, Ap, Xp);
-        conv_load_unit<WM, WN, MIR>(av[0], bv[0], Ap, Xp, cb4, cbl4, cbr4);
+        conv_load_unit<WM, WN, MIR, BF>(av[0], bv[0], Ap, Xp, cb4, cbl4, cbr4);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u + 1 < U) {
                 unit_ptrs(u + 1, Ap, Xp);
-                conv_load_unit<WM, WN, MIR>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
+                conv_load_unit<WM, WN, MIR, BF>(av[(u + 1) & 1], bv[(u + 1) & 1], Ap, Xp, cb4, cbl4, cbr4);
             }
-            conv_mma_unit<WM, WN, BF>(acc, av[u & 1], bv[u & 1]);
+            conv_mma_unit<WM, WN, BF, NW>(acc, av[u & 1], bv[u & 1]);
         }
     } else {
         const int groups = CK >> 3;
@@ -151,9 +180,9 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
             const float* Ap = Ab + (tap * groups * 2 + h) * BM4 + a_lane4;
             const float* Xp = Xb + (h * ROW + tap) * 4;
             for (int g8 = 0; g8 < groups; ++g8) {
-                f32x4 av[WM], bv[WN];
-                conv_load_unit<WM, WN, MIR>(av, bv, Ap, Xp, cb4, cbl4, cbr4);
-                conv_mma_unit<WM, WN, BF>(acc, av, bv);
+                f32x4 av[WM], bv[WN * NW];
+                conv_load_unit<WM, WN, MIR, BF>(av, bv, Ap, Xp, cb4, cbl4, cbr4);
+                conv_mma_unit<WM, WN, BF, NW>(acc, av, bv);
                 Ap += 2 * BM4;
                 Xp += 2 * ROW * 4;
             }
@@ -169,7 +198,7 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // from the ConvRag tables; everything else is the uniform kernel with one sample per tile.
 // WN = 2 (64 x 128 and 128 x 128 tiles; uniform stride-1 launches): two 32-column fragments per wave share every weight fragment --
 // the weight image is 80 % of a chunk's LDS-DMA bytes and it is re-read by every column tile (section 3.1 of DESIGN.md).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, bool BF, bool PAR = false, bool RAG = false>
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -476,7 +505,10 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     for (int wn = 0; wn < WN; ++wn) {
         if (!colv[wn]) continue;
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) conv_store_frag(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+        for (int wm = 0; wm < WM; ++wm) {
+            if (BF == 2 && epi.pairs) conv_store_frag_pairs(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+            else conv_store_frag(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+        }
     }
 }
 
@@ -514,7 +546,7 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
     const int GR = p.CK >> 3;
     for (long e = first; e < total; e += stride) {
         int m, r, j, chunk;
-        if (p.img == AVC_IMG_K4) {
+        if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
             const int u = (int)(e & 3);
             long rest = e >> 2;
             m = (int)(rest % p.Mp);
@@ -534,20 +566,23 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
             j = (int)(rest % p.KS);
             chunk = (int)(rest / p.KS);
         }
-        int red = chunk * p.CK + r;
-        float v = 0.f;
-        if (!p.dgrad) {
-            if (m < p.M && red < p.Cin) {
-                int s = m / p.rows_per_src, mm = m - s * p.rows_per_src;
-                v = p.src[s][((long)mm * p.Cin + red) * p.KS + j];
+        const int red = chunk * p.CK + r;
+        auto value = [&](int c) -> float {   // (m, reduction channel c, tap j)
+            if (!p.dgrad) {
+                if (m < p.M && c < p.Cin) {
+                    int s = m / p.rows_per_src, mm = m - s * p.rows_per_src;
+                    return p.src[s][((long)mm * p.Cin + c) * p.KS + j];
+                }
+            } else {
+                if (m < p.M && c < p.Cout) {
+                    int s = c / p.rows_per_src, rr = c - s * p.rows_per_src;
+                    return p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
+                }
             }
-        } else {
-            if (m < p.M && red < p.Cout) {
-                int s = red / p.rows_per_src, rr = red - s * p.rows_per_src;
-                v = p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
-            }
-        }
-        p.dst[e] = v;
+            return 0.f;
+        };
+        if (p.img == AVC_IMG_K4H) ((unsigned*)p.dst)[e] = bh_pack(value(2 * red), value(2 * red + 1));   // CK / nchunk count DWORD channels
+        else p.dst[e] = value(red);
     }
 }
 
@@ -620,7 +655,7 @@ static int conv_ntiles_n(const ConvArgs& a, int BN) {
 }
 
 // ragged forward launches (inference): the straight-line instances the model uses + the generic one
-template <int WM, bool BF>
+template <int WM, int BF>
 static void conv_launch_rag(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 5, 1, 1, BF, false, true>), grid, block, lds, stream, a);
     else if (fast == -1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, -1, 0, 1, BF, false, true>), grid, block, lds, stream, a);
@@ -628,7 +663,7 @@ static void conv_launch_rag(const ConvArgs& a, int fast, dim3 grid, dim3 block, 
     else hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 0, 0, 1, BF, false, true>), grid, block, lds, stream, a);
 }
 
-template <int WM, int KG, bool BF>
+template <int WM, int KG, int BF>
 static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, true, 5, 1, KG, BF>), grid, block, lds, stream, a);
     else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, true, 5, 2, KG, BF>), grid, block, lds, stream, a);
@@ -642,14 +677,14 @@ static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid
 }
 
 // 64 x 128 tiles (WN = 2): the k = 5 straight-line chunk, forward and mirrored input gradient
-template <bool BF>
+template <int BF>
 static void conv_launch_wide(const ConvArgs& a, bool mir, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, true, 5, 1, 1, BF>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<1, 2, false, 5, 1, 1, BF>), grid, block, lds, stream, a);
 }
 
 // stride-2 dgrad with one column parity per wave (half the MFMAs of the zero-upsampled correlation)
-template <int KG, bool BF>
+template <int KG, int BF>
 static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
     else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
@@ -671,7 +706,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     if (tile == 98) return -8;   // (round 2's one-shot short-row kernel; gone)
     const bool wide_ok = a.ngroups == 1 && a.g[0].KS == 5 && a.g[0].CK == 8 && a.stride == 1 && a.Tout >= 64 && !a.rag.tile && a.x.ps == 1;
     if (tile == 0) {
-        tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS);
+        tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS * (a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1));
         // 64 x 128: half the weight-image traffic per column; only while the launch keeps the chip full
         if (tile == 11 && wide_ok && tun.tile12_wgs > 0) {
             const long ntn = a.Tout >= 128 ? (long)a.B * avc_cdiv(a.Tout, 128) : (long)avc_cdiv(a.B, 128 / a.Tout);
@@ -698,34 +733,50 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     dim3 block(AVC_THREADS * kgroups);
     double flops = 0;
     for (int gi = 0; gi < a.ngroups; ++gi)
-        flops += 2.0 * a.M * a.Cred * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
+        flops += 2.0 * a.M * a.Cred * (a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1) * a.g[gi].KS * (double)a.B * (a.mode == 0 ? a.Tout : a.Tsrc);
     ProfScope ps(a.mode == 0 ? AVC_K_CONV_FWD : AVC_K_CONV_DGRAD, flops, 0.0, stream);
     const bool mir = a.mode == 1 && a.mirror;
     // the model's kernel_size (5) with the chunk depths the plan uses gets straight-line chunks
     const int fast = (a.ngroups == 1 && a.g[0].KS == 5) ? (a.g[0].CK == 8 ? 1 : (a.g[0].CK == 16 ? 2 : (a.g[0].CK == 32 ? 4 : 0)))
                      : ((a.ngroups > 1 && a.mode == 0 && tun.bank_switch) ? -1
                         : ((a.ngroups == 1 && a.g[0].KS == 1 && a.g[0].CK == 32 && tun.bank_switch) ? 14 : 0));
-    const bool bf = a.bf16 == AVC_COMPUTE_BF16;
+    const int bf = a.bf16 == AVC_COMPUTE_BF16 ? 1 : (a.bf16 == AVC_COMPUTE_BF16S ? 2 : 0);
+    if (bf == 2 && (a.img != AVC_IMG_K4H || a.x.ps != 1 || a.x.st != 1)) return -2;   // bf16 pair tensors: time-contiguous dword rows, pair weight image
+    if (a.pairs && (bf != 2 || a.ops != 1 || a.ot != 1 || (a.M & 1) || (a.res_mode != AVC_RES_NONE && a.rt != 1))) return -2;
     a.par = tun.dgrad_par && a.mode == 1 && a.stride == 2 && tile == 11 && a.ngroups == 1 && (fast == 1 || fast == 2) && !a.dbg &&
             a.g[0].padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
-#define AVC_LAUNCH_CONV(WM_, KG_)                                                                             \
-    do {                                                                                                      \
-        if (bf) conv_launch_variant<WM_, KG_, true>(a, mir, fast, grid, block, lds, stream);                  \
-        else conv_launch_variant<WM_, KG_, false>(a, mir, fast, grid, block, lds, stream);                    \
+#define AVC_BF3(CALL_)                       \
+    do {                                     \
+        if (bf == 2) { CALL_(2); }           \
+        else if (bf == 1) { CALL_(1); }      \
+        else { CALL_(0); }                   \
     } while (0)
     if (rag) {
+        if (bf == 2) return -2;   // (ragged plans run fp32 storage)
         const int f = (fast == 1 || fast == -1 || fast == 14) ? fast : 0;
-        if (tile == 21) { if (bf) conv_launch_rag<2, true>(a, f, grid, block, lds, stream); else conv_launch_rag<2, false>(a, f, grid, block, lds, stream); }
-        else { if (bf) conv_launch_rag<1, true>(a, f, grid, block, lds, stream); else conv_launch_rag<1, false>(a, f, grid, block, lds, stream); }
+#define AVC_C_RAG2(BF_) conv_launch_rag<2, BF_>(a, f, grid, block, lds, stream)
+#define AVC_C_RAG1(BF_) conv_launch_rag<1, BF_>(a, f, grid, block, lds, stream)
+        if (tile == 21) { if (bf) AVC_C_RAG2(1); else AVC_C_RAG2(0); }
+        else { if (bf) AVC_C_RAG1(1); else AVC_C_RAG1(0); }
     } else if (a.par) {
-        if (kgroups == 2) { if (bf) conv_launch_par<2, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<2, false>(a, mir, fast, grid, block, lds, stream); }
-        else { if (bf) conv_launch_par<1, true>(a, mir, fast, grid, block, lds, stream); else conv_launch_par<1, false>(a, mir, fast, grid, block, lds, stream); }
+#define AVC_C_PAR2(BF_) conv_launch_par<2, BF_>(a, mir, fast, grid, block, lds, stream)
+#define AVC_C_PAR1(BF_) conv_launch_par<1, BF_>(a, mir, fast, grid, block, lds, stream)
+        if (kgroups == 2) AVC_BF3(AVC_C_PAR2);
+        else AVC_BF3(AVC_C_PAR1);
     } else if (tile == 12) {
-        if (bf) conv_launch_wide<true>(a, mir, grid, block, lds, stream); else conv_launch_wide<false>(a, mir, grid, block, lds, stream);
-    } else if (tile == 21) AVC_LAUNCH_CONV(2, 1);
-    else if (kgroups == 2) AVC_LAUNCH_CONV(1, 2);
-    else AVC_LAUNCH_CONV(1, 1);
-#undef AVC_LAUNCH_CONV
+#define AVC_C_WIDE(BF_) conv_launch_wide<BF_>(a, mir, grid, block, lds, stream)
+        AVC_BF3(AVC_C_WIDE);
+    } else if (tile == 21) {
+#define AVC_C_V21(BF_) conv_launch_variant<2, 1, BF_>(a, mir, fast, grid, block, lds, stream)
+        AVC_BF3(AVC_C_V21);
+    } else if (kgroups == 2) {
+#define AVC_C_V12(BF_) conv_launch_variant<1, 2, BF_>(a, mir, fast, grid, block, lds, stream)
+        AVC_BF3(AVC_C_V12);
+    } else {
+#define AVC_C_V11(BF_) conv_launch_variant<1, 1, BF_>(a, mir, fast, grid, block, lds, stream)
+        AVC_BF3(AVC_C_V11);
+    }
+#undef AVC_BF3
     return (int)hipGetLastError();
 }
 

@@ -905,7 +905,7 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
     a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0;
     return avc_launch_in_fwd(a, s);
 }
 
@@ -915,7 +915,7 @@ static int in_bwd(float slope, const float* g, const float* y, const float* stat
     a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0;
     return avc_launch_in_bwd(a, s);
 }
 
@@ -1206,7 +1206,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 a.mean = ws + stoff + (long)b0 * C; a.rstd = ws + stoff + (long)B * C + (long)b0 * C;
                 a.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.cond_sb = csb; a.cond_off = coff;
                 a.dy = dy + off; a.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.dcond_sb = csb; a.dcond_off = coff;
-                a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = SL;
+                a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = SL; a.planar = 0;
                 return avc_launch_in_bwd(a, s);
             };
             {

@@ -79,9 +79,18 @@ int avc_gather_segments(const float* corpus, long n_rows, int M, const long* sta
     return avc_launch_gather_segments(corpus, n_rows, M, starts, B, T, out, (hipStream_t)stream);
 }
 
+// op-level compute selector: 3 = bf16 pair storage in and out, 4 = bf16 pair operands with fp32 outputs (the heads / last decoder conv)
+static bool op_bh() { const int d = avc_op_tuning().op_compute_dtype; return d == AVC_COMPUTE_BF16S || d == 4; }
+static void op_compute(ConvArgs& a) {
+    const int d = avc_op_tuning().op_compute_dtype;
+    a.bf16 = d == 4 ? AVC_COMPUTE_BF16S : d;
+    a.pairs = d == AVC_COMPUTE_BF16S ? 1 : 0;
+}
+
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
     int CK = avc_conv_ck(avc_op_tuning(), KS);
     int red = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+    if (op_bh()) red = (red + 1) / 2;   // dword channels of bf16 pairs
     int nchunk = avc_cdiv(red, CK), Mp = avc_cdiv(M, 128) * 128;
     return (long)nchunk * KS * CK * Mp;
 }
@@ -101,6 +110,7 @@ int avc_pack_weight(const float* const* srcs, int nsrc, int rows_per_src, int Co
     p.CK = avc_conv_ck(avc_op_tuning(), KS);
     p.img = AVC_IMG_K4;
     int red = dgrad ? Cout : Cin;
+    if (op_bh()) { red = (red + 1) / 2; p.img = AVC_IMG_K4H; }
     p.M = dgrad ? Cin : Cout;
     p.nchunk = avc_cdiv(red, p.CK);
     p.Mp = avc_cdiv(p.M, 128) * 128;
@@ -115,9 +125,11 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
                    int tile, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = avc_op_tuning().op_compute_dtype;
+    op_compute(a);
+    const bool bh = op_bh();
+    if (bh && (Cin & 1)) return -2;
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
-    a.B = B; a.Cred = Cin; a.Tsrc = Tin;
+    a.B = B; a.Cred = bh ? Cin / 2 : Cin; a.Tsrc = Tin;
     a.mode = 0; a.stride = stride; a.mirror = 0;
     int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
     a.M = Cout; a.Mp = avc_cdiv(Cout, 128) * 128;
@@ -130,8 +142,8 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.ngroups = 1;
     a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = out; a.g[0].out2 = out2; a.g[0].res = res; a.g[0].mask = nullptr;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
-    a.img = AVC_IMG_K4;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(a.Cred, a.g[0].CK);
+    a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
     if (tile == 97) { a.img = AVC_IMG_X3; a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK); }   // wp is a split-bf16 image (avc_pack_weight_x3)
     return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
@@ -144,9 +156,11 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
                      void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.bf16 = avc_op_tuning().op_compute_dtype;
+    op_compute(a);
+    const bool bh = op_bh();
+    if (bh && (Cout & 1)) return -2;
     a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
-    a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
+    a.B = B; a.Cred = bh ? Cout / 2 : Cout; a.Tsrc = Tdy;
     a.mode = 1; a.stride = stride;
     int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
     a.mirror = (KS > 1) ? 1 : 0;
@@ -159,8 +173,8 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     a.ngroups = 1;
     a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wpd; a.g[0].bias = nullptr; a.g[0].out = dx; a.g[0].out2 = dx2; a.g[0].res = res; a.g[0].mask = mask;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
-    a.img = AVC_IMG_K4;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(a.Cred, a.g[0].CK);
+    a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
     if (tile == 97) { a.img = AVC_IMG_X3; a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK); }
     return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
@@ -205,6 +219,7 @@ int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, lon
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
     a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.planar = 0;
     return avc_launch_in_fwd(a, (hipStream_t)stream);
 }
 
@@ -217,7 +232,37 @@ int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const fl
     a.dy = dy; a.dcond = dcond; a.dcond_sb = dcond_sb; a.dcond_off = dcond_off;
     a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.planar = 0;
     return avc_launch_in_bwd(a, (hipStream_t)stream);
+}
+
+// ---- the same two on bf16 PAIR rows (include/avc_hip.h "bf16 pair storage"): y / out / res / g / dy are dword tensors [B][C/2][T];
+// planar != 0: y (and dy) are natural bf16 [B][C][T] rows, the output layout of a pixel-shuffling conv
+int avc_instnorm_fwd_pairs(const void* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const void* res, int res_mode,
+                           int Tres, int planar, void* out, float* mean, float* rstd, void* stream) {
+    INFwdArgs a;
+    a.y = (const float*)y; a.out = (float*)out; a.mean = mean; a.rstd = rstd;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.res = (const float*)res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
+    a.R = B * (C / 2); a.C = C; a.T = T; a.relu = relu ? 1 : 0;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.planar = planar ? 1 : 0;
+    return avc_launch_in_fwd_pairs(a, (hipStream_t)stream);
+}
+int avc_instnorm_bwd_pairs(const void* g, const void* y, const float* mean, const float* rstd, int B, int C, int T, const float* cond, long cond_sb,
+                           int cond_off, int relu, int planar, void* dy, float* dcond, long dcond_sb, int dcond_off, void* stream) {
+    INBwdArgs a;
+    a.g = (const float*)g; a.y = (const float*)y; a.mean = mean; a.rstd = rstd;
+    a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
+    a.dy = (float*)dy; a.dcond = dcond; a.dcond_sb = dcond_sb; a.dcond_off = dcond_off;
+    a.R = B * (C / 2); a.C = C; a.T = T; a.relu = relu ? 1 : 0;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.planar = planar ? 1 : 0;
+    return avc_launch_in_bwd_pairs(a, (hipStream_t)stream);
+}
+// fp32 [B, C, T] (explicit element strides) -> bf16 pairs [B][C/2][T]
+int avc_to_pairs(const float* x, long sxb, long sxc, long sxt, int B, int C, int T, void* dst, void* stream) {
+    return avc_launch_to_pairs(x, sxb, sxc, sxt, B, C, T, (float*)dst, (long)(C / 2) * T, T, (hipStream_t)stream);
 }
 
 long avc_clip_adam_ws_floats(long n) { return avc_adam_blocks(n); }

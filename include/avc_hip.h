@@ -190,6 +190,18 @@ int avc_backward(const avc_plan* p, const float* params, const float* x, long sx
                  const float* x_cond, long scb, long scc, int sct, const float* eps, const float* d_dec,
                  const float* d_muls_up, const float* d_emb_up, float lambda_kl, float* grads, float* ws, void* stream);
 
+/* ---- bf16 PAIR storage (compute_dtype "bf16", BASELINE configs[2]): an activation tensor [B, C, T] is a DWORD tensor [B][C/2][T],
+ * dword (b, p, t) = bf16(channel 2p) in the low half, bf16(channel 2p + 1) in the high half; statistics and accumulation stay fp32.
+ * Op-level conv launches select it with avc_set_tuning("op_compute_dtype", 3) (pair tensors in and out; strides in dwords; 4 = pair
+ * operands with fp32 outputs, as the heads and the decoder's last conv run); avc_pack_weight then emits bf16 pair weight images.
+ * InstanceNorm / AdaIN rows (reference: model.py:296,341,77-83 and autograd): planar != 0 reads y (writes dy) as natural bf16
+ * [B][C][T] rows -- the layout a pixel-shuffling conv (model.py:52-59) leaves its output in. */
+int avc_instnorm_fwd_pairs(const void* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const void* res, int res_mode,
+                           int Tres, int planar, void* out, float* mean, float* rstd, void* stream);
+int avc_instnorm_bwd_pairs(const void* g, const void* y, const float* mean, const float* rstd, int B, int C, int T, const float* cond, long cond_sb,
+                           int cond_off, int relu, int planar, void* dy, float* dcond, long dcond_sb, int dcond_off, void* stream);
+int avc_to_pairs(const float* x, long sxb, long sxc, long sxt, int B, int C, int T, void* dst, void* stream);
+
 /* clip_grad_norm_(max_norm) + torch.optim.Adam(amsgrad, coupled L2) of solver.py:75-77,
  * :91-93 on flat buffers.  step is 1-based.  grad_prescale = 1/world_size when g holds an
  * all-reduced SUM.  ws: avc_clip_adam_ws_floats(n) floats.  gnorm_out: device float or NULL. */
