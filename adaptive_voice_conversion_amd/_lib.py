@@ -31,7 +31,7 @@ class ModelCfg(ctypes.Structure):
 
 class ReluSite(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("kind", "B", "C", "T")] + \
-               [(n, ctypes.c_long) for n in ("act_off", "sb", "sc", "st", "y_off", "stat_off", "cond_off", "cond_sb")]
+               [(n, ctypes.c_long) for n in ("act_off", "sb", "sc", "st", "y_off", "stat_off", "cond_off", "cond_sb", "storage")]
 
 
 class Tuning(ctypes.Structure):
@@ -44,6 +44,7 @@ class Tuning(ctypes.Structure):
 
 PLAN_X3 = 4
 PLAN_RAGGED = 8
+PLAN_BF16S = 16
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 

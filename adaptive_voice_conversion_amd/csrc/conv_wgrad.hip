@@ -16,6 +16,7 @@
 #include "avc_common.h"
 #include "avc_internal.h"
 #include "conv_x3_shared.h"
+#include "bf16_pairs.h"
 
 // LDS row strides (floats).  General form: odd (33 / (spc XSEG) | 1): the 32 lanes of a half-wave read one column of 32 different
 // rows with ds_read_b32, conflict-free.  LIN instances (whole 32-column chunks of a stride-1 layer): rows are 16-byte aligned with
@@ -49,7 +50,19 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
 // activations here, so both are split in registers: per 16 columns a lane reads its 8 dy values and the 12 x values that its
 // KS shifted windows cover, splits each ONCE, and assembles the KS B fragments by pairing registers (v_perm) -- 20 splits and
 // 30 MFMAs per block where the fp32 path issues 40 MFMAs of twice the length.  Producers, tiles, slabs: unchanged.
-template <int KS, int NB, int WCO, bool LIN, bool BF, bool X3 = false>
+//
+// BF == 2 (bf16 PAIR storage, bf16_pairs.h): x and dy are dword tensors [B][C/2][T].  The producers stage PAIR rows -- the same code
+// over half as many rows, every DMA'd dword brings two channels -- and the consumers feed v_mfma_f32_32x32x16_bf16: a lane's
+// 8 k-values are 8 consecutive columns of ITS channel, i.e. one half of 8 consecutive dwords of its pair row, gathered with one
+// v_perm_b32 per two columns (lanes 2p and 2p + 1 read the same LDS words: a broadcast, no extra bandwidth).
+#ifndef AVC_EMU
+static __device__ __forceinline__ unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) { return __builtin_amdgcn_perm(d1, d0, sel); }
+#else
+static inline unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) {   // sel = 0x05040100 (low halves) or 0x07060302 (high halves)
+    return sel == 0x05040100u ? ((d0 & 0xffffu) | (d1 << 16)) : ((d0 >> 16) | (d1 & 0xffff0000u));
+}
+#endif
+template <int KS, int NB, int WCO, bool LIN, int BF, bool X3 = false>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
     // which layer of the batch this workgroup works for (wave-uniform scan of <= 16 entries)
     int layer = 0;
@@ -60,6 +73,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     constexpr int TCO = 32 * WCO;           // co rows per workgroup
     constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
     constexpr int NACC = KS * NB;
+    constexpr bool BH = BF == 2;
+    constexpr int RCO = BH ? TCO / 2 : TCO, RCI = BH ? TCI / 2 : TCI;   // LDS / source rows of the two operand tiles (pair rows with BH)
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
@@ -71,6 +86,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     const int local = (int)blockIdx.x - a.wg_begin;
     const int z = local / a.tiles, tile = local - z * a.tiles;   // split index, (co, ci) tile
     const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
+    const int co0r = BH ? co0 >> 1 : co0, ci0r = BH ? ci0 >> 1 : ci0;                   // ... in source rows
+    const int CoutR = BH ? a.Cout >> 1 : a.Cout, CinR = BH ? a.Cin >> 1 : a.Cin;
     const float* xptr = a.x.ptr;
     const float* dyptr = a.dy.ptr;
     float* slabp = a.slab;
@@ -80,14 +97,14 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     const int XSEG = (Tc - 1) * a.stride + KS;
     constexpr int WG_DYROW = wg_dyrow(LIN);
     const int XROW = LIN ? wg_xrow_lin(KS) : ((spc * XSEG) | 1);
-    const int DYS = TCO * WG_DYROW, XS = TCI * XROW;
+    const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
     const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
-    float* dyT = smem;             // [2][TCO][WG_DYROW]
-    float* xT = smem + 2 * DYSP;   // [2][TCI][XROW]
+    float* dyT = smem;             // [2][RCO][WG_DYROW]
+    float* xT = smem + 2 * DYSP;   // [2][RCI][XROW]
     const bool do_db = (dbp != nullptr) && (ci0 == 0);
     const float inv_xrow = 1.0f / (float)XROW;
 
-    float dbsum = 0.f;
+    float dbsum = 0.f, dbsum1 = 0.f;
 
     // Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
     // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1
@@ -99,8 +116,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     // valid address instead of an exec-masked branch; they are never read, or feed accumulator rows
     // that are never stored.  The chunk-invariant byte offsets live in producer registers, the
     // chunk origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
-    constexpr int NPD = (TCO * WG_DYROW + 255) / 256;  // dy pieces per wave
-    constexpr int NPX = (TCI * (LIN ? wg_xrow_lin(KS) : (KS == 1 ? 33 : 71)) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
+    constexpr int NPD = (RCO * WG_DYROW + 255) / 256;  // dy pieces per wave
+    constexpr int NPX = (RCI * (LIN ? wg_xrow_lin(KS) : (KS == 1 ? 33 : 71)) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
     // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the
     // reflection is chunk-invariant, so the x offsets are complete and only the base moves.
     const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
@@ -112,10 +129,10 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
         for (int i = 0; i < NPD; ++i) {
             const int f = (wave + 4 * i) * 64 + lane;
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            row = row < TCO ? row : TCO - 1;
+            row = row < RCO ? row : RCO - 1;
             qcol = qcol < 32 ? qcol : 31;
-            int co = co0 + row;
-            co = co < a.Cout ? co : a.Cout - 1;
+            int co = co0r + row;
+            co = co < CoutR ? co : CoutR - 1;
             const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
             dyo[i] = 4u * (unsigned)((long)sl * a.dy.sb + src_chan_off(a.dy, co) + (long)tl * a.dy.st);
         }
@@ -123,11 +140,11 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
         for (int i = 0; i < NPX; ++i) {
             const int f = (wave + 4 * i) * 64 + lane;
             int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
-            row = row < TCI ? row : TCI - 1;
+            row = row < RCI ? row : RCI - 1;
             int sl = pp / XSEG, p = pp - sl * XSEG;
             if (sl >= spc) { sl = spc - 1; p = XSEG - 1; }  // the odd-stride padding column
-            int ci = ci0 + row;
-            ci = ci < a.Cin ? ci : a.Cin - 1;
+            int ci = ci0r + row;
+            ci = ci < CinR ? ci : CinR - 1;
             int r = avc_reflect(p - a.padL, a.Tin);
             r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);
             xo[i] = 4u * (unsigned)((long)sl * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st);
@@ -138,20 +155,20 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
         for (int i = 0; i < NPD; ++i) {
             const int f = (wave + 4 * i) * 64 + lane;
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            row = row < TCO ? row : TCO - 1;
+            row = row < RCO ? row : RCO - 1;
             qcol = qcol < 32 ? qcol : 31;
-            int co = co0 + row;
-            co = co < a.Cout ? co : a.Cout - 1;
+            int co = co0r + row;
+            co = co < CoutR ? co : CoutR - 1;
             dyo[i] = 4u * (unsigned)(src_chan_off(a.dy, co) + (long)qcol * a.dy.st);
         }
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             const int f = (wave + 4 * i) * 64 + lane;
             int row = avc_fastdiv(f, XROW, inv_xrow), p = f - row * XROW;
-            row = row < TCI ? row : TCI - 1;
+            row = row < RCI ? row : RCI - 1;
             p = p < XSEG ? p : XSEG - 1;
-            int ci = ci0 + row;
-            ci = ci < a.Cin ? ci : a.Cin - 1;
+            int ci = ci0r + row;
+            ci = ci < CinR ? ci : CinR - 1;
             xo[i] = 4u * (unsigned)src_chan_off(a.x, ci);
             xq[i] = p;
         }
@@ -215,8 +232,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
             int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
             if (f < DYS && qcol < 32) {
                 int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
-                int b = cb + sl, t = t0 + tl, co = co0 + row;
-                if (b < a.B && t < a.Tout && co < a.Cout)
+                int b = cb + sl, t = t0 + tl, co = co0r + row;
+                if (b < a.B && t < a.Tout && co < CoutR)
                     avc_glds4(dyptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
                 else
                     dd[f] = 0.f;
@@ -227,9 +244,9 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
             if (f < XS) {
                 int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
                 int sl = pp / XSEG, p = pp - sl * XSEG;
-                int b = cb + sl, ci = ci0 + row;
+                int b = cb + sl, ci = ci0r + row;
                 int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
-                if (sl < spc && b < a.B && ci < a.Cin && r >= 0 && r < a.Tin)
+                if (sl < spc && b < a.B && ci < CinR && r >= 0 && r < a.Tin)
                     avc_glds4(xptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
                 else
                     xd[f] = 0.f;
@@ -244,7 +261,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     __syncthreads();  // zero fill complete before the first DMA lands
     if (producer && c_begin < c_end) issue(c_begin, 0);
     __syncthreads();
-    constexpr int TPR = 256 / TCO;  // producer threads per dy row in the bias-gradient partial sum
+    constexpr int TPR = 256 / RCO;  // producer threads per dy row in the bias-gradient partial sum
     constexpr int CPT = 32 / TPR;
     // The two roles run separate loops that meet at one s_barrier per chunk (the barrier counts wave
     // arrivals, not call sites).  Producer side of the barrier: the next stage has landed (the DMA is
@@ -257,15 +274,34 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
             if (do_db) {
                 const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) dbsum += dr[k];
+                for (int k = 0; k < CPT; ++k) {
+                    if constexpr (BH) {
+                        const unsigned d = bh_as_u32(dr[k]);
+                        dbsum += bh_lo(d);
+                        dbsum1 += bh_hi(d);
+                    } else {
+                        dbsum += dr[k];
+                    }
+                }
             }
             if (!(dbg & 4)) __syncthreads();
         }
         if (do_db) {
 #pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) dbsum += __shfl_xor(dbsum, o);
-            int co = co0 + ptid / TPR;
-            if ((ptid % TPR) == 0 && co < a.Cout) dbp[(long)z * a.db_stride + co] = dbsum;
+            for (int o = 1; o < TPR; o <<= 1) {
+                dbsum += __shfl_xor(dbsum, o);
+                if (BH) dbsum1 += __shfl_xor(dbsum1, o);
+            }
+            if constexpr (BH) {
+                const int co = co0 + 2 * (ptid / TPR);
+                if ((ptid % TPR) == 0 && co < a.Cout) {
+                    dbp[(long)z * a.db_stride + co] = dbsum;
+                    dbp[(long)z * a.db_stride + co + 1] = dbsum1;
+                }
+            } else {
+                const int co = co0 + ptid / TPR;
+                if ((ptid % TPR) == 0 && co < a.Cout) dbp[(long)z * a.db_stride + co] = dbsum;
+            }
         }
         return;
     }
@@ -279,8 +315,9 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const int buf = (chunk - c_begin) & 1;
         if (!(dbg & 2)) {
-            const float* arow = dyT + buf * DYSP + (wave_m * 32 + li) * WG_DYROW;
-            const float* brow = xT + buf * XSP + (wave_n * NB * 32 + li) * XROW;
+            const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * WG_DYROW;
+            const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * XROW;
+            constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
             // fragments of k-step s+1 are requested before the MFMAs of step s are queued.  LIN (template): whole
             // 32-column chunks of a stride-1 layer -- column 2s+h of the chunk is element 2s+h of both
             // LDS rows, so every fragment address is base + immediate (the general form costs ~30
@@ -304,7 +341,66 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
 #pragma unroll
                         for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
                 };
-                if constexpr (X3 && LIN && !BF) {
+                if constexpr (BH) {
+                    // two blocks of 16 columns per chunk; lane-half h owns columns 16 kb + 8 h .. + 7 in BOTH operands
+                    const unsigned sel = (li & 1) ? 0x07060302u : 0x05040100u;   // this lane's channel = low / high half of its pair row
+                    constexpr int NX = 8 + KS - 1;
+                    auto fetch = [&](int kb, unsigned (&ad)[8], unsigned (&xd)[NB][LIN ? NX : 8 * KS]) {
+                        if constexpr (LIN) {   // 16-byte aligned rows: ds_read_b128
+                            const float* ap = arow + 16 * kb + 8 * h;
+                            const float* bp = brow + 16 * kb + 8 * h;
+#pragma unroll
+                            for (int i4 = 0; i4 < 2; ++i4) {
+                                const f32x4 v = *(const f32x4*)(ap + 4 * i4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) ad[4 * i4 + i] = bh_as_u32(v[i]);
+                            }
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int i4 = 0; i4 < (NX + 3) / 4; ++i4) {
+                                    const f32x4 v = *(const f32x4*)(bp + nb * NBROW * XROW + 4 * i4);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (4 * i4 + i < NX) xd[nb][4 * i4 + i] = bh_as_u32(v[i]);
+                                }
+                        } else {               // short samples / strided layers: every column has its own window
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int qcol = 16 * kb + 8 * h + i;
+                                const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
+                                ad[i] = bh_as_u32(arow[qcol]);
+                                const float* bp = brow + sl * XSEG + tl * a.stride;
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                    for (int j = 0; j < KS; ++j) xd[nb][i * KS + j] = bh_as_u32(bp[nb * NBROW * XROW + j]);
+                            }
+                        }
+                    };
+                    auto block = [&](const unsigned (&ad)[8], const unsigned (&xd)[NB][LIN ? NX : 8 * KS]) {
+                        avc_u32x4 at;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) at[q4] = bh_sel(ad[2 * q4], ad[2 * q4 + 1], sel);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int j = 0; j < KS; ++j) {
+                                avc_u32x4 b;
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    if constexpr (LIN) b[q4] = bh_sel(xd[nb][j + 2 * q4], xd[nb][j + 2 * q4 + 1], sel);
+                                    else b[q4] = bh_sel(xd[nb][(2 * q4) * KS + j], xd[nb][(2 * q4 + 1) * KS + j], sel);
+                                }
+                                acc[nb * KS + j] = avc_mfma_bf16x8(at, b, acc[nb * KS + j]);
+                            }
+                    };
+                    unsigned a0[8], x0[NB][LIN ? NX : 8 * KS], a1[8], x1[NB][LIN ? NX : 8 * KS];
+                    fetch(0, a0, x0);
+                    fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
+                    block(a0, x0);
+                    block(a1, x1);
+                } else if constexpr (X3 && LIN && !BF) {
                     // two blocks of 16 columns: lane-half h owns columns 16 kb + 8 h .. + 7 of the chunk
                     constexpr int NX = 8 + KS - 1;   // x values under the KS shifted windows of 8 columns
                     auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {   // 16-byte aligned rows (LIN): ds_read_b128
@@ -511,7 +607,8 @@ static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
 }
 
 static size_t wgrad_lds_bytes(const WgradArgs& a, int NB, int WCO) {
-    const int TCO = 32 * WCO, TCI = 32 * NB * (4 / WCO);
+    const int half = a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1;   // pair rows
+    const int TCO = 32 * WCO / half, TCI = 32 * NB * (4 / WCO) / half;
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
@@ -600,27 +697,30 @@ void avc_wgrad_plan(const avc_tuning& tun, int B, int Cin, int Cout, int Tout, i
 
 
 template <int KS, int NB, int WCO>
-static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, bool bf, bool x3, size_t lds, double flops, hipStream_t stream) {
+static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, int bf, bool x3, size_t lds, double flops, hipStream_t stream) {
     if (lds > 158 * 1024) return -3;
     dim3 grid(total_wgs);
     ProfScope ps(AVC_K_CONV_WGRAD, flops, 0.0, stream);
-    if (bf) {
-        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, true>), grid, dim3(WG_THREADS), lds, stream, bt);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+    if (bf == 2) {
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else if (bf) {
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
     } else if (lin) {
         if constexpr (KS * NB <= 8) {
             if (x3) {
-                hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+                hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 0, true>), grid, dim3(WG_THREADS), lds, stream, bt);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, false>), grid, dim3(WG_THREADS), lds, stream, bt);
-    } else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, false>), grid, dim3(WG_THREADS), lds, stream, bt);
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
     return (int)hipGetLastError();
 }
 
 template <int KS>
-static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, bool bf, bool x3, size_t lds, double flops, hipStream_t stream) {
+static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, int bf, bool x3, size_t lds, double flops, hipStream_t stream) {
     return k.WCO == 4 ? launch_wgrad_t<KS, 1, 4>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream)
                       : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream);
 }
@@ -653,7 +753,11 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ab
             flops += 2.0 * d.Cout * d.Cin * d.KS * (double)d.B * d.Tout;
             done[j] = 1;
         }
-        const bool bf = a0.bf16 == AVC_COMPUTE_BF16, x3 = a0.bf16 == AVC_COMPUTE_F32X3;
+        const int bf = a0.bf16 == AVC_COMPUTE_BF16 ? 1 : (a0.bf16 == AVC_COMPUTE_BF16S ? 2 : 0);
+        const bool x3 = a0.bf16 == AVC_COMPUTE_F32X3;
+        if (bf == 2)
+            for (int j = 0; j < bt.nlayers; ++j)
+                if ((bt.L[j].Cin & 1) || (bt.L[j].Cout & 1) || bt.L[j].x.st != 1 || bt.L[j].dy.st != 1 || bt.L[j].x.ps != 1 || bt.L[j].dy.ps != 1) return -2;
         int rc;
         if (k.KS == 1 && k.NB == 4) rc = launch_wgrad_t<1, 4, 4>(bt, wgs, k.lin, bf, x3, lds, flops, stream);
         else switch (k.KS) {

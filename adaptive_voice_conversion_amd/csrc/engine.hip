@@ -59,6 +59,7 @@ struct LayerP {
     long wrs_f = -1, wrs_d = -1;
     bool conv_path = true;             // launched through conv_gemm.hip (AVC_IMG_K4 images); false: the dense stack (AVC_IMG_PLAIN)
     long wplain = -1;                  // extra AVC_IMG_PLAIN forward image (the affine layer: its d_emb GEMM reads it as a [Kp][Mp] matrix)
+    bool bh = false;                   // bf16 pair operands (AVC_PLAN_BF16S): AVC_IMG_K4H images over Cin / 2 (Cout / 2) dword channels
 };
 
 struct EncNet {
@@ -136,6 +137,10 @@ struct avc_plan {
     int nev_need = 0;         // events one backward pass records on the wgrad streams
     long dec_param_off = 0;   // first float of the decoder's parameters in the flat buffer (they are the tail)
     long enc_param_off = 0;   // first float of the content encoder's (the speaker encoder's are the head)
+    // AVC_PLAN_BF16S: every [B, C, T] activation / activation gradient is a bf16 pair tensor (bf16_pairs.h) at the same workspace
+    // offsets (half of each allocation is used); muls / dec / emb / cond and their gradients, statistics, slabs stay fp32
+    bool bh = false;
+    long ddecp = -1, dmulsp = -1;   // pair copies of d(dec) and d(muls): the conv launches that consume them read pair operands
 
     long alloc(long n) {
         long o = ws_top;
@@ -176,9 +181,12 @@ static int add_layer(avc_plan* p, int Cout, int Cin, int KS, int stride, bool co
 
 // Bn/Tf: batch and output length of the forward launch; Td: output length of the dgrad launch
 // conv_path: the layer is launched through avc_launch_conv (false: the dense stack, which reads plain fp32 images in its own kernel)
-static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, bool conv_path = true) {
+static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int Bn, int Tf, int Td, int ngroups = 1, bool conv_path = true,
+                         bool pairs_ok = true) {
     const avc_tuning& tun = p->tun;
     L.conv_path = conv_path;
+    L.bh = p->bh && conv_path && pairs_ok;
+    if (p->bh) L.bf16 = L.bh ? AVC_COMPUTE_BF16S : AVC_COMPUTE_BF16;   // (fp32-stored operands of the affine / dense layers: rounded on the way in)
     L.Mp_f = avc_cdiv(L.Cout, 128) * 128;
     L.need_dgrad = need_dgrad;
     L.dgM = dgM > 0 ? dgM : L.Cin;
@@ -187,10 +195,14 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.CK = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
     int td = avc_conv_pick_tile(tun, L.Mp_d, Bn, Td, 1, L.Cout * L.KS);
     L.CKd = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
-    L.nchunk_f = avc_cdiv(L.Cin, L.CK);
-    L.nchunk_d = avc_cdiv(L.Cout, L.CKd);
-    L.x3_f = conv_path && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
-    L.x3_d = conv_path && need_dgrad && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
+    if (L.bh && L.KS >= 4 && ngroups == 1) {   // a chunk of 8 dword channels is 5 short MFMAs per barrier: take 16 (32 reduction channels)
+        L.CK = L.CK < 16 ? 16 : L.CK;
+        L.CKd = L.CKd < 16 ? 16 : L.CKd;
+    }
+    L.nchunk_f = avc_cdiv(L.bh ? L.Cin / 2 : L.Cin, L.CK);
+    L.nchunk_d = avc_cdiv(L.bh ? L.Cout / 2 : L.Cout, L.CKd);
+    L.x3_f = !p->bh && conv_path && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 0, L.Cin, L.KS, L.stride, Tf, Bn, L.Cout);
+    L.x3_d = !p->bh && conv_path && need_dgrad && ngroups == 1 && L.nsrc == 1 && avc_conv_x3_eligible(tun, 1, L.Cout, L.KS, L.stride, Td, Bn, L.dgM);
     if (L.x3_f) { L.CK = L.KS == 1 ? 32 : 16; L.nchunk_f = avc_cdiv(L.Cin, L.CK); }
     if (L.x3_d) { L.CKd = L.KS == 1 ? 32 : 16; L.nchunk_d = avc_cdiv(L.Cout, L.CKd); }
     if (L.x3_f) L.wrs_f = p->alloc(avc_conv_x3_image_floats(L.Cout, L.Cin, L.KS));
@@ -254,7 +266,8 @@ extern "C" int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_
 
 extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out) {
     if (!cfg || !out || B < 1 || T < 1) return fail(-1, "avc_plan_create: bad arguments");
-    if (flags & ~(AVC_PLAN_INFERENCE | AVC_PLAN_SPEAKER_ONLY | AVC_PLAN_X3)) return fail(-1, "avc_plan_create: unknown flag");
+    if (flags & ~(AVC_PLAN_INFERENCE | AVC_PLAN_SPEAKER_ONLY | AVC_PLAN_X3 | AVC_PLAN_BF16S)) return fail(-1, "avc_plan_create: unknown flag");
+    if ((flags & AVC_PLAN_X3) && (flags & AVC_PLAN_BF16S)) return fail(-1, "avc_plan_create: AVC_PLAN_X3 and AVC_PLAN_BF16S exclude each other");
     if (tuning && tuning->struct_size != (int)sizeof(avc_tuning)) return fail(-1, "avc_plan_create_tuned: avc_tuning of another library version (use avc_tuning_init)");
     if (flags & AVC_PLAN_SPEAKER_ONLY) flags |= AVC_PLAN_INFERENCE;
     if (T_cond <= 0) T_cond = T;
@@ -284,6 +297,12 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     p->T = T;
     p->Tc = T_cond;
     p->M = cfg->enc.c_in;
+    if (flags & AVC_PLAN_BF16S) {
+        p->bh = true;
+        p->compute = AVC_COMPUTE_BF16S;
+        p->tun.conv_x3 = 0;
+        p->tun.wgrad_x3 = 0;
+    }
 
     // ---- parameters in reference registration order
     build_enc_params(p, p->spk, cfg->spk, true);
@@ -336,6 +355,18 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         d.T[l + 1] = d.T[l] * dc.upsample[l];
     }
     p->Tout = d.T[d.n];
+    if (p->bh) {
+        // pair rows: two channels per dword, four frames per 16-byte access of the row kernels
+        bool ok = !((cfg->enc.c_in | cfg->enc.c_h | cfg->enc.c_bank | cfg->enc.c_out | cfg->spk.c_h | cfg->spk.c_bank | dc.c_h | dc.c_in | dc.c_out) & 1);
+        for (int l = 0; l <= p->spk.n; ++l) ok = ok && (p->spk.T[l] % 4 == 0);
+        for (int l = 0; l <= p->enc.n; ++l) ok = ok && (p->enc.T[l] % 4 == 0);
+        for (int l = 0; l <= d.n; ++l) ok = ok && (d.T[l] % 4 == 0) && (d.T[l] <= 2048);
+        for (int l = 0; l < p->enc.n; ++l) ok = ok && (p->enc.T[l] <= 2048) && (p->spk.T[l] <= 2048);
+        if (!ok) {
+            delete p;
+            return fail(-2, "avc_plan_create: AVC_PLAN_BF16S needs even channel counts and frame counts that are multiples of 4 (<= 2048) at every level");
+        }
+    }
 
     // ---- packed weights (inference plans keep no dgrad images; speaker-only plans only the speaker encoder's)
     const bool dg = !infer;
@@ -360,7 +391,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
             finish_layer(p, p->layers[d.c1[l]], dg, 0, B, d.T[l], d.T[l]);
             finish_layer(p, p->layers[d.c2[l]], dg, 0, B, d.T[l], d.T[l]);
         }
-        finish_layer(p, p->layers[d.affine], dg, 0, 1, B, B);
+        finish_layer(p, p->layers[d.affine], dg, 0, 1, B, B, 1, true, false);
         if (dg) {   // d(emb) = W^T dcond runs through the weight-gradient kernel, which reads W as a plain [Kp][Mp] matrix
             LayerP& La = p->layers[d.affine];
             La.wplain = p->alloc((long)La.nchunk_f * La.CK * La.Mp_f);
@@ -445,6 +476,10 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->gB2 = p->alloc(Bl * maxCT);
         p->gC2 = p->alloc(Bl * maxCT);
         p->dhA = p->alloc((long)p->spk.c.c_h * Bl);
+        if (p->bh) {
+            p->ddecp = p->alloc(Bl * p->M * p->Tout / 2);
+            p->dmulsp = p->alloc(Bl * Cz * p->Tb);
+        }
     }
 
     p->named["emb"] = p->emb;
@@ -472,48 +507,53 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->named["d_cond"] = d.dcond;
     }
 
-    // ---- ReLU site table in the reference's forward call order (avc_plan_relu_site)
+    // ---- ReLU site table in the reference's forward call order (avc_plan_relu_site).  Pair plans: activation / conv-output tensors
+    // are bf16 pair tensors (storage 1: strides in dwords) or, after a pixel-shuffling conv, natural bf16 rows (storage 2)
     {
-        auto conv_site = [&](long off, int Bn, int C, int T, long sb, long sc, long st) {
+        const long H = p->bh ? 2 : 1;   // channels per row of a stored [B, C, T] tensor
+        auto conv_site = [&](long off, int Bn, int C, int T, long sb, long sc, long st, int storage) {
             avc_relu_site r;
             memset(&r, 0, sizeof(r));
             r.kind = 0; r.B = Bn; r.C = C; r.T = T; r.act_off = off; r.sb = sb; r.sc = sc; r.st = st;
             r.y_off = r.stat_off = r.cond_off = -1;
+            r.storage = storage;
             p->sites.push_back(r);
         };
-        auto in_site = [&](long y, long st, int C, int T, long cond, long csb) {
+        auto in_site = [&](long y, long st, int C, int T, long cond, long csb, int storage) {
             avc_relu_site r;
             memset(&r, 0, sizeof(r));
             r.kind = 1; r.B = B; r.C = C; r.T = T; r.act_off = -1;
             r.y_off = y; r.stat_off = st; r.cond_off = cond; r.cond_sb = csb;
+            r.storage = storage;
             p->sites.push_back(r);
         };
+        const int PS = p->bh ? 1 : 0;
         const EncNet& sp = p->spk;
         const int Cs_ = sp.c.c_h;
-        for (int g = 0; g < sp.nb; ++g) conv_site(sp.cat + (long)g * sp.c.c_bank * sp.T[0], B, sp.c.c_bank, sp.T[0], (long)sp.CC * sp.T[0], sp.T[0], 1);
-        conv_site(sp.h0, B, Cs_, sp.T[0], (long)Cs_ * sp.T[0], sp.T[0], 1);
+        for (int g = 0; g < sp.nb; ++g) conv_site(sp.cat + (long)g * (sp.c.c_bank / H) * sp.T[0], B, sp.c.c_bank, sp.T[0], (long)(sp.CC / H) * sp.T[0], sp.T[0], 1, PS);
+        conv_site(sp.h0, B, Cs_, sp.T[0], (long)(Cs_ / H) * sp.T[0], sp.T[0], 1, PS);
         for (int l = 0; l < sp.n; ++l) {
-            conv_site(sp.a1[l], B, Cs_, sp.T[l], (long)Cs_ * sp.T[l], sp.T[l], 1);
-            conv_site(sp.a2[l], B, Cs_, sp.T[l + 1], (long)Cs_ * sp.T[l + 1], sp.T[l + 1], 1);
+            conv_site(sp.a1[l], B, Cs_, sp.T[l], (long)(Cs_ / H) * sp.T[l], sp.T[l], 1, PS);
+            conv_site(sp.a2[l], B, Cs_, sp.T[l + 1], (long)(Cs_ / H) * sp.T[l + 1], sp.T[l + 1], 1, PS);
         }
-        for (int l = 0; l < sp.nd; ++l) {  // dense activations are stored channel-major [C][B]; the reference sees [B, C]
-            conv_site(sp.d1[l], B, Cs_, 1, 1, B, 0);
-            conv_site(sp.d2[l], B, Cs_, 1, 1, B, 0);
+        for (int l = 0; l < sp.nd; ++l) {  // dense activations are stored channel-major [C][B] fp32; the reference sees [B, C]
+            conv_site(sp.d1[l], B, Cs_, 1, 1, B, 0, 0);
+            conv_site(sp.d2[l], B, Cs_, 1, 1, B, 0, 0);
         }
         const EncNet& en = p->enc;
         const int Ce_ = en.c.c_h;
         if (!spk_only) {
-        for (int g = 0; g < en.nb; ++g) conv_site(en.cat + (long)g * en.c.c_bank * en.T[0], B, en.c.c_bank, en.T[0], (long)en.CC * en.T[0], en.T[0], 1);
-        in_site(en.h0, en.st0, Ce_, en.T[0], -1, 0);
+        for (int g = 0; g < en.nb; ++g) conv_site(en.cat + (long)g * (en.c.c_bank / H) * en.T[0], B, en.c.c_bank, en.T[0], (long)(en.CC / H) * en.T[0], en.T[0], 1, PS);
+        in_site(en.h0, en.st0, Ce_, en.T[0], -1, 0, PS);
         for (int l = 0; l < en.n; ++l) {
-            in_site(en.y1[l], en.st1[l], Ce_, en.T[l], -1, 0);
-            in_site(en.y2[l], en.st2[l], Ce_, en.T[l + 1], -1, 0);
+            in_site(en.y1[l], en.st1[l], Ce_, en.T[l], -1, 0, PS);
+            in_site(en.y2[l], en.st2[l], Ce_, en.T[l + 1], -1, 0, PS);
         }
         const long csb_ = (long)2 * d.n * 2 * Cd;
-        in_site(d.y0, d.st0, (int)Cd, d.T[0], -1, 0);
+        in_site(d.y0, d.st0, (int)Cd, d.T[0], -1, 0, PS);
         for (int l = 0; l < d.n; ++l) {
-            in_site(d.y1[l], d.st1[l], (int)Cd, d.T[l], d.cond + (long)(2 * l) * 2 * Cd, csb_);
-            in_site(d.y2[l], d.st2[l], (int)Cd, d.T[l + 1], d.cond + (long)(2 * l + 1) * 2 * Cd, csb_);
+            in_site(d.y1[l], d.st1[l], (int)Cd, d.T[l], d.cond + (long)(2 * l) * 2 * Cd, csb_, PS);
+            in_site(d.y2[l], d.st2[l], (int)Cd, d.T[l + 1], d.cond + (long)(2 * l + 1) * 2 * Cd, csb_, (p->bh && dc.upsample[l] > 1) ? 2 : PS);
         }
         }
     }
@@ -566,6 +606,7 @@ extern "C" int avc_plan_set_single_stream(avc_plan* p, int on) {
 
 extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
     if (!p || (dtype != AVC_COMPUTE_F32 && dtype != AVC_COMPUTE_BF16)) return fail(-1, "avc_plan_set_compute_dtype: dtype must be 0 (fp32) or 1 (bf16 operands)");
+    if (p->bh) return fail(-1, "avc_plan_set_compute_dtype: the plan was created with AVC_PLAN_BF16S (bf16 storage is a property of the workspace layout)");
     p->compute = dtype;
     for (LayerP& L : p->layers) L.bf16 = dtype;
     return 0;
@@ -687,12 +728,13 @@ static ConvArgs mk_fwd(const avc_plan* p, float slope, const LayerP& L, const fl
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = 1;
-    a.B = Bn; a.Cred = L.Cin; a.Tsrc = Tsrc;
+    a.B = Bn; a.Cred = L.bh ? L.Cin / 2 : L.Cin; a.Tsrc = Tsrc;
     a.mode = 0; a.stride = L.stride; a.bf16 = L.bf16;
+    a.pairs = L.bh ? 1 : 0;   // (callers clear it for the fp32 outputs of the heads and the decoder's last conv)
     a.M = L.Cout; a.Mp = L.Mp_f;
     a.ngroups = 1;
     set_group(a.g[0], ws + (L.x3_f ? L.wrs_f : L.wpf), layer_bias(p, L, params, ws), L.KS, L.CK, L.nchunk_f);
-    a.img = L.x3_f ? AVC_IMG_X3 : AVC_IMG_K4;
+    a.img = L.x3_f ? AVC_IMG_X3 : (L.bh ? AVC_IMG_K4H : AVC_IMG_K4);
     a.Tout = (Tsrc + a.g[0].padL + a.g[0].padR - L.KS) / L.stride + 1;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
     a.act = act;
@@ -706,7 +748,8 @@ static ConvArgs mk_dgrad(float slope, const LayerP& L, const float* ws, const fl
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x.ptr = dy; a.x.sb = sb; a.x.sc = sc; a.x.st = st; a.x.ps = ps;
-    a.B = Bn; a.Cred = L.Cout; a.Tsrc = Tdy;
+    a.B = Bn; a.Cred = L.bh ? L.Cout / 2 : L.Cout; a.Tsrc = Tdy;
+    a.pairs = L.bh ? 1 : 0;
     a.mode = 1; a.stride = L.stride; a.mirror = (L.KS > 1) ? 1 : 0; a.bf16 = L.bf16;
     a.M = L.dgM; a.Mp = L.Mp_d; a.Tout = Tin;
     a.ob = ob; a.oc = oc; a.ot = ot; a.ops = 1;
@@ -714,7 +757,7 @@ static ConvArgs mk_dgrad(float slope, const LayerP& L, const float* ws, const fl
     a.slope = slope;   // (applied where the launch masks by a ReLU output)
     a.ngroups = 1;
     set_group(a.g[0], ws + (L.x3_d ? L.wrs_d : L.wpd), nullptr, L.KS, L.CKd, L.nchunk_d);
-    a.img = L.x3_d ? AVC_IMG_X3 : AVC_IMG_K4;
+    a.img = L.x3_d ? AVC_IMG_X3 : (L.bh ? AVC_IMG_K4H : AVC_IMG_K4);
     a.g[0].out = dx;
     return a;
 }
@@ -860,7 +903,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
     a.Cout = L.Cout; a.Cin = L.Cin; a.KS = L.KS;
     a.dgrad = 0; a.CK = L.CK; a.nchunk = L.nchunk_f; a.M = L.Cout; a.Mp = L.Mp_f;
     a.dst = ws + L.wpf;
-    a.img = L.conv_path ? AVC_IMG_K4 : AVC_IMG_PLAIN;
+    a.img = L.conv_path ? (L.bh ? AVC_IMG_K4H : AVC_IMG_K4) : AVC_IMG_PLAIN;
     if (L.x3_f) {   // only the image the launch will read
         PackArgs r;
         avc_pack_x3_args(r, p->par(params, L.w[0]), L.Cout, L.Cin, L.KS, 0, ws + L.wrs_f);
@@ -897,7 +940,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
 }
 
 static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
-                  int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0) {
+                  int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0, bool pairs = false, int planar = 0) {
     // stats = [mean[Bfull*C] | rstd[Bfull*C]]; a sub-batch launch (b0, Bn) of a Bfull-sample tensor passes
     // y/out/res/cond already offset to sample b0
     if (Bfull == 0) Bfull = Bn;
@@ -905,17 +948,25 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
     a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = planar;
+    if (pairs) {
+        a.R = Bn * (C / 2);
+        return avc_launch_in_fwd_pairs(a, s);
+    }
     return avc_launch_in_fwd(a, s);
 }
 
 static int in_bwd(float slope, const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
-                  long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s) {
+                  long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s, bool pairs = false) {
     INBwdArgs a;
     a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
     a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0;
+    if (pairs) {
+        a.R = Bn * (C / 2);
+        return avc_launch_in_bwd_pairs(a, s);
+    }
     return avc_launch_in_bwd(a, s);
 }
 
@@ -927,31 +978,37 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
     // conv_bank (model.py:85-91): all bank members in ONE grouped launch writing the concat buffer in place
     const int B = p->B, T0 = e.T[0];
     const float SL = e.slope;
+    const bool bh = p->bh;
+    const long CCr = bh ? e.CC / 2 : e.CC, Cbr = bh ? e.c.c_bank / 2 : e.c.c_bank;   // rows per sample: pair rows with bh
+    float* tail = ws + e.cat + (long)e.nb * Cbr * T0;   // raw input last (model.py:90)
+    if (bh) RUN(avc_launch_to_pairs(x, sxb, sxc, sxt, B, e.c.c_in, T0, tail, CCr * T0, T0, s));   // ... as bf16 pairs, and the bank reads THAT copy
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
-    a.B = B; a.Cred = e.c.c_in; a.Tsrc = T0;
+    if (bh) { a.x.ptr = tail; a.x.sb = CCr * T0; a.x.sc = T0; a.x.st = 1; }
+    a.B = B; a.Cred = bh ? e.c.c_in / 2 : e.c.c_in; a.Tsrc = T0;
     a.mode = 0; a.stride = 1; a.bf16 = p->compute;
     a.M = e.c.c_bank; a.Mp = avc_cdiv(e.c.c_bank, 128) * 128; a.Tout = T0;
-    a.ob = (long)e.CC * T0; a.oc = T0; a.ot = 1; a.ops = 1;
+    a.ob = CCr * T0; a.oc = T0; a.ot = 1; a.ops = 1;
     a.act = 1;
     a.slope = SL;
     a.ngroups = e.nb;
-    a.img = AVC_IMG_K4;
+    a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
+    a.pairs = bh ? 1 : 0;
     for (int g = 0; g < e.nb; ++g) {
         const LayerP& L = p->layers[e.bank[g]];
         set_group(a.g[g], ws + L.wpf, p->par(params, L.b[0]), L.KS, L.CK, L.nchunk_f);
-        a.g[g].out = ws + e.cat + (long)g * e.c.c_bank * T0;
+        a.g[g].out = ws + e.cat + (long)g * Cbr * T0;
     }
     RUN(avc_launch_conv(a, s, 0, p->tun));
-    // raw input last (model.py:90)
-    RUN(avc_launch_copy_rows(x, sxb, sxc, sxt, B, e.c.c_in, T0, ws + e.cat + (long)e.nb * e.c.c_bank * T0, (long)e.CC * T0, T0, s));
+    if (!bh) RUN(avc_launch_copy_rows(x, sxb, sxc, sxt, B, e.c.c_in, T0, tail, (long)e.CC * T0, T0, s));
     return 0;
 }
 
 static int forward_impl(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
                         const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
     const int B = p->B;
+    const bool bh = p->bh;
     // 0. weights -> LDS-image order (they change every optimizer step)
     // The conv banks and in_convs open both encoder branches and run for ~1 ms: only their images
     // are packed up front; the rest is packed on a (forward-idle) wgrad stream under the bank convs.
@@ -984,11 +1041,13 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const hipStream_t s = sideS;
         const EncNet& e = p->spk;
         const float SL = e.slope;
-        const int C = e.c.c_h;
+        const int Cc = e.c.c_h;                       // channels
+        const long C = bh ? Cc / 2 : Cc;              // rows per sample of a [B, c_h, T] tensor (pair rows with bh): every stride below
+        const long CCr = bh ? e.CC / 2 : e.CC;
         RUN(enc_front(p, e, params, ws, xc, scb, scc, sct, s));
         {
             const LayerP& L = p->layers[e.in_conv];
-            ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
+            ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
@@ -1002,13 +1061,14 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             RUN(avc_launch_conv(b, s, 0, p->tun));
         }
         const int Tn = e.T[e.n];
-        RUN(avc_launch_timepool_fwd(ws + e.out[e.n], B, C, Tn, ws + e.pooled, s));
+        if (bh) RUN(avc_launch_timepool_fwd_pairs(ws + e.out[e.n], B, Cc, Tn, ws + e.pooled, s));
+        else RUN(avc_launch_timepool_fwd(ws + e.out[e.n], B, Cc, Tn, ws + e.pooled, s));
         // dense blocks + output layer: ONE fused launch (dense.hip); activations channel-major [C][B]
         {
             DenseArgs da;
             memset(&da, 0, sizeof(da));
             da.nlayers = 2 * e.nd + 1;
-            da.B = B; da.C = C; da.slope = SL;
+            da.B = B; da.C = Cc; da.slope = SL;
             da.in = ws + e.hd[0];
             da.emb = ws + p->emb;
             for (int l = 0; l < da.nlayers; ++l) {
@@ -1034,26 +1094,28 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     if (!spk_only) {
         const EncNet& e = p->enc;
         const float SL = e.slope;
-        const int C = e.c.c_h;
+        const int Cc = e.c.c_h;
+        const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
         RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
         {
-            ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, (long)e.CC * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
+            ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.h0, B, C, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s));
+            RUN(in_fwd(SL, ws + e.h0, B, Cc, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s, 0, 0, bh));
         }
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y1[l], B, C, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s));
+            RUN(in_fwd(SL, ws + e.y1[l], B, Cc, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s, 0, 0, bh));
             ConvArgs b = mk_fwd(p, SL, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
             const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
             RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y2[l], B, C, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s));
+            RUN(in_fwd(SL, ws + e.y2[l], B, Cc, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s, 0, 0, bh));
         }
         const int Tb = p->Tb;
         ConvArgs h = mk_fwd(p, SL, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
+        h.pairs = 0;   // mu | log_sigma stay fp32 (the loss and the reparameterisation read them)
         RUN(avc_launch_conv(h, s, 0, p->tun));
     }
 
@@ -1062,9 +1124,11 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     if (!spk_only) {
         const DecNet& d = p->dec;
         const float SL = d.slope;
-        const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb;
-        RUN(avc_launch_reparam_fwd(ws + p->muls, eps, B, Cz, Tb, ws + d.z, s));
-        const long csb = (long)2 * d.n * 2 * C;
+        const int Cc = d.c.c_h, Czc = d.c.c_in, Tb = p->Tb;
+        const long C = bh ? Cc / 2 : Cc, Cz = bh ? Czc / 2 : Czc;   // rows per sample (pair rows with bh)
+        if (bh) RUN(avc_launch_reparam_fwd_pairs(ws + p->muls, eps, B, Czc, Tb, ws + d.z, s));
+        else RUN(avc_launch_reparam_fwd(ws + p->muls, eps, B, Czc, Tb, ws + d.z, s));
+        const long csb = (long)2 * d.n * 2 * Cc;
         {   // all 2n AdaIN affine Linears as ONE GEMM on emb (they share their input)
             ConvArgs a = mk_fwd(p, SL, p->layers[d.affine], params, ws, ws + p->emb, 0, 1, d.c.c_cond, 1, B, ws + d.cond, 0, 1, (int)csb, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
@@ -1079,24 +1143,29 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             {
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, C, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0));
+                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, Cc, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0, bh));
             }
             for (int l = 0; l < d.n; ++l) {
                 const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
                 const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, C, Ti, cond, csb, (2 * l) * 2 * C, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0));
+                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, Cc, Ti, cond, csb, (2 * l) * 2 * Cc, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0, bh));
                 // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
                 ConvArgs b = mk_fwd(p, SL, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
                 b.ops = up;
+                if (bh) {   // the conv-output pairs [B][c_h up / 2][Ti] ARE the natural bf16 rows of the shuffled tensor: "planar" y2 (rowops_pairs.hip)
+                    b.ops = 1;
+                    b.ob = (long)C * To; b.oc = Ti;
+                }
                 RUN(avc_launch_conv(b, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, C, To, cond, csb, (2 * l + 1) * 2 * C, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
-                                    ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0));
+                RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, Cc, To, cond, csb, (2 * l + 1) * 2 * Cc, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                                    ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0, bh, (bh && up > 1) ? 1 : 0));
             }
             const int To = p->Tout;
             ConvArgs o = mk_fwd(p, SL, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
                                 ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
+            o.pairs = 0;   // dec is fp32 (the L1 loss / the caller read it)
             RUN(avc_launch_conv(o, s, 0, p->tun));
             return 0;
         };
@@ -1138,21 +1207,26 @@ extern "C" int avc_loss(const avc_plan* p, const float* x, long sxb, long sxc, i
 static int enc_back_front(BwdCtx& c, const EncNet& e, const float* x, long sxb, long sxc, int sxt, const float* dy_in) {
     // dy_in: gradient wrt the in_conv output [B, C, T0]
     const avc_plan* p = c.p;
-    const int B = p->B, C = e.c.c_h, T0 = e.T[0];
+    const bool bh = p->bh;
+    const int B = p->B, T0 = e.T[0];
+    const long C = bh ? e.c.c_h / 2 : e.c.c_h, CCr = bh ? e.CC / 2 : e.CC, Cbr = bh ? e.c.c_bank / 2 : e.c.c_bank;   // rows per sample (pair rows with bh)
     const float SL = e.slope;
     float* ws = c.ws;
     const LayerP& L = p->layers[e.in_conv];
-    RUN(wgrad_layer(c, L, ws + e.cat, (long)e.CC * T0, T0, 1, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0));
+    RUN(wgrad_layer(c, L, ws + e.cat, CCr * T0, T0, 1, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0));
     if (!c.dry) {
         // d(cat) for the bank channels only, masked by the bank ReLU (cat > 0)
-        ConvArgs a = mk_dgrad(SL, L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, (long)e.CC * T0, T0, 1);
+        ConvArgs a = mk_dgrad(SL, L, ws, dy_in, (long)C * T0, T0, 1, 1, B, T0, T0, nullptr, CCr * T0, T0, 1);
         a.g[0].out2 = ws + e.dcat;
         a.g[0].mask = ws + e.cat;
         RUN(avc_launch_conv(a, c.s, 0, p->tun));
     }
     for (int g = 0; g < e.nb; ++g) {
         const LayerP& Lb = p->layers[e.bank[g]];
-        RUN(wgrad_layer(c, Lb, x, sxb, sxc, sxt, ws + e.dcat + (long)g * e.c.c_bank * T0, (long)e.CC * T0, T0, 1, 1, B, T0, T0));
+        if (bh)   // the bank read the pair copy of the input at the tail of the concat buffer
+            RUN(wgrad_layer(c, Lb, ws + e.cat + (long)e.nb * Cbr * T0, CCr * T0, T0, 1, ws + e.dcat + (long)g * Cbr * T0, CCr * T0, T0, 1, 1, B, T0, T0));
+        else
+            RUN(wgrad_layer(c, Lb, x, sxb, sxc, sxt, ws + e.dcat + (long)g * e.c.c_bank * T0, (long)e.CC * T0, T0, 1, 1, B, T0, T0));
     }
     return 0;
 }
@@ -1168,6 +1242,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     c.wstream = overlap ? p->wstream[0] : s;
     c.red.s = s; c.red.dry = dry;
     const int B = p->B;
+    const bool bh = p->bh;
     float* gA = ws + p->gA;
     float* gB = ws + p->gB;
     float* gC = ws + p->gC;
@@ -1179,9 +1254,15 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     {
         const DecNet& d = p->dec;
         const float SL = d.slope;
-        const int C = d.c.c_h, Cz = d.c.c_in, Tb = p->Tb, To = p->Tout;
-        const long csb = (long)2 * d.n * 2 * C;
+        const int Cc = d.c.c_h, Czc = d.c.c_in, Tb = p->Tb, To = p->Tout;
+        const long C = bh ? Cc / 2 : Cc, Cz = bh ? Czc / 2 : Czc;   // rows per sample (pair rows with bh): every stride / offset below
+        const long Mr = bh ? p->M / 2 : p->M;
+        const long csb = (long)2 * d.n * 2 * Cc;
         const float* ddec = d_dec ? d_dec : ws + p->ddec;
+        if (bh) {   // the conv launches read pair operands: d(dec) (fp32: written by avc_loss or handed in by the autograd seam) -> pairs
+            if (!dry) RUN(avc_launch_to_pairs(ddec, (long)p->M * To, To, 1, B, p->M, To, ws + p->ddecp, Mr * To, To, s));
+            ddec = ws + p->ddecp;
+        }
         const LayerP& Lo = p->layers[d.out_conv];
         const LayerP& Li = p->layers[d.in_conv];
         // every dy a weight-gradient launch reads gets its own buffer (the launches run later, beside the encoders' backward)
@@ -1200,29 +1281,35 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             float* gA = ws + p->gA;
             float* gB = ws + p->gB;
             float* gC = ws + p->gC;
-            auto half_in_bwd = [&](const float* g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy) -> int {
+            auto half_in_bwd = [&](const float* g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy, int planar = 0) -> int {
                 INBwdArgs a;
                 a.g = g + off; a.y = ws + yoff + off;
-                a.mean = ws + stoff + (long)b0 * C; a.rstd = ws + stoff + (long)B * C + (long)b0 * C;
+                a.mean = ws + stoff + (long)b0 * Cc; a.rstd = ws + stoff + (long)B * Cc + (long)b0 * Cc;
                 a.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.cond_sb = csb; a.cond_off = coff;
                 a.dy = dy + off; a.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.dcond_sb = csb; a.dcond_off = coff;
-                a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = SL; a.planar = 0;
+                a.R = Bn * Cc; a.C = Cc; a.T = T; a.relu = 1; a.slope = SL; a.planar = planar;
+                if (bh) {
+                    a.R = Bn * (Cc / 2);
+                    return avc_launch_in_bwd_pairs(a, s);
+                }
                 return avc_launch_in_bwd(a, s);
             };
             {
-                const long oi = (long)b0 * p->M * To, oo = (long)b0 * C * To;
-                ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, (long)p->M * To, To, 1, 1, Bn, To, To, gA + oo, (long)C * To, To, 1);
+                const long oi = (long)b0 * Mr * To, oo = (long)b0 * C * To;
+                ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, Mr * To, To, 1, 1, Bn, To, To, gA + oo, (long)C * To, To, 1);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             for (int l = d.n - 1; l >= 0; --l) {
                 const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
                 const long o2 = (long)b0 * C * T2, o1 = (long)b0 * C * Ti;
-                RUN(half_in_bwd(gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * C, true, dy2[l]));
+                RUN(half_in_bwd(gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * Cc, true, dy2[l], (bh && up > 1) ? 1 : 0));
                 {   // dy2 is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
-                    ConvArgs a = mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1);
+                    // (pair plans: dy2 was written planar = as the conv-output pairs [B][c_h up / 2][Ti], a plain stride-1 source)
+                    ConvArgs a = bh ? mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, Ti, 1, 1, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1)
+                                    : mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1);
                     RUN(avc_launch_conv(a, s, 0, p->tun));
                 }
-                RUN(half_in_bwd(gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * C, true, dy1[l]));
+                RUN(half_in_bwd(gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
                 {
                     ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, gC + o1, (long)C * Ti, Ti, 1);
                     set_res(a, gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
@@ -1232,7 +1319,8 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             }
             const long ob = (long)b0 * C * Tb;
             RUN(half_in_bwd(gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
-            ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Cz * Tb, (long)Cz * Tb, Tb, 1);
+            ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Czc * Tb, (long)Czc * Tb, Tb, 1);
+            a.pairs = 0;   // d(z) is fp32: the latent backward combines it with the fp32 mu / log_sigma
             RUN(avc_launch_conv(a, s, 0, p->tun));
             return 0;
         };
@@ -1248,10 +1336,11 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             }
         }
         // the weight gradients of the decoder (recorded; launched in batches on the wgrad stream, flush_wgrads)
-        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, (long)p->M * To, To, 1, 1, B, To, To));
+        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, Mr * To, To, 1, 1, B, To, To));
         for (int l = d.n - 1; l >= 0; --l) {
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
-            RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, T2, up, up, B, Ti, Ti));
+            if (bh) RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, Ti, 1, 1, B, Ti, Ti));
+            else RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, T2, up, up, B, Ti, Ti));
             RUN(wgrad_layer(c, p->layers[d.c1[l]], ws + d.out[l], (long)C * Ti, Ti, 1, dy1[l], (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
         }
         RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dy0, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
@@ -1268,7 +1357,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             w.x.ptr = ws + d.dcond; w.x.sb = 0; w.x.sc = csb; w.x.st = 1; w.x.ps = 1;
             w.dy.ptr = ws + La.wplain; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
-            w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = p->compute;
+            w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = bh ? AVC_COMPUTE_BF16 : p->compute;   // (fp32-stored operands either way)
             avc_wgrad_plan_batch(&w, 1, 256);
             const long wsz = (long)w.Cout * w.Cin;
             const long off = c.slab_used;
@@ -1284,8 +1373,9 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
         // latent: KL term + reparameterisation (solver.py:86, model.py:384)
         if (!dry) {
-            float lk = lambda_kl / (float)((long)B * Cz * Tb);
-            RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Cz, Tb, lk, ws + p->dmuls, s));
+            float lk = lambda_kl / (float)((long)B * Czc * Tb);
+            RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Czc, Tb, lk, ws + p->dmuls, s));
+            if (bh) RUN(avc_launch_to_pairs(ws + p->dmuls, (long)2 * Czc * Tb, Tb, 1, B, 2 * Czc, Tb, ws + p->dmulsp, (long)Czc * Tb, Tb, s));
         }
         RUN(flush_wgrads(c));  // decoder gradients are complete
         // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
@@ -1308,7 +1398,8 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         auto rot = [&]() { float* t = gA; gA = gC; gC = t; };
         const EncNet& e = p->spk;
         const float SL = e.slope;
-        const int C = e.c.c_h;
+        const int Cc = e.c.c_h;
+        const long C = bh ? Cc / 2 : Cc;   // rows per sample of the [B, c_h, T] tensors (pair rows with bh)
         float* dhA = ws + p->dhA;
         const LayerP& Lo = p->layers[e.outl];
         // output layer + dense blocks: ONE fused dgrad launch produces every dz (and d pooled);
@@ -1317,7 +1408,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             DenseArgs da;
             memset(&da, 0, sizeof(da));
             da.nlayers = 2 * e.nd + 1;
-            da.B = B; da.C = C; da.slope = SL;
+            da.B = B; da.C = Cc; da.slope = SL;
             da.in = ws + p->demb;      // [c_out][B] channel-major
             da.in2 = nullptr;           // (upstream d_emb is already folded into demb above)
             da.dpooled = dhA;
@@ -1328,7 +1419,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 DenseLayer& D = da.layer[l];
                 D.wp = ws + L.wpd;
                 D.Cin = L.Cin; D.Cout = L.Cout; D.Kp = L.nchunk_d * L.CKd; D.Mp = L.Mp_d;
-                dzl[l] = last ? nullptr : c.fresh((long)C * B);
+                dzl[l] = last ? nullptr : c.fresh((long)Cc * B);
                 if (!last) {
                     D.act = ws + ((l & 1) ? e.d2[l / 2] : e.d1[l / 2]);
                     D.dz = dzl[l];
@@ -1352,7 +1443,10 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
         dyA = c.fresh((long)B * C * Tn);
-        if (!dry) RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, C, Tn, gA, dyA, SL, s));
+        if (!dry) {
+            if (bh) RUN(avc_launch_timepool_bwd_pairs(dhA, ws + e.a2[e.n - 1], B, Cc, Tn, gA, dyA, SL, s));
+            else RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, Cc, Tn, gA, dyA, SL, s));
+        }
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
             const LayerP& L1 = p->layers[e.c1[l]];
@@ -1389,11 +1483,13 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     {
         const EncNet& e = p->enc;
         const float SL = e.slope;
-        const int C = e.c.c_h, Tb = p->Tb, Co2 = 2 * e.c.c_out;
+        const int Cc = e.c.c_h, Tb = p->Tb;
+        const long C = bh ? Cc / 2 : Cc, Co2 = bh ? e.c.c_out : 2 * e.c.c_out;   // rows per sample (pair rows with bh)
+        const float* dmuls = ws + (bh ? p->dmulsp : p->dmuls);
         const LayerP& Lh = p->layers[e.heads];
-        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
+        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
         if (!dry) {
-            ConvArgs a = mk_dgrad(SL, Lh, ws, ws + p->dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
+            ConvArgs a = mk_dgrad(SL, Lh, ws, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = e.n - 1; l >= 0; --l) {
@@ -1401,14 +1497,14 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const LayerP& L1 = p->layers[e.c1[l]];
             const LayerP& L2 = p->layers[e.c2[l]];
             dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, C, T2, nullptr, 0, 0, dyA, nullptr, s));
+            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, Cc, T2, nullptr, 0, 0, dyA, nullptr, s, bh));
             if (!dry) {
                 ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
             dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, C, Ti, nullptr, 0, 0, dyB, nullptr, s));
+            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, Cc, Ti, nullptr, 0, 0, dyB, nullptr, s, bh));
             if (!dry) {
                 ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
@@ -1418,7 +1514,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         dyA = c.fresh((long)B * C * e.T[0]);
-        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, C, e.T[0], nullptr, 0, 0, dyA, nullptr, s));
+        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
         RUN(flush_wgrads(c));
     }

@@ -192,7 +192,7 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     memset(&a, 0, sizeof(a));
     {
         const avc_tuning& t = avc_op_tuning();
-        a.bf16 = (t.op_compute_dtype == AVC_COMPUTE_F32 && t.wgrad_x3) ? AVC_COMPUTE_F32X3 : t.op_compute_dtype;
+        a.bf16 = (t.op_compute_dtype == AVC_COMPUTE_F32 && t.wgrad_x3) ? AVC_COMPUTE_F32X3 : (op_bh() ? AVC_COMPUTE_BF16S : t.op_compute_dtype);
     }
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;

@@ -64,11 +64,25 @@ def _on(t):
     return torch.cuda.device(t.device) if (t is not None and t.is_cuda) else contextlib.nullcontext()
 
 
+def unpack_pairs(p):
+    """bf16 pair tensor (int32 [B, C/2, T]: channel 2p in the low half, 2p + 1 in the high half) -> fp32 [B, C, T]"""
+    lo = (p & 0xFFFF).to(torch.int16).view(torch.bfloat16).to(torch.float32)
+    hi = ((p >> 16) & 0xFFFF).to(torch.int16).view(torch.bfloat16).to(torch.float32)
+    return torch.stack((lo, hi), dim=2).reshape(p.shape[0], 2 * p.shape[1], p.shape[2])
+
+
+def unpack_planar(p):
+    """natural bf16 rows (int32 [B, C, T/2]: frames 2i, 2i + 1 per dword) -> fp32 [B, C, T]"""
+    lo = (p & 0xFFFF).to(torch.int16).view(torch.bfloat16).to(torch.float32)
+    hi = ((p >> 16) & 0xFFFF).to(torch.int16).view(torch.bfloat16).to(torch.float32)
+    return torch.stack((lo, hi), dim=3).reshape(p.shape[0], p.shape[1], 2 * p.shape[2])
+
+
 class Plan:
     """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
     tests may inject the CPU lane-level simulation build instead."""
 
-    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp32x3": 0, "f32x3": 0}
+    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp32x3": 0, "f32x3": 0, "bf16s": 3, "bf16_storage": 3}
 
     def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None, tuning=None):
         """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
@@ -93,6 +107,9 @@ class Plan:
         x3 = key in ("fp32x3", "f32x3")
         if x3:
             flags |= _lib.PLAN_X3
+        bh = self.COMPUTE[key] == 3
+        if bh:
+            flags |= _lib.PLAN_BF16S
         self.tuning = dict(tuning or {})
         tun = _lib.make_tuning(self.lib, self.tuning)
         with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
@@ -100,8 +117,9 @@ class Plan:
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
-        self.compute_dtype = "fp32x3" if x3 else ("bf16" if self.COMPUTE[key] else "fp32")
-        if self.lib.avc_plan_set_compute_dtype(h, self.COMPUTE[key]) != 0:
+        self.compute_dtype = "fp32x3" if x3 else ("bf16s" if bh else ("bf16" if self.COMPUTE[key] else "fp32"))
+        self.pair_storage = bh
+        if not bh and self.lib.avc_plan_set_compute_dtype(h, self.COMPUTE[key]) != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.num_params = self.lib.avc_plan_num_params(h)
         self.param_floats = self.lib.avc_plan_param_floats(h)
@@ -171,12 +189,20 @@ class Plan:
             self.lib.avc_plan_relu_site(self.h, i, C.byref(s))
             B, Cc, T = s.B, s.C, s.T
             if s.kind == 0:
-                act = torch.as_strided(ws, (B, Cc, T), (s.sb, s.sc, s.st), s.act_off)
+                if s.storage == 1:
+                    act = unpack_pairs(torch.as_strided(ws.view(torch.int32), (B, Cc // 2, T), (s.sb, s.sc, s.st), s.act_off))
+                else:
+                    act = torch.as_strided(ws, (B, Cc, T), (s.sb, s.sc, s.st), s.act_off)
                 m = act > 0
                 if T == 1 and s.st == 0:
                     m = m.reshape(B, Cc)
             else:
-                y = ws[s.y_off:s.y_off + B * Cc * T].view(B, Cc, T)
+                if s.storage == 1:
+                    y = unpack_pairs(ws.view(torch.int32)[s.y_off:s.y_off + B * (Cc // 2) * T].view(B, Cc // 2, T))
+                elif s.storage == 2:
+                    y = unpack_planar(ws.view(torch.int32)[s.y_off:s.y_off + B * Cc * (T // 2)].view(B, Cc, T // 2))
+                else:
+                    y = ws[s.y_off:s.y_off + B * Cc * T].view(B, Cc, T)
                 mean = ws[s.stat_off:s.stat_off + B * Cc].view(B, Cc, 1)
                 rstd = ws[s.stat_off + B * Cc:s.stat_off + 2 * B * Cc].view(B, Cc, 1)
                 xh = ((y - mean) * rstd).double()      # the same two fp32 roundings as the kernel

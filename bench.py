@@ -74,27 +74,39 @@ def profile_classes(solver, x, eps, steps):
     return out
 
 
-def instnorm_dominant_shape(B, C, T, launches=50):
+def instnorm_dominant_shape(B, C, T, launches=50, pairs=False):
     """IN/AdaIN/ReLU forward + backward at the dominant shape [B, C, T] of the step: `launches`
-    back-to-back launches between two HIP events on the launch stream (no per-launch bracket)."""
+    back-to-back launches between two HIP events on the launch stream (no per-launch bracket).
+    pairs: the bf16 pair-row kernels of compute_dtype "bf16s" (2 bytes per element)."""
     from adaptive_voice_conversion_amd import _lib
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    nb = 8  # rotate buffers: 8 x 3 x 16.8 MB > 256 MiB Infinity Cache at the bench shape
-    ys = [torch.randn(B, C, T, device=dev) for _ in range(nb)]
-    outs = [torch.empty_like(y) for y in ys]
-    gs = [torch.randn_like(y) for y in ys]
+    nb = 16 if pairs else 8  # rotate buffers: 8 x 3 x 16.8 MB > 256 MiB Infinity Cache at the bench shape
+    if pairs:   # dword tensors [B][C/2][T]: any bit pattern of finite bf16 pairs will do
+        ys = [torch.randn(B, C, T, device=dev).to(torch.bfloat16).view(torch.int32).view(B, C // 2, T) for _ in range(nb)]
+        outs = [torch.empty_like(y) for y in ys]
+        gs = [torch.randn(B, C, T, device=dev).to(torch.bfloat16).view(torch.int32).view(B, C // 2, T) for _ in range(nb)]
+    else:
+        ys = [torch.randn(B, C, T, device=dev) for _ in range(nb)]
+        outs = [torch.empty_like(y) for y in ys]
+        gs = [torch.randn_like(y) for y in ys]
     cond = torch.randn(B, 2 * C, device=dev)
     mean, rstd = torch.empty(B * C, device=dev), torch.empty(B * C, device=dev)
     dcond = torch.zeros(B, 2 * C, device=dev)
 
     def fwd(k):
-        lib.avc_instnorm_fwd(P(ys[k]), B, C, T, P(cond), 2 * C, 0, 1, None, 0, 0, P(outs[k]), P(mean), P(rstd), st)
+        if pairs:
+            lib.avc_instnorm_fwd_pairs(P(ys[k]), B, C, T, P(cond), 2 * C, 0, 1, None, 0, 0, 0, P(outs[k]), P(mean), P(rstd), st)
+        else:
+            lib.avc_instnorm_fwd(P(ys[k]), B, C, T, P(cond), 2 * C, 0, 1, None, 0, 0, P(outs[k]), P(mean), P(rstd), st)
 
     def bwd(k):
-        lib.avc_instnorm_bwd(P(gs[k]), P(ys[k]), P(mean), P(rstd), B, C, T, P(cond), 2 * C, 0, 1, P(outs[k]), P(dcond), 2 * C, 0, st)
+        if pairs:
+            lib.avc_instnorm_bwd_pairs(P(gs[k]), P(ys[k]), P(mean), P(rstd), B, C, T, P(cond), 2 * C, 0, 1, 0, P(outs[k]), P(dcond), 2 * C, 0, st)
+        else:
+            lib.avc_instnorm_bwd(P(gs[k]), P(ys[k]), P(mean), P(rstd), B, C, T, P(cond), 2 * C, 0, 1, P(outs[k]), P(dcond), 2 * C, 0, st)
 
     res = {}
     for name, fn, passes in (("fwd", fwd, 2), ("bwd", bwd, 3)):
@@ -108,7 +120,8 @@ def instnorm_dominant_shape(B, C, T, launches=50):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / launches
-        res[name] = dict(avg_launch_us=us, bytes_per_launch=passes * 4.0 * B * C * T, gbs=passes * 4.0 * B * C * T / us / 1e3)
+        esz = 2.0 if pairs else 4.0
+        res[name] = dict(avg_launch_us=us, bytes_per_launch=passes * esz * B * C * T, gbs=passes * esz * B * C * T / us / 1e3)
     return res
 
 
@@ -395,6 +408,8 @@ def dsp_bench(a, dev):
 def workload_label(a, world):
     """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
     prec = {"f32": "fp32", "bf16": "bf16 matrix products (fp32 accumulate, fp32 master weights and optimizer state)",
+            "bf16s": "bf16 matrix products AND bf16 storage of activations / activation gradients (fp32 accumulate and statistics, fp32 master "
+                     "weights and optimizer state)",
             "f32x3": "fp32 storage and results; the big conv / weight-gradient products from three bf16 terms per operand on the bf16 matrix core "
                      "(fp32-level accuracy, opt-in; DESIGN 3.5) -- NOT the headline precision path"}[a.dtype]
     if a.mode == "infer":
@@ -404,7 +419,7 @@ def workload_label(a, world):
     else:
         idx = None
         if a.mels == 80 and a.frames == 128 and a.batch == 256:
-            idx = {"f32": 1, "bf16": 2}.get(a.dtype)
+            idx = {"f32": 1, "bf16": 2, "bf16s": 2}.get(a.dtype)
         elif a.mels == 80 and a.frames == 1024 and a.batch == 64 and a.dtype == "f32":
             idx = 4
         what = (f"recon+KL train step (fwd, loss, bwd, {'RCCL all-reduce, ' if world > 1 else ''}clip, Adam-amsgrad), "
@@ -444,7 +459,7 @@ def main():
                     help="train = BASELINE configs[1]/[4]-style train step (the headline metric); infer = configs[3] one-shot conversion; "
                          "dsp = the mel <-> waveform back end of a conversion (SURVEY §8f row 4; not a BASELINE.json config)")
     ap.add_argument("--seconds", type=float, default=5.0, help="--mode dsp: length of the synthetic utterance")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s", "f32x3"), default="f32",
                     help="f32 = the headline (BASELINE configs[1]); bf16 = configs[2]'s compute mode (bf16 matrix products, "
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -509,6 +524,8 @@ def main():
     cfg = stock_config(a.mels)
     if a.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
+    if a.dtype == "bf16s":   # configs[2] with bf16 storage (bf16 channel-pair tensors)
+        cfg["compute_dtype"] = "bf16s"
     if a.dtype == "f32x3":   # opt-in: fp32-accurate products from three bf16 terms on the bf16 matrix core
         cfg["compute_dtype"] = "fp32x3"
     torch.manual_seed(0)
@@ -614,7 +631,7 @@ def main():
             dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
             d = prof[dom]
             # f32x3: six 8-pass bf16 MFMAs per 16 reduction steps -> the matrix pipe's ceiling for these products is the bf16 peak / 6
-            peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
+            peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16s": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
             traffic, tsrc = pmc_class_traffic(dom) if (cfg_idx == 1) else (None, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
                                "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
@@ -629,7 +646,7 @@ def main():
             ib = [prof[k] for k in ("instnorm_fwd", "instnorm_bwd") if k in prof]
             if ib:
                 C = cfg["ContentEncoder"]["c_h"]
-                dom_s = instnorm_dominant_shape(B, C, T)
+                dom_s = instnorm_dominant_shape(B, C, T, pairs=(a.dtype == "bf16s"))
                 bts = dom_s["fwd"]["bytes_per_launch"] + dom_s["bwd"]["bytes_per_launch"]
                 us = dom_s["fwd"]["avg_launch_us"] + dom_s["bwd"]["avg_launch_us"]
                 gbs = bts / us / 1e3
@@ -637,7 +654,7 @@ def main():
                 tot_ms = sum(p["ms_per_step"] for p in ib)
                 tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
                 tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
-                have = bool(tf and tb and B == 256 and T == 128)
+                have = bool(tf and tb and B == 256 and T == 128 and a.dtype != "bf16s")
                 out["roofline_instnorm"] = {
                     "kernel": f"instnorm_fwd + instnorm_bwd (IN/AdaIN/ReLU) at the dominant shape [{B},{C},{T}]",
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,

@@ -103,6 +103,8 @@ typedef struct avc_relu_site {
     int kind, B, C, T;
     long act_off, sb, sc, st;
     long y_off, stat_off, cond_off, cond_sb;
+    long storage;   /* 0: fp32 tensors; AVC_PLAN_BF16S plans: 1 = bf16 pair tensor at act_off / y_off (dwords [B][C/2][T], sb / sc in dwords),
+                     * 2 = natural bf16 rows [B][C][T] at y_off (the output of a pixel-shuffling conv) */
 } avc_relu_site;
 int avc_plan_num_relu_sites(const avc_plan* p);
 int avc_plan_relu_site(const avc_plan* p, int i, avc_relu_site* out);
@@ -148,6 +150,13 @@ void avc_tuning_init(avc_tuning* t);
  * (tuning->conv_x3 = 1, wgrad_x3 = 1 unless the caller's tuning already asks for more). */
 #define AVC_PLAN_X3 4
 #define AVC_PLAN_RAGGED 8   /* set by avc_plan_create_ragged (reported by avc_plan_flags) */
+/* AVC_PLAN_BF16S = compute mode "bf16" with bf16 STORAGE (BASELINE configs[2]: bf16 compute, fp32 master weights and optimizer state):
+ * every [B, C, T] activation and activation gradient in the workspace is a bf16 channel-pair tensor (dwords [B][C/2][T], see "bf16
+ * PAIR storage" below), conv / Linear products run on v_mfma_f32_32x32x16_bf16 from bf16 pair weight images, accumulation, InstanceNorm
+ * statistics, mu / log_sigma, dec, emb, the AdaIN affine parameters, all parameter gradients and the optimizer stay fp32.  Inputs and
+ * outputs of the entry points keep their fp32 types.  Needs even channel counts and frame counts that are multiples of 4 at every level
+ * (-2 otherwise); avc_plan_compute_dtype reports 3; avc_plan_buffer offsets of activation tensors then address pair tensors. */
+#define AVC_PLAN_BF16S 16
 int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out);
 /* profiling aid on an existing plan: 1 = every kernel of this plan on the caller's stream */
 int avc_plan_set_single_stream(avc_plan* p, int on);

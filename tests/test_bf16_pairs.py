@@ -316,3 +316,57 @@ def test_to_pairs_of_transposed_view(kind):
     dst = torch.zeros(2, 3, 9, dtype=torch.int32, device=dev)
     assert lib.avc_to_pairs(P(x), x.stride(0), x.stride(1), x.stride(2), 2, 6, 9, P(dst), None) == 0
     torch.testing.assert_close(from_pairs(dst.cpu()), bf16r(x.cpu()), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight gradient
+# ---------------------------------------------------------------------------------------------------------------
+WG = [
+    # B, Cin, Cout, T, KS, stride
+    (2, 32, 32, 32, 5, 1),
+    (3, 24, 40, 20, 5, 2),
+    (2, 70, 34, 21, 5, 2),
+    (1, 16, 32, 70, 5, 1),
+    (2, 8, 32, 19, 8, 1),
+    (1, 40, 32, 33, 1, 1),
+    (9, 16, 32, 3, 5, 1),
+    (2, 130, 40, 40, 1, 1),      # 1x1 with the 128x128 four-accumulator tile
+    (2, 80, 32, 64, 4, 1),       # Cin = 80: 128co x 32ci tile, whole chunks
+    (8, 16, 32, 16, 5, 1),       # whole short samples per chunk
+    (8, 16, 32, 32, 5, 2),
+    (7, 16, 32, 16, 5, 1),
+    (4, 64, 64, 64, 5, 1),       # whole 32-column chunks (ds_read_b128 path)
+    pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
+    pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
+    pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
+    pytest.param(8, 1104, 128, 128, 1, 1, marks=GPU),
+    pytest.param(8, 80, 128, 128, 8, 1, marks=GPU),
+    pytest.param(2, 128, 128, 1024, 5, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", WG)
+def test_pairs_conv_wgrad(kind, B, Cin, Cout, T, KS, stride):
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 31 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin, KS, generator=g, dtype=torch.float64) / (Cin * KS) ** 0.5).requires_grad_(True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = O.pad_conv(bf16r(x).double(), w, b, stride)
+    dy = torch.randn(y.shape, generator=g)
+    dw_ref, db_ref = torch.autograd.grad(y, [w, b], bf16r(dy).double())
+    To = y.shape[2]
+    ws = torch.full((lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, To, KS),), float("nan"), device=dev)
+    dW = torch.full((Cout, Cin, KS), float("nan"), device=dev)
+    db = torch.full((Cout,), float("nan"), device=dev)
+    xd, dyd = to_pairs(x).to(dev), to_pairs(dy).to(dev)
+    with op_dtype(lib, 3):
+        rc = lib.avc_conv1d_wgrad(P(xd), xd.stride(0), xd.stride(1), 1, P(dyd), dyd.stride(0), dyd.stride(1), 1, 1, B, Cin, Cout, T, To, KS, stride,
+                                  P(dW), P(db), P(ws), None)
+    assert rc == 0, rc
+    scale = dw_ref.abs().max().item()
+    torch.testing.assert_close(dW.cpu(), dw_ref.float(), rtol=1e-4, atol=1e-5 * max(1.0, scale))     # fp32 accumulation of exact bf16 products
+    torch.testing.assert_close(db.cpu(), db_ref.float(), rtol=1e-4, atol=1e-4)
