@@ -167,6 +167,7 @@ struct INFwdArgs {
     int R, C, T, relu;
     float slope;
     int planar;         // pair kernels (rowops_pairs.hip): y rows are natural bf16 rows (the output of a pixel-shuffling conv)
+    int nv_hint;        // pair kernels: 16-byte vectors per lane (avc_tuning.in_pairs_nv)
 };
 
 // ragged InstanceNorm forward (ragged_rows.hip): packed [C][T_b] blocks, see ConvRag
@@ -201,6 +202,7 @@ struct INBwdArgs {
     int R, C, T, relu;
     float slope;
     int planar;       // pair kernels: y and dy rows are natural bf16 rows
+    int nv_hint;
 };
 
 struct AdamArgs {

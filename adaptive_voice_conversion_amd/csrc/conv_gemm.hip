@@ -47,6 +47,11 @@
 #ifndef AVC_CONV_STAGES
 #define AVC_CONV_STAGES 2
 #endif
+// ... of the bf16 pair-storage instances (BF == 2): their chunks hold 1/8 of the matrix-pipe time of an fp32 chunk, the LDS-DMA round trip
+// is what a workgroup waits for
+#ifndef AVC_CONV_STAGES_BH
+#define AVC_CONV_STAGES_BH 2
+#endif
 
 // s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (here: LDS-DMA loads, which complete in issue order)
 // still outstanding; lgkmcnt / expcnt untouched.  gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0].
@@ -248,7 +253,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     const int AS = KS * CK * BM;  // floats per A stage
     const int XS = CK * ROW;      // floats per X stage
-    constexpr int NS = AVC_CONV_STAGES;              // chunk c + 2 is in flight while chunk c multiplies (see the main loop)
+    constexpr int NS = (BF == 2) ? AVC_CONV_STAGES_BH : AVC_CONV_STAGES;   // chunk c + NS - 1 is in flight while chunk c multiplies (see the main loop)
     float* As = smem + kg * NS * AS;                 // this group's A stages
     float* Xs = smem + KG * NS * AS + kg * NS * XS;  // ... and X stages
 
@@ -638,7 +643,7 @@ static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     for (int gi = 0; gi < a.ngroups; ++gi) {
         ConvGeom q = conv_geom(a.mode, a.stride, a.Tout, a.g[gi].KS, BN, 0);
         size_t AS = (size_t)a.g[gi].KS * a.g[gi].CK * BM, XS = (size_t)a.g[gi].CK * q.ROW;
-        size_t bytes = (size_t)AVC_CONV_STAGES * (AS + XS) * 4;
+        size_t bytes = (size_t)(a.bf16 == AVC_COMPUTE_BF16S ? AVC_CONV_STAGES_BH : AVC_CONV_STAGES) * (AS + XS) * 4;
         worst = bytes > worst ? bytes : worst;
     }
     return worst + 16;
@@ -727,7 +732,9 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     dim3 grid(rag ? a.rag.ntiles : conv_ntiles_n(a, BN), a.Mp / BM, a.ngroups);
     // split-K groups: only where the grid leaves CUs or SIMD slots idle (<= 1 workgroup per CU)
     int kgroups = 1;
-    if (!rag && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
+    // (bf16 pair storage: the small layers are bound by launch / prologue latency, a second wave group only adds to it -- measured,
+    // profiles/r03_bf16s_tune.log)
+    if (!rag && a.bf16 != AVC_COMPUTE_BF16S && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
     if (lds > 160 * 1024) return -5;
     dim3 block(AVC_THREADS * kgroups);

@@ -195,9 +195,10 @@ static void finish_layer(avc_plan* p, LayerP& L, bool need_dgrad, int dgM, int B
     L.CK = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(tf, L.Mp_f, Bn, Tf, ngroups), 0, L.stride, Tf, tf);
     int td = avc_conv_pick_tile(tun, L.Mp_d, Bn, Td, 1, L.Cout * L.KS);
     L.CKd = avc_conv_ck_for(tun, L.KS, avc_conv_num_wgs(td, L.Mp_d, Bn, Td, 1), 1, L.stride, Td, td);
-    if (L.bh && L.KS >= 4 && ngroups == 1) {   // a chunk of 8 dword channels is 5 short MFMAs per barrier: take 16 (32 reduction channels)
-        L.CK = L.CK < 16 ? 16 : L.CK;
-        L.CKd = L.CKd < 16 ? 16 : L.CKd;
+    if (L.bh && L.KS >= 4 && ngroups == 1) {   // chunk depth in dword channels (tuning bh_ck5; measured: 8 beats 16 beats 32 on the step)
+        const int want = (tun.bh_ck5 == 16 || tun.bh_ck5 == 32) ? (int)tun.bh_ck5 : 8;
+        L.CK = want;
+        L.CKd = want;
     }
     L.nchunk_f = avc_cdiv(L.bh ? L.Cin / 2 : L.Cin, L.CK);
     L.nchunk_d = avc_cdiv(L.bh ? L.Cout / 2 : L.Cout, L.CKd);
@@ -402,13 +403,14 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     // ---- activations.  Inference plans (AVC_PLAN_INFERENCE) keep only what the forward pass touches;
     // speaker-only plans (AVC_PLAN_SPEAKER_ONLY) only the speaker encoder's buffers.
     const long Bl = B;
+    const long H = p->bh ? 2 : 1;   // a stored [B, C, T] activation takes C / H dword rows per sample (bf16 pairs: half the floats)
     auto alloc_enc = [&](EncNet& e, bool spk) {
-        const long C = e.c.c_h;
-        e.cat = p->alloc(Bl * e.CC * e.T[0]);
-        if (!infer) e.dcat = p->alloc(Bl * e.CC * e.T[0]);
+        const long C = e.c.c_h / H;
+        e.cat = p->alloc(Bl * (e.CC / H) * e.T[0]);
+        if (!infer) e.dcat = p->alloc(Bl * (e.CC / H) * e.T[0]);
         e.h0 = p->alloc(Bl * C * e.T[0]);
         e.out[0] = spk ? e.h0 : p->alloc(Bl * C * e.T[0]);
-        if (!spk) e.st0 = p->alloc(2 * Bl * C);
+        if (!spk) e.st0 = p->alloc(2 * Bl * e.c.c_h);
         for (int l = 0; l < e.n; ++l) {
             e.a1[l] = p->alloc(Bl * C * e.T[l]);
             e.out[l + 1] = p->alloc(Bl * C * e.T[l + 1]);
@@ -419,17 +421,18 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
                 e.a2[l] = -1;
                 e.y1[l] = p->alloc(Bl * C * e.T[l]);
                 e.y2[l] = p->alloc(Bl * C * e.T[l + 1]);
-                e.st1[l] = p->alloc(2 * Bl * C);
-                e.st2[l] = p->alloc(2 * Bl * C);
+                e.st1[l] = p->alloc(2 * Bl * e.c.c_h);
+                e.st2[l] = p->alloc(2 * Bl * e.c.c_h);
             }
         }
-        if (spk) {
-            e.pooled = p->alloc(C * Bl);
+        if (spk) {   // (the dense stack is fp32)
+            const long Cf = e.c.c_h;
+            e.pooled = p->alloc(Cf * Bl);
             e.hd[0] = e.pooled;
             for (int l = 0; l < e.nd; ++l) {
-                e.d1[l] = p->alloc(C * Bl);
-                e.d2[l] = p->alloc(C * Bl);
-                e.hd[l + 1] = p->alloc(C * Bl);
+                e.d1[l] = p->alloc(Cf * Bl);
+                e.d2[l] = p->alloc(Cf * Bl);
+                e.hd[l + 1] = p->alloc(Cf * Bl);
             }
         }
     };
@@ -439,16 +442,16 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     if (!spk_only) {
         alloc_enc(p->enc, false);
         p->muls = p->alloc(Bl * 2 * Cz * p->Tb);
-        d.z = p->alloc(Bl * Cz * p->Tb);
+        d.z = p->alloc(Bl * (Cz / H) * p->Tb);
         d.cond = p->alloc(Bl * 2 * d.n * 2 * Cd);
-        d.y0 = p->alloc(Bl * Cd * d.T[0]);
-        d.out[0] = p->alloc(Bl * Cd * d.T[0]);
+        d.y0 = p->alloc(Bl * (Cd / H) * d.T[0]);
+        d.out[0] = p->alloc(Bl * (Cd / H) * d.T[0]);
         d.st0 = p->alloc(2 * Bl * Cd);
         for (int l = 0; l < d.n; ++l) {
-            d.y1[l] = p->alloc(Bl * Cd * d.T[l]);
-            d.a1[l] = p->alloc(Bl * Cd * d.T[l]);
-            d.y2[l] = p->alloc(Bl * Cd * d.T[l + 1]);
-            d.out[l + 1] = p->alloc(Bl * Cd * d.T[l + 1]);
+            d.y1[l] = p->alloc(Bl * (Cd / H) * d.T[l]);
+            d.a1[l] = p->alloc(Bl * (Cd / H) * d.T[l]);
+            d.y2[l] = p->alloc(Bl * (Cd / H) * d.T[l + 1]);
+            d.out[l + 1] = p->alloc(Bl * (Cd / H) * d.T[l + 1]);
             d.st1[l] = p->alloc(2 * Bl * Cd);
             d.st2[l] = p->alloc(2 * Bl * Cd);
         }
@@ -464,7 +467,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->loss_partial = p->alloc(2 * 1024);
         // ---- gradient temporaries (sized for the largest [B, C, T] they ever hold)
         long maxCT = 0;
-        auto upd = [&](long c, long t) { maxCT = (c * t > maxCT) ? c * t : maxCT; };
+        auto upd = [&](long c, long t) { maxCT = ((c / H) * t > maxCT) ? (c / H) * t : maxCT; };
         for (int l = 0; l <= p->spk.n; ++l) upd(p->spk.c.c_h, p->spk.T[l]);
         for (int l = 0; l <= p->enc.n; ++l) upd(p->enc.c.c_h, p->enc.T[l]);
         for (int l = 0; l <= d.n; ++l) upd(Cd, d.T[l]);
@@ -940,7 +943,7 @@ static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, 
 }
 
 static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off, const float* res,
-                  int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0, bool pairs = false, int planar = 0) {
+                  int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0, bool pairs = false, int planar = 0, int nv = 0) {
     // stats = [mean[Bfull*C] | rstd[Bfull*C]]; a sub-batch launch (b0, Bn) of a Bfull-sample tensor passes
     // y/out/res/cond already offset to sample b0
     if (Bfull == 0) Bfull = Bn;
@@ -948,7 +951,7 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
     a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = planar;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = planar; a.nv_hint = nv;
     if (pairs) {
         a.R = Bn * (C / 2);
         return avc_launch_in_fwd_pairs(a, s);
@@ -957,12 +960,12 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
 }
 
 static int in_bwd(float slope, const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
-                  long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s, bool pairs = false) {
+                  long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s, bool pairs = false, int nv = 0) {
     INBwdArgs a;
     a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0; a.nv_hint = nv;
     if (pairs) {
         a.R = Bn * (C / 2);
         return avc_launch_in_bwd_pairs(a, s);
@@ -1009,6 +1012,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
                         const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
     const int B = p->B;
     const bool bh = p->bh;
+    const int NV = (int)p->tun.in_pairs_nv;
     // 0. weights -> LDS-image order (they change every optimizer step)
     // The conv banks and in_convs open both encoder branches and run for ~1 ms: only their images
     // are packed up front; the rest is packed on a (forward-idle) wgrad stream under the bank convs.
@@ -1034,6 +1038,20 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         if (pack_async) hipEventRecord(p->ev_pack[1], ps);
     }
 
+    const bool spk_only = (p->flags & AVC_PLAN_SPEAKER_ONLY) != 0;  // AE.get_speaker_embeddings (model.py:393-395)
+    // first kernels of the content encoder (conv bank, in_conv, InstanceNorm) on the caller's stream
+    auto content_front = [&]() -> int {
+        if (spk_only) return 0;
+        const EncNet& e = p->enc;
+        const float SL = e.slope;
+        const int Cc = e.c.c_h;
+        const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
+        RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
+        ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
+        RUN(avc_launch_conv(a, s, 0, p->tun));
+        RUN(in_fwd(SL, ws + e.h0, B, Cc, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s, 0, 0, bh, 0, NV));
+        return 0;
+    };
     // ---------------- speaker encoder (model.py:265-277), concurrent with the content encoder
     const hipStream_t mainS = s;
     const hipStream_t sideS = fork_side(p, mainS);
@@ -1045,6 +1063,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const long C = bh ? Cc / 2 : Cc;              // rows per sample of a [B, c_h, T] tensor (pair rows with bh): every stride below
         const long CCr = bh ? e.CC / 2 : e.CC;
         RUN(enc_front(p, e, params, ws, xc, scb, scc, sct, s));
+        RUN(content_front());   // (main stream) issued under this branch's long bank kernel: the content encoder is the longer branch
         {
             const LayerP& L = p->layers[e.in_conv];
             ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
@@ -1090,28 +1109,22 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
     }
 
     // ---------------- content encoder (model.py:301-323)
-    const bool spk_only = (p->flags & AVC_PLAN_SPEAKER_ONLY) != 0;  // AE.get_speaker_embeddings (model.py:393-395)
     if (!spk_only) {
         const EncNet& e = p->enc;
         const float SL = e.slope;
         const int Cc = e.c.c_h;
         const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
-        RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
-        {
-            ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.h0, B, Cc, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s, 0, 0, bh));
-        }
+        // (conv bank, in_conv and its InstanceNorm were issued by content_front(), above)
         if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
             RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y1[l], B, Cc, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s, 0, 0, bh));
+            RUN(in_fwd(SL, ws + e.y1[l], B, Cc, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s, 0, 0, bh, 0, NV));
             ConvArgs b = mk_fwd(p, SL, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
             const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
             RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y2[l], B, Cc, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s, 0, 0, bh));
+            RUN(in_fwd(SL, ws + e.y2[l], B, Cc, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s, 0, 0, bh, 0, NV));
         }
         const int Tb = p->Tb;
         ConvArgs h = mk_fwd(p, SL, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
@@ -1137,46 +1150,58 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         // most CUs waiting on launch / pipeline latency (0.86 ms with one kernel in flight, traced).  Two
         // half-batch chains on two streams interleave their phases; every tensor is [B, ...], so a half is
         // a pointer offset.
-        auto dec_chain = [&](int b0, int Bn, hipStream_t s) -> int {
+        // phase 0: in_conv + IN; phases 1 .. 2n: (first conv + AdaIN) / (second conv + AdaIN + residual) of block (ph - 1) / 2; phase 2n + 1: out_conv
+        auto dec_phase = [&](int b0, int Bn, hipStream_t s, int ph) -> int {
             const long oz = (long)b0 * Cz * Tb, ob0 = (long)b0 * C * Tb;
             const float* cond = ws + d.cond + (long)b0 * csb;
-            {
+            if (ph == 0) {
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, Cc, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0, bh));
+                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, Cc, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0, bh, 0, NV));
+                return 0;
             }
-            for (int l = 0; l < d.n; ++l) {
-                const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
-                const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
+            if (ph == 2 * d.n + 1) {
+                const int To = p->Tout;
+                ConvArgs o = mk_fwd(p, SL, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
+                                    ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
+                o.pairs = 0;   // dec is fp32 (the L1 loss / the caller read it)
+                RUN(avc_launch_conv(o, s, 0, p->tun));
+                return 0;
+            }
+            const int l = (ph - 1) / 2;
+            const int Ti = d.T[l], To = d.T[l + 1], up = d.c.upsample[l];
+            const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
+            if ((ph - 1) % 2 == 0) {
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, Cc, Ti, cond, csb, (2 * l) * 2 * Cc, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0, bh));
-                // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
-                ConvArgs b = mk_fwd(p, SL, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
-                b.ops = up;
-                if (bh) {   // the conv-output pairs [B][c_h up / 2][Ti] ARE the natural bf16 rows of the shuffled tensor: "planar" y2 (rowops_pairs.hip)
-                    b.ops = 1;
-                    b.ob = (long)C * To; b.oc = Ti;
-                }
-                RUN(avc_launch_conv(b, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, Cc, To, cond, csb, (2 * l + 1) * 2 * Cc, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
-                                    ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0, bh, (bh && up > 1) ? 1 : 0));
+                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, Cc, Ti, cond, csb, (2 * l) * 2 * Cc, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0, bh, 0, NV));
+                return 0;
             }
-            const int To = p->Tout;
-            ConvArgs o = mk_fwd(p, SL, p->layers[d.out_conv], params, ws, ws + d.out[d.n] + (long)b0 * C * To, (long)C * To, To, 1, Bn, To,
-                                ws + p->decb + (long)b0 * p->M * To, (long)p->M * To, To, 1, 0);
-            o.pairs = 0;   // dec is fp32 (the L1 loss / the caller read it)
-            RUN(avc_launch_conv(o, s, 0, p->tun));
+            // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
+            ConvArgs b = mk_fwd(p, SL, p->layers[d.c2[l]], params, ws, ws + d.a1[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y2[l] + oo, (long)C * To, To, 1, 0);
+            b.ops = up;
+            if (bh) {   // the conv-output pairs [B][c_h up / 2][Ti] ARE the natural bf16 rows of the shuffled tensor: "planar" y2 (rowops_pairs.hip)
+                b.ops = 1;
+                b.ob = (long)C * To; b.oc = Ti;
+            }
+            RUN(avc_launch_conv(b, s, 0, p->tun));
+            RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, Cc, To, cond, csb, (2 * l + 1) * 2 * Cc, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                                ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0, bh, (bh && up > 1) ? 1 : 0, NV));
             return 0;
         };
+        const int nph = 2 * d.n + 2;
         if (B >= p->tun.dec_split_min && side_ready(p)) {
+            // the host ISSUES the two chains phase by phase in turn: a chain issued whole before the other one starts has run to its end by the
+            // time the second chain's first launch reaches the GPU (the kernels are as short as a launch call: traced, profiles/r03_bf16s_timeline.txt)
             const int Bh = B / 2;
             const hipStream_t s2 = fork_side(p, s);
-            RUN(dec_chain(0, Bh, s));
-            RUN(dec_chain(Bh, B - Bh, s2));
+            for (int ph = 0; ph < nph; ++ph) {
+                RUN(dec_phase(0, Bh, s, ph));
+                RUN(dec_phase(Bh, B - Bh, s2, ph));
+            }
             join_side(p, s, s2);
         } else {
-            RUN(dec_chain(0, B, s));
+            for (int ph = 0; ph < nph; ++ph) RUN(dec_phase(0, B, s, ph));
         }
     }
     return 0;
@@ -1243,6 +1268,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     c.red.s = s; c.red.dry = dry;
     const int B = p->B;
     const bool bh = p->bh;
+    const int NV = (int)p->tun.in_pairs_nv;
     float* gA = ws + p->gA;
     float* gB = ws + p->gB;
     float* gC = ws + p->gC;
@@ -1277,62 +1303,71 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // else is ready before d(emb) and d(muls) exist (traced: 0.7 ms with one kernel in flight).  Like the forward pass it is
         // issued as two half-batch chains on two streams for B >= dec_split_min: every tensor is [B, ...], a half is a pointer
         // offset, and InstanceNorm / AdaIN statistics and d(cond) rows are per sample.
-        auto chain = [&](int b0, int Bn, hipStream_t s) -> int {
-            float* gA = ws + p->gA;
-            float* gB = ws + p->gB;
-            float* gC = ws + p->gC;
+        struct ChainSt {
+            float *gA, *gB, *gC;
+        };
+        // phase 0: out_conv input gradient; phases 1 .. 2n walk the blocks from the last one: (AdaIN backward of the second conv + its input
+        // gradient) / (AdaIN backward of the first conv + its input gradient joined with the skip path); phase 2n + 1: IN backward + in_conv
+        auto chain_phase = [&](ChainSt& st, int b0, int Bn, hipStream_t s, int ph) -> int {
             auto half_in_bwd = [&](const float* g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy, int planar = 0) -> int {
                 INBwdArgs a;
                 a.g = g + off; a.y = ws + yoff + off;
                 a.mean = ws + stoff + (long)b0 * Cc; a.rstd = ws + stoff + (long)B * Cc + (long)b0 * Cc;
                 a.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.cond_sb = csb; a.cond_off = coff;
                 a.dy = dy + off; a.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.dcond_sb = csb; a.dcond_off = coff;
-                a.R = Bn * Cc; a.C = Cc; a.T = T; a.relu = 1; a.slope = SL; a.planar = planar;
+                a.R = Bn * Cc; a.C = Cc; a.T = T; a.relu = 1; a.slope = SL; a.planar = planar; a.nv_hint = (int)p->tun.in_pairs_nv;
                 if (bh) {
                     a.R = Bn * (Cc / 2);
                     return avc_launch_in_bwd_pairs(a, s);
                 }
                 return avc_launch_in_bwd(a, s);
             };
-            {
+            if (ph == 0) {
                 const long oi = (long)b0 * Mr * To, oo = (long)b0 * C * To;
-                ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, Mr * To, To, 1, 1, Bn, To, To, gA + oo, (long)C * To, To, 1);
+                ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, Mr * To, To, 1, 1, Bn, To, To, st.gA + oo, (long)C * To, To, 1);
                 RUN(avc_launch_conv(a, s, 0, p->tun));
+                return 0;
             }
-            for (int l = d.n - 1; l >= 0; --l) {
-                const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
-                const long o2 = (long)b0 * C * T2, o1 = (long)b0 * C * Ti;
-                RUN(half_in_bwd(gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * Cc, true, dy2[l], (bh && up > 1) ? 1 : 0));
-                {   // dy2 is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
-                    // (pair plans: dy2 was written planar = as the conv-output pairs [B][c_h up / 2][Ti], a plain stride-1 source)
-                    ConvArgs a = bh ? mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, Ti, 1, 1, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1)
-                                    : mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, gB + o1, (long)C * Ti, Ti, 1);
-                    RUN(avc_launch_conv(a, s, 0, p->tun));
-                }
-                RUN(half_in_bwd(gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
-                {
-                    ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, gC + o1, (long)C * Ti, Ti, 1);
-                    set_res(a, gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                    RUN(avc_launch_conv(a, s, 0, p->tun));
-                }
-                float* t = gA; gA = gC; gC = t;
+            if (ph == 2 * d.n + 1) {
+                const long ob = (long)b0 * C * Tb;
+                RUN(half_in_bwd(st.gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
+                ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Czc * Tb, (long)Czc * Tb, Tb, 1);
+                a.pairs = 0;   // d(z) is fp32: the latent backward combines it with the fp32 mu / log_sigma
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+                return 0;
             }
-            const long ob = (long)b0 * C * Tb;
-            RUN(half_in_bwd(gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
-            ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Czc * Tb, (long)Czc * Tb, Tb, 1);
-            a.pairs = 0;   // d(z) is fp32: the latent backward combines it with the fp32 mu / log_sigma
+            const int l = d.n - 1 - (ph - 1) / 2;
+            const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
+            const long o2 = (long)b0 * C * T2, o1 = (long)b0 * C * Ti;
+            if ((ph - 1) % 2 == 0) {
+                RUN(half_in_bwd(st.gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * Cc, true, dy2[l], (bh && up > 1) ? 1 : 0));
+                // dy2 is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
+                // (pair plans: dy2 was written planar = as the conv-output pairs [B][c_h up / 2][Ti], a plain stride-1 source)
+                ConvArgs a = bh ? mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, Ti, 1, 1, Bn, Ti, Ti, st.gB + o1, (long)C * Ti, Ti, 1)
+                                : mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, st.gB + o1, (long)C * Ti, Ti, 1);
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+                return 0;
+            }
+            RUN(half_in_bwd(st.gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
+            ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, st.gC + o1, (long)C * Ti, Ti, 1);
+            set_res(a, st.gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
             RUN(avc_launch_conv(a, s, 0, p->tun));
+            float* t = st.gA; st.gA = st.gC; st.gC = t;
             return 0;
         };
         if (!dry) {
+            const int nph = 2 * d.n + 2;
+            ChainSt st0 = {ws + p->gA, ws + p->gB, ws + p->gC}, st1 = st0;
             if (B >= p->tun.dec_split_min && side_ready(p)) {
                 const int Bh = B / 2;
                 const hipStream_t s2 = fork_side(p, s);
-                RUN(chain(0, Bh, s));
-                RUN(chain(Bh, B - Bh, s2));
+                for (int ph = 0; ph < nph; ++ph) {   // issued in turn (see the forward pass)
+                    RUN(chain_phase(st0, 0, Bh, s, ph));
+                    RUN(chain_phase(st1, Bh, B - Bh, s2, ph));
+                }
                 join_side(p, s, s2);
             } else {
-                RUN(chain(0, B, s));
+                for (int ph = 0; ph < nph; ++ph) RUN(chain_phase(st0, 0, B, s, ph));
             }
         }
         // the weight gradients of the decoder (recorded; launched in batches on the wgrad stream, flush_wgrads)
@@ -1382,6 +1417,48 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
         if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
     }
+
+    // ---------------- content encoder (issued from inside the speaker branch below, right after that branch's first kernel: the host
+    // issues launches about as fast as these kernels run, so whichever branch is issued second starts late by the other one's issue time)
+    auto content_branch = [&]() -> int {
+        const EncNet& e = p->enc;
+        const float SL = e.slope;
+        const int Cc = e.c.c_h, Tb = p->Tb;
+        const long C = bh ? Cc / 2 : Cc, Co2 = bh ? e.c.c_out : 2 * e.c.c_out;   // rows per sample (pair rows with bh)
+        const float* dmuls = ws + (bh ? p->dmulsp : p->dmuls);
+        const LayerP& Lh = p->layers[e.heads];
+        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
+        if (!dry) {
+            ConvArgs a = mk_dgrad(SL, Lh, ws, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
+            RUN(avc_launch_conv(a, s, 0, p->tun));
+        }
+        for (int l = e.n - 1; l >= 0; --l) {
+            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
+            const LayerP& L1 = p->layers[e.c1[l]];
+            const LayerP& L2 = p->layers[e.c2[l]];
+            dyA = c.fresh((long)B * C * T2);
+            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, Cc, T2, nullptr, 0, 0, dyA, nullptr, s, bh, NV));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+            }
+            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
+            dyB = c.fresh((long)B * C * Ti);
+            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, Cc, Ti, nullptr, 0, 0, dyB, nullptr, s, bh, NV));
+            if (!dry) {
+                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
+                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
+                RUN(avc_launch_conv(a, s, 0, p->tun));
+            }
+            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
+            rot();
+        }
+        dyA = c.fresh((long)B * C * e.T[0]);
+        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh, NV));
+        RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
+        RUN(flush_wgrads(c));
+        return 0;
+    };
 
     // ---------------- speaker encoder (side stream, own temporaries: concurrent with the content encoder)
     const hipStream_t mainS = s;
@@ -1440,6 +1517,13 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             // 13 Linear layers on [C][B] channel-major operands: same kernel instance -> ONE batched launch
             for (int i = 0; i < ng; ++i) RUN(wgrad_layer(c, *gl[i], gx[i], 0, B, 1, gdy[i], 0, B, 1, 1, 1, B, B));
         }
+        // ... the content encoder's whole branch is issued now (main stream), under the dense-stack kernel that opens this branch
+        RUN(flush_wgrads(c));
+        c.s = mainS;
+        c.wstream = overlap ? p->wstream[0] : mainS;
+        RUN(content_branch());
+        c.s = sideS;
+        c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output
         const int Tn = e.T[e.n];
         dyA = c.fresh((long)B * C * Tn);
@@ -1479,46 +1563,6 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         c.s = mainS;
         c.wstream = overlap ? p->wstream[0] : mainS;
     }
-    // ---------------- content encoder
-    {
-        const EncNet& e = p->enc;
-        const float SL = e.slope;
-        const int Cc = e.c.c_h, Tb = p->Tb;
-        const long C = bh ? Cc / 2 : Cc, Co2 = bh ? e.c.c_out : 2 * e.c.c_out;   // rows per sample (pair rows with bh)
-        const float* dmuls = ws + (bh ? p->dmulsp : p->dmuls);
-        const LayerP& Lh = p->layers[e.heads];
-        RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
-        if (!dry) {
-            ConvArgs a = mk_dgrad(SL, Lh, ws, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
-        }
-        for (int l = e.n - 1; l >= 0; --l) {
-            const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
-            const LayerP& L1 = p->layers[e.c1[l]];
-            const LayerP& L2 = p->layers[e.c2[l]];
-            dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, Cc, T2, nullptr, 0, 0, dyA, nullptr, s, bh));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-            }
-            RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
-            dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, Cc, Ti, nullptr, 0, 0, dyB, nullptr, s, bh));
-            if (!dry) {
-                ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
-                set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-            }
-            RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
-            rot();
-        }
-        dyA = c.fresh((long)B * C * e.T[0]);
-        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh));
-        RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
-        RUN(flush_wgrads(c));
-    }
-
     if (!dry) join_side(p, mainS, sideS);
     if (overlap) {
         for (int i = 0; i < 2; ++i) {

@@ -328,28 +328,52 @@ int avc_launch_in_fwd_pairs(const INFwdArgs& a, hipStream_t s) {
                   (a.res_mode == AVC_RES_IDENTITY && a.Tres != a.T)))
         return -2;
     ProfScope ps(AVC_K_IN_FWD, 0.0, 2.0 * 4.0 * (double)a.R * a.T, s);   // 1 read + 1 write of 2 bytes x 2 channels per dword
-    if (n4 <= 4) launch_fwd<4, 1>(a, s);
-    else if (n4 <= 8) launch_fwd<8, 1>(a, s);
-    else if (n4 <= 16) launch_fwd<16, 1>(a, s);
-    else if (n4 <= 32) launch_fwd<32, 1>(a, s);
-    else if (n4 <= 64) launch_fwd<64, 1>(a, s);
-    else if (n4 <= 128) launch_fwd<64, 2>(a, s);
-    else if (n4 <= 256) launch_fwd<64, 4>(a, s);
-    else launch_fwd<64, 8>(a, s);
+    // lanes per row x 16-byte vectors per lane: nv (tuning in_pairs_nv) vectors per lane while the row still fills >= 4 lanes
+    int nv = a.nv_hint == 2 || a.nv_hint == 4 ? a.nv_hint : 1;
+    while (nv > 1 && (n4 / nv < 4 || n4 % nv)) nv >>= 1;
+    const int lpr = n4 / nv;
+#define AVC_INP(L_, N_) launch_fwd<L_, N_>(a, s)
+    if (nv == 1 || (lpr & (lpr - 1)) || lpr > 64) {
+        if (n4 <= 4) AVC_INP(4, 1);
+        else if (n4 <= 8) AVC_INP(8, 1);
+        else if (n4 <= 16) AVC_INP(16, 1);
+        else if (n4 <= 32) AVC_INP(32, 1);
+        else if (n4 <= 64) AVC_INP(64, 1);
+        else if (n4 <= 128) AVC_INP(64, 2);
+        else if (n4 <= 256) AVC_INP(64, 4);
+        else AVC_INP(64, 8);
+    } else if (nv == 2) {
+        if (lpr == 4) AVC_INP(4, 2); else if (lpr == 8) AVC_INP(8, 2); else if (lpr == 16) AVC_INP(16, 2); else if (lpr == 32) AVC_INP(32, 2); else AVC_INP(64, 2);
+    } else {
+        if (lpr == 4) AVC_INP(4, 4); else if (lpr == 8) AVC_INP(8, 4); else if (lpr == 16) AVC_INP(16, 4); else if (lpr == 32) AVC_INP(32, 4); else AVC_INP(64, 4);
+    }
+#undef AVC_INP
     return (int)hipGetLastError();
 }
 int avc_launch_in_bwd_pairs(const INBwdArgs& a, hipStream_t s) {
     const int n4 = a.T >> 2;
     if ((a.T & 3) || (a.C & 1) || n4 > 512) return -2;
     ProfScope ps(AVC_K_IN_BWD, 0.0, 3.0 * 4.0 * (double)a.R * a.T, s);
-    if (n4 <= 4) launch_bwd<4, 1>(a, s);
-    else if (n4 <= 8) launch_bwd<8, 1>(a, s);
-    else if (n4 <= 16) launch_bwd<16, 1>(a, s);
-    else if (n4 <= 32) launch_bwd<32, 1>(a, s);
-    else if (n4 <= 64) launch_bwd<64, 1>(a, s);
-    else if (n4 <= 128) launch_bwd<64, 2>(a, s);
-    else if (n4 <= 256) launch_bwd<64, 4>(a, s);
-    else launch_bwd<64, 8>(a, s);
+    // lanes per row x 16-byte vectors per lane: nv (tuning in_pairs_nv) vectors per lane while the row still fills >= 4 lanes
+    int nv = a.nv_hint == 2 || a.nv_hint == 4 ? a.nv_hint : 1;
+    while (nv > 1 && (n4 / nv < 4 || n4 % nv)) nv >>= 1;
+    const int lpr = n4 / nv;
+#define AVC_INP(L_, N_) launch_bwd<L_, N_>(a, s)
+    if (nv == 1 || (lpr & (lpr - 1)) || lpr > 64) {
+        if (n4 <= 4) AVC_INP(4, 1);
+        else if (n4 <= 8) AVC_INP(8, 1);
+        else if (n4 <= 16) AVC_INP(16, 1);
+        else if (n4 <= 32) AVC_INP(32, 1);
+        else if (n4 <= 64) AVC_INP(64, 1);
+        else if (n4 <= 128) AVC_INP(64, 2);
+        else if (n4 <= 256) AVC_INP(64, 4);
+        else AVC_INP(64, 8);
+    } else if (nv == 2) {
+        if (lpr == 4) AVC_INP(4, 2); else if (lpr == 8) AVC_INP(8, 2); else if (lpr == 16) AVC_INP(16, 2); else if (lpr == 32) AVC_INP(32, 2); else AVC_INP(64, 2);
+    } else {
+        if (lpr == 4) AVC_INP(4, 4); else if (lpr == 8) AVC_INP(8, 4); else if (lpr == 16) AVC_INP(16, 4); else if (lpr == 32) AVC_INP(32, 4); else AVC_INP(64, 4);
+    }
+#undef AVC_INP
     return (int)hipGetLastError();
 }
 

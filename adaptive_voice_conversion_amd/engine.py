@@ -82,13 +82,18 @@ class Plan:
     """One (B, T, T_cond) launch plan.  ``lib`` defaults to the gfx950 library;
     tests may inject the CPU lane-level simulation build instead."""
 
-    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp32x3": 0, "f32x3": 0, "bf16s": 3, "bf16_storage": 3}
+    COMPUTE = {"fp32": 0, "float32": 0, "f32": 0, "fp32x3": 0, "f32x3": 0, "bf16": 3, "bfloat16": 3, "bf16s": 3, "bf16_storage": 3,
+               "bf16r": 1, "bf16_operands": 1}
 
     def __init__(self, config, B, T, T_cond=None, lib=None, compute_dtype="fp32", mode="train", device=None, tuning=None):
-        """compute_dtype: "fp32" (default, the reference's precision) or "bf16" = conv / Linear operands
-        rounded to bf16 inside the matrix core, fp32 accumulate and fp32 storage (BASELINE config 3); "fp32x3" = fp32-accurate
-        products from three bf16 terms per operand on the bf16 matrix core for the big k = 5 convs and the whole-chunk weight
-        gradients (opt-in; csrc/conv_x3.hip), exact fp32 everywhere else.
+        """compute_dtype: "fp32" (default, the reference's precision);
+        "bf16" = BASELINE config 3's precision on the bf16 STORAGE engine (AVC_PLAN_BF16S: activations and activation gradients are bf16
+        channel-pair tensors in HBM and LDS, v_mfma_f32_32x32x16_bf16 products, fp32 accumulation / statistics / parameters / optimizer);
+        shapes the pair kernels do not take (odd channel counts, frame counts that are not multiples of 4 at some level) fall back to
+        "bf16r" -- ``plan.compute_dtype`` says which one the plan runs; "bf16s" = the storage engine or an error;
+        "bf16r" = fp32 storage, conv / Linear operands rounded to bf16 as they enter the matrix core (round 2's bf16 mode);
+        "fp32x3" = fp32-accurate products from three bf16 terms per operand on the bf16 matrix core for the big k = 5 convs and the
+        whole-chunk weight gradients (opt-in; csrc/conv_x3.hip), exact fp32 everywhere else.
         mode: "train" (forward + loss + backward), "inference" (forward only: the workspace holds no gradient,
         slab or dy buffers) or "speaker" (only the speaker encoder runs, AE.get_speaker_embeddings).
         device: the plan's helper streams are created on it (default: the current device).
@@ -108,18 +113,22 @@ class Plan:
         if x3:
             flags |= _lib.PLAN_X3
         bh = self.COMPUTE[key] == 3
-        if bh:
-            flags |= _lib.PLAN_BF16S
+        strict = key in ("bf16s", "bf16_storage")
         self.tuning = dict(tuning or {})
         tun = _lib.make_tuning(self.lib, self.tuning)
         with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
-            rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(tun), ctypes.byref(h))
+            rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags | (_lib.PLAN_BF16S if bh else 0),
+                                                ctypes.byref(tun), ctypes.byref(h))
+            if rc == -2 and bh and not strict:   # a shape outside the pair kernels: the operand-rounding bf16 mode takes any shape
+                bh = False
+                rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(tun), ctypes.byref(h))
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
-        self.compute_dtype = "fp32x3" if x3 else ("bf16s" if bh else ("bf16" if self.COMPUTE[key] else "fp32"))
+        operand_bf16 = (self.COMPUTE[key] in (1, 3)) and not bh
+        self.compute_dtype = "fp32x3" if x3 else ("bf16" if bh else ("bf16r" if operand_bf16 else "fp32"))
         self.pair_storage = bh
-        if not bh and self.lib.avc_plan_set_compute_dtype(h, self.COMPUTE[key]) != 0:
+        if not bh and self.lib.avc_plan_set_compute_dtype(h, 1 if operand_bf16 else 0) != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.num_params = self.lib.avc_plan_num_params(h)
         self.param_floats = self.lib.avc_plan_param_floats(h)
@@ -251,8 +260,8 @@ class RaggedPlan:
             raise ValueError("T and T_cond must be equally long, non-empty lists")
         self.B = len(self.T)
         key = str(compute_dtype).lower()
-        if key not in ("fp32", "float32", "f32", "bf16", "bfloat16"):
-            raise ValueError("ragged plans compute in fp32 or bf16")
+        if key not in ("fp32", "float32", "f32", "bf16", "bfloat16", "bf16r", "bf16_operands"):
+            raise ValueError("ragged plans compute in fp32 or bf16 (operand rounding: the pair-storage engine takes uniform shapes)")
         h = ctypes.c_void_p()
         tun = _lib.make_tuning(self.lib, tuning)
         arr = ctypes.c_int * self.B
@@ -262,8 +271,8 @@ class RaggedPlan:
         if rc != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.h = h
-        bf = key in ("bf16", "bfloat16")
-        self.compute_dtype = "bf16" if bf else "fp32"
+        bf = key in ("bf16", "bfloat16", "bf16r", "bf16_operands")
+        self.compute_dtype = "bf16r" if bf else "fp32"
         if self.lib.avc_plan_set_compute_dtype(h, 1 if bf else 0) != 0:
             raise RuntimeError(self.lib.avc_last_error().decode())
         self.param_floats = self.lib.avc_plan_param_floats(h)

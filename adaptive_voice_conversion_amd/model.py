@@ -184,7 +184,8 @@ class AE(nn.Module):
     """model.py:373-395."""
 
     def __init__(self, config, lib=None, compute_dtype=None, tuning=None):
-        """``compute_dtype`` ("fp32" default | "bf16" | "fp32x3"; also read from ``config["compute_dtype"]``) is an
+        """``compute_dtype`` ("fp32" default | "bf16" (bf16 storage engine) | "bf16r" (fp32 storage, bf16 operands) | "fp32x3"; also read
+        from ``config["compute_dtype"]``; engine.Plan documents the modes) is an
         extension over the reference: the precision of the conv / Linear matrix products (engine.Plan).
         ``tuning``: {avc_tuning field: value} captured by every plan of this module (A/B measurements, tests)."""
         super().__init__()
@@ -324,7 +325,7 @@ class AE(nn.Module):
         key = (T, Tc, str(dev))
         hit = self._ragged.get(key)
         if hit is None:
-            plan = RaggedPlan(self.config, T, Tc, lib=self._lib, compute_dtype="bf16" if self.compute_dtype == "bf16" else "fp32", device=dev,
+            plan = RaggedPlan(self.config, T, Tc, lib=self._lib, compute_dtype="bf16r" if str(self.compute_dtype).lower().startswith(("bf16", "bfloat16")) else "fp32", device=dev,
                               tuning=self._tuning)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")

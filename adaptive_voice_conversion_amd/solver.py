@@ -138,7 +138,7 @@ class Solver(object):
         # bf16 too -- 9.8 MB instead of 19.6 MB per step over xGMI; `allreduce_dtype: fp32` in the config keeps
         # the wire fp32.  The sum of W bf16-rounded gradients carries a relative error of ~2^-9 per element, the same order as
         # the bf16 matrix products that produced them.
-        wire_bf16 = self.config.get("allreduce_dtype", "bf16" if str(self.config.get("compute_dtype", "fp32")).lower() in ("bf16", "bfloat16", "bf16s", "bf16_storage") else "fp32") == "bf16"
+        wire_bf16 = self.config.get("allreduce_dtype", "bf16" if str(self.config.get("compute_dtype", "fp32")).lower() .startswith(("bf16", "bfloat16")) else "fp32") == "bf16"
 
         def reduce(seg, wire):
             if wire is None:

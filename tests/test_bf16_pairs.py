@@ -370,3 +370,102 @@ def test_pairs_conv_wgrad(kind, B, Cin, Cout, T, KS, stride):
     scale = dw_ref.abs().max().item()
     torch.testing.assert_close(dW.cpu(), dw_ref.float(), rtol=1e-4, atol=1e-5 * max(1.0, scale))     # fp32 accumulation of exact bf16 products
     torch.testing.assert_close(db.cpu(), db_ref.float(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole engine on pair storage (AVC_PLAN_BF16S; compute_dtype "bf16" / "bf16s")
+# ---------------------------------------------------------------------------------------------------------------
+def _tiny(act="relu"):
+    return O.tiny_config(act=act)
+
+
+def _flat_params(plan, sd, dev):
+    from tests.test_engine import flat_params
+    return flat_params(plan, sd, dev)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_storage_engine_shape_rules_and_fallback(kind):
+    """The pair kernels take even channel counts and frame counts that are multiples of 4 at every level.  "bf16s" refuses other
+    shapes; "bf16" falls back to the operand-rounding mode ("bf16r": fp32 storage) and says so."""
+    from adaptive_voice_conversion_amd.engine import Plan
+    lib, dev = backend(kind)
+    cfg = _tiny()
+    ok = Plan(cfg, 2, 32, lib=lib, compute_dtype="bf16")
+    assert ok.compute_dtype == "bf16" and ok.pair_storage and lib.avc_plan_compute_dtype(ok.h) == 3
+    odd = Plan(cfg, 2, 34, lib=lib, compute_dtype="bf16")          # 34 -> 17 frames after the stride-2 block
+    assert odd.compute_dtype == "bf16r" and not odd.pair_storage and lib.avc_plan_compute_dtype(odd.h) == 1
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        Plan(cfg, 2, 34, lib=lib, compute_dtype="bf16s")
+    # half the activation bytes: the workspace of a pair plan is smaller than the fp32 plan's
+    f32 = Plan(cfg, 2, 32, lib=lib)
+    assert ok.workspace_floats < 0.8 * f32.workspace_floats
+    # the compute dtype of a pair plan is a property of its workspace layout
+    assert lib.avc_plan_set_compute_dtype(ok.h, 0) != 0
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_storage_engine_forward_inference_and_determinism(kind, act):
+    """(1) forward of the train plan against the fp32 oracle (rel-L2 <= 3e-2, SURVEY 8c's bf16 bar), for both activations;
+    (2) an inference plan (no gradient buffers) computes the same function bit for bit; (3) forward + backward twice: identical bits."""
+    from adaptive_voice_conversion_amd.engine import Plan
+    lib, dev = backend(kind)
+    cfg = _tiny(act)
+    B, T = 3, 32
+    sd = O.make_state_dict(cfg, 2)
+    x, eps = O.make_inputs(cfg, B, T, 2)
+    xd, ed = x.to(dev), eps.to(dev)
+    plan = Plan(cfg, B, T, lib=lib, compute_dtype="bf16s")
+    params = _flat_params(plan, sd, dev)
+    ws = torch.zeros(plan.workspace_floats, device=dev)
+    plan.forward(params, xd, None, ed, ws)
+    Cz = cfg["ContentEncoder"]["c_out"]
+    shapes = {"muls": (B, 2 * Cz, plan.latent_len), "emb": (B, cfg["SpeakerEncoder"]["c_out"]), "dec": (B, cfg["Decoder"]["c_out"], plan.out_len)}
+    got = {k: plan.view(ws, k, v).cpu().clone() for k, v in shapes.items()}
+    mu, ls, emb, dec = O.ae_forward(x, eps, sd, cfg)
+    ref = {"muls": torch.cat([mu, ls], 1), "emb": emb, "dec": dec}
+    for k in got:
+        e = ((got[k] - ref[k]).norm() / ref[k].norm()).item()
+        assert e < 3e-2, (k, e)
+    inf = Plan(cfg, B, T, lib=lib, compute_dtype="bf16s", mode="inference")
+    assert inf.workspace_floats < plan.workspace_floats
+    wsi = torch.zeros(inf.workspace_floats, device=dev)
+    inf.forward(params, xd, None, ed, wsi)
+    for k, v in shapes.items():
+        assert torch.equal(inf.view(wsi, k, v).cpu(), got[k]), k
+    plan.loss(xd, 10.0, ws)
+    g1 = torch.zeros(plan.param_floats, device=dev)
+    plan.backward(params, xd, None, ed, g1, ws, lambda_kl=1.0)
+    g2 = torch.zeros_like(g1)
+    plan.forward(params, xd, None, ed, ws)
+    plan.loss(xd, 10.0, ws)
+    plan.backward(params, xd, None, ed, g2, ws, lambda_kl=1.0)
+    assert torch.isfinite(g1).all() and torch.equal(g1, g2), "the pair-storage backward is not deterministic"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_storage_engine_transposed_input_and_half_batch_chains(kind):
+    """The [B, T, M] -> [B, M, T] view of data_utils.py:14-16 enters through the fp32 -> pair seam kernel (explicit strides), and the two
+    half-batch decoder chains (dec_split_min) compute what the single chain computes."""
+    from adaptive_voice_conversion_amd.engine import Plan
+    lib, dev = backend(kind)
+    cfg = _tiny()
+    B, T = 4, 32
+    sd = O.make_state_dict(cfg, 5)
+    x, eps = O.make_inputs(cfg, B, T, 5)
+    xt = x.transpose(1, 2).contiguous().to(dev)      # [B, T, M]
+    xv = xt.transpose(1, 2)                           # the view the data pipeline hands over
+    outs = []
+    for split_min, xin in ((10 ** 6, x.to(dev)), (2, xv)):
+        plan = Plan(cfg, B, T, lib=lib, compute_dtype="bf16s", tuning={"dec_split_min": split_min})
+        params = _flat_params(plan, sd, dev)
+        ws = torch.zeros(plan.workspace_floats, device=dev)
+        plan.forward(params, xin, None, eps.to(dev), ws)
+        plan.loss(xin, 10.0, ws)
+        g = torch.zeros(plan.param_floats, device=dev)
+        plan.backward(params, xin, None, eps.to(dev), g, ws, lambda_kl=1.0)
+        outs.append((plan.view(ws, "dec", (B, cfg["Decoder"]["c_out"], plan.out_len)).cpu().clone(), g.cpu().clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=0, atol=0)
+    # (the half-batch split changes the split-K grouping of some weight-gradient launches: summation order only)
+    assert ((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm()).item() < 1e-4

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, wire="fp32"):
+def _worker(rank, world, port, out_dir, wire="fp32", compute=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +33,8 @@ def _worker(rank, world, port, out_dir, wire="fp32"):
     lib, _ = backend("emu")
     cfg = O.tiny_config()
     cfg["allreduce_dtype"] = wire
+    if compute:
+        cfg["compute_dtype"] = compute
     sd = O.make_state_dict(cfg, 4)
     B = 4
     x, eps = O.make_inputs(cfg, B, 32, 4)
@@ -94,3 +96,13 @@ def test_two_rank_step_equals_global_batch_step(tmp_path):
     lr = cfg["optimizer"]["lr"]
     diff = (b0["params"] - r0["params"]).abs()
     assert diff.max().item() <= 4.2 * lr and (diff > 0.05 * lr).float().mean().item() < 0.2
+    # BASELINE configs[2] as a whole: the bf16 STORAGE engine (compute_dtype "bf16") on every rank + the bf16 wire it defaults to.
+    # Same contract: bit-identical replicas, a global gradient norm within bf16 distance of the fp32 run's.
+    d2 = tmp_path / "bf16_storage"
+    d2.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), str(d2), "bf16", "bf16"), nprocs=world, join=True)
+    c0, c1 = torch.load(d2 / "rank0.pt"), torch.load(d2 / "rank1.pt")
+    assert torch.equal(c0["params"], c1["params"]), "replicas diverged"
+    assert c0["metas"][0]["grad_norm"] == pytest.approx(r0["metas"][0]["grad_norm"], rel=5e-2)
+    assert c0["metas"][0]["loss_rec"] == pytest.approx(r0["metas"][0]["loss_rec"], rel=2e-2)
+    assert (c0["params"] - r0["params"]).abs().max().item() <= 4.2 * lr

@@ -339,7 +339,8 @@ def rel_l2(a, b):
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 2, 32), pytest.param("gpu", "m80", 4, 128, marks=GPU)])
 def test_bf16_compute_mode_vs_fp32_oracle(kind, cfgname, B, T):
-    """BASELINE config 3's compute mode: conv / Linear operands rounded to bf16 inside the matrix core,
+    """compute_dtype "bf16r" (BASELINE config 3's precision on fp32 STORAGE; "bf16" itself is the bf16 storage engine,
+    tests/test_graded_configs.py::test_bf16_storage_mode_at_graded_shape): conv / Linear operands rounded to bf16 inside the matrix core,
     fp32 accumulate, everything stored in fp32.  Tolerances: forward rel-L2 <= 3e-2 against the fp32
     oracle; whole gradient cosine >= 0.995 / rel-L2 <= 1e-1 against the oracle
     differentiated on the engine's own ReLU branch (no reference number exists for bf16 gradients;
@@ -349,8 +350,8 @@ def test_bf16_compute_mode_vs_fp32_oracle(kind, cfgname, B, T):
     sd = O.make_state_dict(cfg, 4)
     x, eps = O.make_inputs(cfg, B, T, 4)
     xd = x.to(dev)
-    plan = Plan(cfg, B, T, lib=lib, compute_dtype="bf16")
-    assert plan.compute_dtype == "bf16" and lib.avc_plan_compute_dtype(plan.h) == 1
+    plan = Plan(cfg, B, T, lib=lib, compute_dtype="bf16r")
+    assert plan.compute_dtype == "bf16r" and lib.avc_plan_compute_dtype(plan.h) == 1
     params = flat_params(plan, sd, dev)
     ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
     plan.forward(params, xd, None, eps.to(dev), ws)

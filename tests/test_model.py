@@ -183,10 +183,12 @@ def test_autograd_seam_with_direct_embedding_and_latent_losses(kind):
         assert e <= 2e-4 * d + 2e-6, (k, e, d)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16r"])
 @pytest.mark.parametrize("kind,cfgname,B,T,steps", [("emu", "tiny", 2, 32, 6), pytest.param("gpu", "m80", 16, 128, 30, marks=pytest.mark.gpu)])
-def test_bf16_compute_training_curve_tracks_fp32(kind, cfgname, B, T, steps):
+def test_bf16_compute_training_curve_tracks_fp32(kind, cfgname, B, T, steps, mode):
     """config["compute_dtype"] = "bf16" (BASELINE config 3: bf16 matrix products, fp32 master weights and
-    optimizer state): the loss curve stays within 2 % of the fp32 engine's from the same init and
+    optimizer state; the bf16 STORAGE engine) and "bf16r" (the same precision on fp32 storage, operands rounded as they
+    enter the matrix core): the loss curve stays within 2 % of the fp32 engine's from the same init and
     batch (SURVEY §8c asks for 1 % over 100 steps of real training; this is the short-run check) and
     the checkpoint stays a plain fp32 state_dict."""
     import copy
@@ -196,7 +198,7 @@ def test_bf16_compute_training_curve_tracks_fp32(kind, cfgname, B, T, steps):
     x, eps = O.make_inputs(cfg, B, T, 0)
     args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_log")
     cfg16 = copy.deepcopy(cfg)
-    cfg16["compute_dtype"] = "bf16"
+    cfg16["compute_dtype"] = mode
     runs = []
     for c in (cfg, cfg16):
         s = Solver(c, args, lib=lib if kind == "emu" else None)
@@ -206,8 +208,10 @@ def test_bf16_compute_training_curve_tracks_fp32(kind, cfgname, B, T, steps):
             curve.append(s.ae_step(x.to(dev), 1.0, eps=eps.to(dev))["loss_rec"])
         runs.append((s, curve))
     (s32, c32), (s16, c16) = runs
-    assert s16.model.compute_dtype == "bf16" and s32.model.compute_dtype == "fp32"
-    print(f"[{kind}] loss_rec fp32 {c32[0]:.4f} -> {c32[-1]:.4f} | bf16 {c16[0]:.4f} -> {c16[-1]:.4f}")
+    assert s16.model.compute_dtype == mode and s32.model.compute_dtype == "fp32"
+    plan16 = s16.model._plan(B, T, T, dev)[0]
+    assert plan16.compute_dtype == mode and plan16.pair_storage == (mode == "bf16")
+    print(f"[{kind}] loss_rec fp32 {c32[0]:.4f} -> {c32[-1]:.4f} | {mode} {c16[0]:.4f} -> {c16[-1]:.4f}")
     for a, b in zip(c32, c16):
         assert b == pytest.approx(a, rel=2e-2)
     assert c16[-1] < c16[0]
