@@ -737,6 +737,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     if (!rag && a.bf16 != AVC_COMPUTE_BF16S && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
     if (lds > 160 * 1024) return -5;
+    if (tun.conv_min_lds > 0 && (size_t)tun.conv_min_lds > lds && tun.conv_min_lds <= 160 * 1024) lds = (size_t)tun.conv_min_lds;   // (fewer co-resident workgroups)
     dim3 block(AVC_THREADS * kgroups);
     double flops = 0;
     for (int gi = 0; gi < a.ngroups; ++gi)

@@ -144,6 +144,7 @@ typedef struct avc_tuning {
                              * at least this many workgroups; 0 = never */
     long wgrad_batch_units; /* pending (tile x K-chunk) units that trigger a batched launch early (1 << 40 = never) */
     long tile_thr11, tile_thr21, ck16_wgs, ck32_wgs, kg_wgs;   /* conv tile / chunk-depth / split-K-group thresholds in workgroups */
+    long conv_min_lds;      /* occupancy experiment: every conv_gemm launch asks for at least this many BYTES of LDS (0 = what the tiles need) */
     long in_pairs_nv;       /* bf16 pair InstanceNorm rows: 16-byte vectors per lane, 1 (default: one lane group spans the row) | 2 | 4 */
     long bh_ck5;            /* AVC_PLAN_BF16S plans: chunk depth (DWORD channels = bf16 channel pairs) of the k >= 4 convs: 8 (default) | 16 | 32 */
 } avc_tuning;
