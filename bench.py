@@ -156,6 +156,100 @@ def instnorm_dominant_shape(B, C, T, launches=50, pairs=False):
     return res
 
 
+def instnorm_all_shapes(plan, reps=8, pairs=False):
+    """Every InstanceNorm / AdaIN launch of ONE train step (the plan's own site list: shapes, affine or not; every second site with an
+    identity residual join, as the blocks have), forward in network order then backward in reverse, issued back to back `reps` times
+    between ONE pair of HIP events on the launch stream -- no per-launch bracket (an event pair around a 5-us kernel measures the
+    bracket: the in-library class profile does that and is reported beside this).  Bytes: the algorithmic 2 N (forward) / 3 N (backward)
+    per launch of BASELINE.md (the residual read is not counted)."""
+    from adaptive_voice_conversion_amd import _lib
+    from adaptive_voice_conversion_amd._lib import ReluSite
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sites = []
+    for i in range(plan.lib.avc_plan_num_relu_sites(plan.h)):
+        r = ReluSite()
+        plan.lib.avc_plan_relu_site(plan.h, i, ctypes.byref(r))
+        if r.kind != 0:
+            sites.append((r.B, r.C, r.T, r.cond_off >= 0))
+    if not sites:
+        return None
+    esz = 2.0 if pairs else 4.0
+    bufs = {}
+    def buf(shape, k):   # (one buffer set per distinct shape and role; values are irrelevant to the timing but finite)
+        key = (shape, k)
+        if key not in bufs:
+            B, C, T = shape
+            if pairs:
+                bufs[key] = torch.randn(B, C, T, device=dev).to(torch.bfloat16).view(torch.int32).view(B, C // 2, T)
+            else:
+                bufs[key] = torch.randn(B, C, T, device=dev)
+        return bufs[key]
+    Bm, Cm = max(s_[0] for s_ in sites), max(s_[1] for s_ in sites)
+    cond = torch.randn(Bm, 2 * Cm, device=dev)
+    dcond = torch.zeros(Bm, 2 * Cm, device=dev)
+    mean, rstd = torch.empty(Bm * Cm, device=dev), torch.empty(Bm * Cm, device=dev)
+    def fwd(i, s_, stream):
+        B, C, T, aff = s_
+        y, o = buf((B, C, T), "y%d" % (i % 3)), buf((B, C, T), "o%d" % (i % 3))
+        res = buf((B, C, T), "r") if (i & 1) else None
+        c = cond if aff else None
+        if pairs:
+            return lib.avc_instnorm_fwd_pairs(P(y), B, C, T, P(c), 2 * Cm, 0, 1, P(res), 1 if res is not None else 0, T if res is not None else 0, 0, P(o), P(mean), P(rstd), stream)
+        return lib.avc_instnorm_fwd(P(y), B, C, T, P(c), 2 * Cm, 0, 1, P(res), 1 if res is not None else 0, T if res is not None else 0, P(o), P(mean), P(rstd), stream)
+    def bwd(i, s_, stream):
+        B, C, T, aff = s_
+        g, y, o = buf((B, C, T), "g%d" % (i % 3)), buf((B, C, T), "y%d" % (i % 3)), buf((B, C, T), "o%d" % (i % 3))
+        c = cond if aff else None
+        if pairs:
+            return lib.avc_instnorm_bwd_pairs(P(g), P(y), P(mean), P(rstd), B, C, T, P(c), 2 * Cm, 0, 1, 0, P(o), P(dcond if aff else None), 2 * Cm, 0, stream)
+        return lib.avc_instnorm_bwd(P(g), P(y), P(mean), P(rstd), B, C, T, P(c), 2 * Cm, 0, 1, P(o), P(dcond if aff else None), 2 * Cm, 0, stream)
+    def sequence(stream):
+        for i, s_ in enumerate(sites):
+            assert fwd(i, s_, stream) == 0
+        for i, s_ in reversed(list(enumerate(sites))):
+            assert bwd(i, s_, stream) == 0
+    nbytes = sum((2 + 3) * esz * B * C * T for (B, C, T, _) in sites)
+    sequence(st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        sequence(st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out = {"launches": 2 * len(sites), "algorithmic_bytes": nbytes, "ms": ms, "gbs": nbytes / (ms * 1e-3) / 1e9, "issue": "host loop",
+           "shapes": sorted({(B, C, T) for (B, C, T, _) in sites}, reverse=True),
+           "note": "the step's IN launches (plan site list) back to back between one event pair, mean of %d repetitions" % reps}
+    try:   # the same sequence replayed from a HIP graph (no host launches); the faster is reported, with which it was
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                sequence(ctypes.c_void_p(side.cuda_stream))
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        gms = e0.elapsed_time(e1) / reps
+        out["host_loop_ms"], out["graph_replay_ms"] = ms, gms
+        if gms < ms:
+            out.update(ms=gms, gbs=nbytes / (gms * 1e-3) / 1e9, issue="HIP graph replay of the same launches")
+        del graph
+    except Exception as e:
+        out["graph_error"] = repr(e)[:200]
+    return out
+
+
 PMC_SUMMARIES = ("r03_pmc_fetch_write_summary.json",)
 
 
@@ -696,7 +790,12 @@ def main():
                     "traffic_source": (f"{s1}: rocprofv3 --pmc passes of this command on the same kernels (replayed, not a counter read of this run)") if have else None,
                     "algorithmic_bytes": bts, "fwd": dom_s["fwd"], "bwd": dom_s["bwd"],
                     "all_shapes_per_step": {"gbs": tot_b / (tot_ms * 1e-3) / 1e9, "ms": tot_ms, "algorithmic_bytes": tot_b,
-                                            "note": "all IN launches of one step (every T_l), each bracketed by its own event pair"}}
+                                            "note": "all IN launches of one step (every T_l), each bracketed by its own event pair (the bracket of a 5-us kernel includes event overhead)"}}
+                try:
+                    plan_, _ws = solver.model._plan(B, T, T, dev)
+                    out["roofline_instnorm"]["all_shapes_back_to_back"] = instnorm_all_shapes(plan_, pairs=(a.dtype == "bf16" and getattr(plan_, "pair_storage", False)))
+                except Exception as e:   # never lose the bench line to a diagnostic
+                    out["roofline_instnorm"]["all_shapes_back_to_back"] = {"error": repr(e)[:200]}
             out["kernel_classes"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
                                          if kk in ("ms_per_step", "launches_per_step", "avg_us", "tflops", "gbs")}
                                      for k, v in prof.items()}
