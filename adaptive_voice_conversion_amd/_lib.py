@@ -147,7 +147,7 @@ def declare(lib):
     lib.avc_dsp_stft_batch.argtypes = [c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_dsp_istft_batch.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_dsp_griffin_lim_batch.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-    lib.avc_dsp_griffin_lim_ragged.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_dsp_griffin_lim_ragged.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_dsp_magnitude.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.avc_dsp_db_normalize.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     lib.avc_dsp_denormalize_amp.argtypes = [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]

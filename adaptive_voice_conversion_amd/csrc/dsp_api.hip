@@ -100,12 +100,21 @@ int avc_dsp_griffin_lim(const float* S, int T, int n_fft, int hop_length, int wi
 }
 
 // Utterances of DIFFERENT lengths: S is [F][Ttot] with utterance b in columns toff[b] .. toff[b+1]-1 (toff: B + 1 device ints,
-// toff[0] = 0, toff[B] = Ttot; the caller guarantees every utterance has enough frames for the reflect padding:
-// hop (T_b - 1) > n_fft / 2), y receives the waveforms back to back: utterance b at sample hop (toff[b] - b).
-int avc_dsp_griffin_lim_ragged(const float* S, const int* toff, int B, int Ttot, int n_fft, int hop_length, int win_length, int n_iter,
-                               const float* basis_fwd, const float* basis_inv, float* ws, float* y, void* stream) {
-    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !toff || !basis_fwd || !basis_inv || !ws || !y || B < 1 || Ttot < 2 * B || n_iter < 0)
+// toff[0] = 0, toff[B] = Ttot), y receives the waveforms back to back: utterance b at sample hop (toff[b] - b).  toff_host is the
+// HOST copy of the same B + 1 offsets: the kernels index frames and samples through the device array without bounds checks, so the
+// library validates the host copy (monotone, toff[0] = 0, toff[B] = Ttot, hop (T_b - 1) > n_fft / 2 for the reflect padding of every
+// utterance's STFT: -6, as the equal-length entry point) and the caller keeps the two identical.
+int avc_dsp_griffin_lim_ragged(const float* S, const int* toff, const int* toff_host, int B, int Ttot, int n_fft, int hop_length, int win_length,
+                               int n_iter, const float* basis_fwd, const float* basis_inv, float* ws, float* y, void* stream) {
+    if (!dsp_geom_ok(n_fft, hop_length, win_length) || !S || !toff || !toff_host || !basis_fwd || !basis_inv || !ws || !y || B < 1 || Ttot < 2 * B ||
+        n_iter < 0)
         return -1;
+    if (toff_host[0] != 0 || toff_host[B] != Ttot) return -1;
+    for (int b = 0; b < B; ++b) {
+        const int Tb = toff_host[b + 1] - toff_host[b];
+        if (Tb < 2) return -1;
+        if ((long)hop_length * (Tb - 1) <= n_fft / 2) return -6;
+    }
     const int F = n_fft / 2 + 1, F2 = n_fft + 2;
     auto up = [](long n) { return (n + 63) / 64 * 64; };
     float* xbest = ws;

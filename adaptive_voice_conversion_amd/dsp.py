@@ -239,12 +239,13 @@ class MelDSP:
         if all(T == Ts[0] for T in Ts):
             y = self._griffin_lim_cat(mag, B, Ts[0], n_iter)
             return [self._finish(y[b], do_trim) for b in range(B)]
-        toff = torch.tensor(np.concatenate([[0], np.cumsum(Ts)]), dtype=torch.int32, device=self.device)
+        toff_host = np.ascontiguousarray(np.concatenate([[0], np.cumsum(Ts)]), dtype=np.int32)   # validated by the library
+        toff = torch.from_numpy(toff_host).to(self.device)
         Ttot = int(sum(Ts))
         ws = torch.empty(self.lib.avc_dsp_griffin_lim_ws_floats(Ttot, hp.n_fft, hp.hop_length, hp.win_length), device=self.device)
         y = torch.empty(hp.hop_length * (Ttot - B), device=self.device)
         with self._dev():
-            self._ok(self.lib.avc_dsp_griffin_lim_ragged(_P(mag), _P(toff), B, Ttot, hp.n_fft, hp.hop_length, hp.win_length,
+            self._ok(self.lib.avc_dsp_griffin_lim_ragged(_P(mag), _P(toff), ctypes.c_void_p(toff_host.ctypes.data), B, Ttot, hp.n_fft, hp.hop_length, hp.win_length,
                                                          hp.n_iter if n_iter is None else n_iter, _P(self.basis_fwd), _P(self.basis_inv),
                                                          _P(ws), _P(y), self._stream()))
         starts = [hp.hop_length * (sum(Ts[:b]) - b) for b in range(B)]

@@ -264,11 +264,12 @@ int avc_dsp_istft_batch(const float* spec, int B, int T, int n_fft, int hop_leng
                         float* y, void* stream);
 int avc_dsp_griffin_lim_batch(const float* S, int B, int T, int n_fft, int hop_length, int win_length, int n_iter, const float* basis_fwd,
                               const float* basis_inv, float* ws, float* y, void* stream);
-/* ... and of DIFFERENT lengths: toff = B + 1 device ints (first frame of every utterance, toff[B] = Ttot); S is [F][Ttot]; the
- * waveforms come back to back, utterance b (hop (T_b - 1) samples) at sample hop (toff[b] - b).  Every utterance needs
- * hop (T_b - 1) > n_fft / 2 (the reflect padding of its STFT).  ws: avc_dsp_griffin_lim_ws_floats(Ttot, ...). */
-int avc_dsp_griffin_lim_ragged(const float* S, const int* toff, int B, int Ttot, int n_fft, int hop_length, int win_length, int n_iter,
-                               const float* basis_fwd, const float* basis_inv, float* ws, float* y, void* stream);
+/* ... and of DIFFERENT lengths: toff = B + 1 device ints (first frame of every utterance, toff[B] = Ttot), toff_host = the same
+ * offsets in host memory (validated here: -1 unless monotone from 0 to Ttot, -6 unless every utterance has hop (T_b - 1) > n_fft / 2,
+ * the reflect padding of its STFT; the kernels index through the device copy unchecked); S is [F][Ttot]; the waveforms come back to
+ * back, utterance b (hop (T_b - 1) samples) at sample hop (toff[b] - b).  ws: avc_dsp_griffin_lim_ws_floats(Ttot, ...). */
+int avc_dsp_griffin_lim_ragged(const float* S, const int* toff, const int* toff_host, int B, int Ttot, int n_fft, int hop_length, int win_length,
+                               int n_iter, const float* basis_fwd, const float* basis_inv, float* ws, float* y, void* stream);
 int avc_dsp_magnitude(const float* spec, int n_fft, int T, float* mag, void* stream);                                   /* utils.py:69 */
 /* out[t][c] = clip((20 log10(max(1e-5, in[c][t])) - ref_db + max_db) / max_db, 1e-8, 1)   (utils.py:76-85) */
 int avc_dsp_db_normalize(const float* in, int C, int T, float ref_db, float max_db, float* out, void* stream);

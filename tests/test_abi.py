@@ -74,3 +74,24 @@ def test_tuning_is_plan_scoped_or_thread_local_never_process_wide():
     assert Plan(cfg, 2, 40, lib=lib).workspace_floats == plain.workspace_floats        # ... and left no trace for the next plan
     with pytest.raises(KeyError):
         Plan(cfg, 2, 40, lib=lib, tuning={"conv_rs": 1})
+
+
+def test_ragged_griffin_lim_validates_the_host_offsets():
+    """avc_dsp_griffin_lim_ragged indexes frames and samples through the DEVICE offset array without bounds checks; the library
+    validates the host copy first and refuses (before any launch: no GPU needed) offsets that are not monotone from 0 to Ttot
+    (-1) or an utterance too short for the reflect padding of its STFT (-6, as the equal-length entry point)."""
+    import numpy as np
+    from adaptive_voice_conversion_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)   # never dereferenced: every case below is rejected by the host-side checks
+    n_fft, hop, win = 2048, 300, 1200
+
+    def call(toff, Ttot, B=None):
+        th = np.ascontiguousarray(toff, dtype=np.int32)
+        return lib.avc_dsp_griffin_lim_ragged(one, one, ctypes.c_void_p(th.ctypes.data), len(toff) - 1 if B is None else B, Ttot, n_fft, hop, win, 1,
+                                              one, one, one, one, None)
+    assert call([0, 40, 30, 90], 90) == -1          # not monotone
+    assert call([1, 40, 90], 90) == -1              # does not start at 0
+    assert call([0, 40, 80], 90) == -1              # does not end at Ttot
+    assert call([0, 40, 44, 90], 90) == -6          # 4 frames: 300 * 3 <= 1024
+    assert lib.avc_dsp_griffin_lim_ragged(one, one, None, 2, 90, n_fft, hop, win, 1, one, one, one, one, None) == -1   # no host copy
