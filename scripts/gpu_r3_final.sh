@@ -13,6 +13,9 @@ timeout 900 python bench.py --steps 20 --warmup 5 --profile-json $OUT/kernel_cla
 # 3. other configurations
 j() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['ms_per_step'],3), round(d['value'],1), d['unit'])"; }
 timeout 300 python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/train_bf16_b256.json 2>/dev/null; j bf16 < $OUT/train_bf16_b256.json
+timeout 300 python bench.py --dtype bf16r --steps 20 --warmup 5 --no-cpu-baseline > $OUT/train_bf16r_b256.json 2>/dev/null; j bf16r < $OUT/train_bf16r_b256.json
+timeout 300 python bench.py --dtype bf16 --batch 64 --frames 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_bf16_t1024_b64.json 2>/dev/null; j bf16_t1024 < $OUT/train_bf16_t1024_b64.json
+timeout 300 python bench.py --dtype bf16 --mode infer --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/infer_bf16_b1024.json 2>/dev/null; j bf16_infer1024 < $OUT/infer_bf16_b1024.json
 timeout 300 python bench.py --dtype f32x3 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/train_f32x3_b256.json 2>/dev/null; j f32x3 < $OUT/train_f32x3_b256.json
 timeout 300 python bench.py --mode infer --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/infer_b1024.json 2>/dev/null; j infer1024 < $OUT/infer_b1024.json
 timeout 300 python bench.py --batch 64 --frames 1024 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_t1024_b64.json 2>/dev/null; j t1024 < $OUT/train_t1024_b64.json
@@ -27,6 +30,8 @@ find $OUT/rocprof_multi -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kerne
 find $OUT/rocprof_single -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats_single_stream.csv \;
 rm -rf $OUT/rocprof_multi $OUT/rocprof_single
 head -8 $OUT/rocprof_kernel_stats_single_stream.csv | cut -c1-200
-# 5. the GPU suite
+# 5. the GPU suite (SKIP_TESTS=1: it ran in its own call, scripts/gpu_suite.sh)
+if [ -z "$SKIP_TESTS" ]; then
 timeout 2400 python -m pytest tests -q -m gpu -s > $OUT/tests.log 2>&1; tail -4 $OUT/tests.log
 grep -o "\[gpu[^]]*\][^[]*" $OUT/tests.log | grep -v "x3 dgrad\|x3 fwd" > $OUT/gpu_parity_report.txt
+fi
