@@ -38,7 +38,7 @@ class Tuning(ctypes.Structure):
     """avc_tuning (include/avc_hip.h): launch heuristics / diagnostic switches a plan captures at creation."""
     _fields_ = [(n, ctypes.c_int) for n in ("struct_size", "single_stream", "dec_split_min", "conv_x3", "wgrad_x3", "dgrad_par", "bank_switch",
                                             "conv_ck5", "wgrad_batch", "wgrad_batch_wgs", "wgrad_target_wgs", "conv_ablation", "wgrad_ablation",
-                                            "op_compute_dtype", "tile12_wgs")] + \
+                                            "op_compute_dtype", "side_prio", "tile12_wgs")] + \
                [(n, ctypes.c_long) for n in ("wgrad_batch_units", "tile_thr11", "tile_thr21", "ck16_wgs", "ck32_wgs", "kg_wgs", "conv_min_lds", "in_pairs_nv", "bh_ck5")]
 
 
@@ -169,6 +169,10 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or adaptive_voice_conversion_amd/csrc/build.sh)")
+        # torch first: its wheel bundles its own libamdhip64 (soname .so.7, looked up as "libamdhip64.so" through torch/lib's RPATH); if this
+        # library pulled /opt/rocm's copy in before torch, the process would hold TWO HIP runtimes and every launch on a torch stream would
+        # fail with hipErrorNoDevice (100).  With torch's copy already mapped, the .so.7 dependency below resolves to it.
+        import torch  # noqa: F401
         try:
             _lib = declare(ctypes.CDLL(LIB_PATH))
         except OSError as e:  # pragma: no cover

@@ -618,7 +618,12 @@ extern "C" int avc_plan_compute_dtype(const avc_plan* p) { return p ? p->compute
 
 static void plan_init_streams(avc_plan* p) {
     p->side_state = -1;
-    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
+    // the side stream carries the speaker-encoder branch: the LONGER pole of both passes (forward: pooling + the latency-bound dense stack
+    // after its convs, before the decoder can start; backward: d_emb -> dense stack -> its whole dgrad chain -> the last weight gradients).
+    // side_prio = 1 dispatches its workgroups ahead of the content branch's and the weight-gradient streams'.
+    if ((p->tun.side_prio ? hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking)) != hipSuccess) {
         (void)hipGetLastError();  // no device: single-stream plan
         return;
     }
@@ -627,8 +632,6 @@ static void plan_init_streams(avc_plan* p) {
               hipEventCreateWithFlags(&p->ev_dec_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_spk_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
     for (int i = 0; i < 2; ++i) {
         ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;

@@ -55,7 +55,7 @@ int avc_set_tuning(const char* name, int value) {
 #define AVC_TUNE_FIELD(f) if (!strcmp(name, #f)) { t.f = value; return 0; }
     AVC_TUNE_FIELD(single_stream) AVC_TUNE_FIELD(dec_split_min) AVC_TUNE_FIELD(conv_x3) AVC_TUNE_FIELD(wgrad_x3) AVC_TUNE_FIELD(dgrad_par)
     AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
-    AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(wgrad_batch_units)
+    AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(side_prio) AVC_TUNE_FIELD(wgrad_batch_units)
     AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds)
 #undef AVC_TUNE_FIELD
     if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }

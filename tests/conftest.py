@@ -8,6 +8,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: the kernels on the lane-level simulator, the oracle against the goldens, 2-rank gloo) is 12 minutes
+    of mostly single-threaded work in one process; on a box WITHOUT a GPU it is spread over 4 pytest-xdist workers unless the caller
+    chose a worker count (or AVC_TESTS_SERIAL=1).  GPU runs stay in one process: the tests share one device.
+    xdist workers run this hook too: the inherited AVC_TESTS_XDIST_PARENT / PYTEST_XDIST_WORKER guards keep them from spawning workers
+    of their own."""
+    if os.environ.get("AVC_TESTS_XDIST_PARENT") or os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput") \
+            or os.environ.get("AVC_TESTS_SERIAL"):
+        return None
+    opt = config.option
+    if not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", "absent") is not None:
+        return None   # xdist absent / disabled (-p no:xdist), or -n given
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return None
+    except Exception:
+        return None
+    os.environ["AVC_TESTS_XDIST_PARENT"] = "1"      # inherited by every worker process
+    os.environ.setdefault("OMP_NUM_THREADS", "2")   # 4 workers x 2 threads on the 8-vCPU build box
+    opt.numprocesses = min(4, max(1, (os.cpu_count() or 2) // 2))
+    opt.tx = ["popen"] * opt.numprocesses
+    if getattr(opt, "dist", "no") == "no":
+        opt.dist = "load"
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
     config.addinivalue_line("markers", "slow: long-running CPU test")

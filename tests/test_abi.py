@@ -2,6 +2,7 @@
 include/avc_hip.h declares (no compute: there is no GPU in the CPU test tier),
 and the product loader fails loudly instead of falling back."""
 import ctypes
+import torch  # noqa: F401  (before the library: one HIP runtime per process, see _lib.load)
 import os
 import re
 import subprocess
