@@ -83,6 +83,7 @@ def branch_matched_oracle(plan, ws, x, eps, sd, cfg):
 CASES = [
     ("emu", "tiny", 2, 32, False), ("emu", "tiny", 3, 24, True),
     ("emu", "tiny_lrelu", 3, 40, False),   # act: lrelu in all three networks
+    ("emu", "tiny", 19, 16, False),        # two workgroups of the 16-sample dense-stack kernel, the second one partial
     pytest.param("gpu", "tiny_lrelu", 5, 64, False, marks=GPU),
     ("emu", "tiny128", 2, 40, False),   # 128 hidden channels
     ("emu", "tiny128x3", 2, 40, False), # ... + tuning conv_x3 = 2: the split-bf16 conv kernel in every eligible layer of the plan
