@@ -1,0 +1,38 @@
+"""Diagnostics of Solver's half-batch pipeline on the GPU: (1) is the overlapped issue BIT-identical to the same two plans issued serially
+(every kernel is deterministic: any difference is a race)?  (2) how far is it from the whole-batch step?  (3) ms/step."""
+import copy, os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adaptive_voice_conversion_amd.solver import Solver
+from bench import stock_config
+
+B, T, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+tun = {k: int(v) for k, v in (kv.split("=") for kv in sys.argv[4:])}
+dev = torch.device("cuda", 0)
+cfg = stock_config(80)
+g = torch.Generator().manual_seed(1)
+x = torch.randn(B, 80, T, generator=g).to(dev)
+args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_log", tuning=tun)
+
+def run(halves, serial, n, skew="forward"):
+    c = copy.deepcopy(cfg); c["pipeline_halves"] = halves; c["pipeline_skew"] = skew
+    torch.manual_seed(0)
+    s = Solver(c, args)
+    s.halves_serial = serial
+    p = s.step_plans(B, T, dev, x)[0][0]
+    eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], p.latent_len, generator=torch.Generator().manual_seed(2)).to(dev)
+    for _ in range(3): s.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): s.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / n
+    return s.model.flat_parameters().clone(), ms
+
+print(f"B={B} T={T} steps={steps} tuning={tun} GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
+pw, tw = run(False, False, steps)
+ps, ts = run(True, True, steps)
+po, to = run(True, False, steps)
+po2, to2 = run(True, False, steps)
+pn, tn = run(True, False, steps, skew="none")
+d = lambda a, b: (int((a != b).sum()), float((a - b).abs().max()))
+print(f"  whole batch {tw:.3f} ms | halves serial {ts:.3f} | halves overlapped {to:.3f} / {to2:.3f} | skew none {tn:.3f}")
+print(f"  overlapped vs serial (differing elements, max |diff|): {d(po, ps)}; overlapped run 2 vs run 1: {d(po2, po)}; skew none vs serial: {d(pn, ps)}; serial vs whole batch: {d(ps, pw)}")
