@@ -64,27 +64,44 @@ static __device__ __forceinline__ ConvEpi conv_epi(const ConvArgs& a) {
     return e;
 }
 
-static inline __device__ float conv_load_res(const ConvEpi& a, const float* res, int b, int m, int t) {
-    const float* base = res + a.rbase + (long)b * a.rb + (long)m * a.rc;
+// residual term of one output element from the (up to two) values conv_res_fetch loaded for it
+static __device__ __forceinline__ float conv_res_value(const ConvEpi& a, float v0, float v1, int t) {
     switch (a.res_mode) {
         case AVC_RES_IDENTITY:
-            return base[(long)t * a.rt];
-        case AVC_RES_AVGPOOL2: {
-            int i0 = 2 * t, i1 = 2 * t + 1;
-            float v0 = base[(long)i0 * a.rt];
-            if (i1 < a.Tres) return (v0 + base[(long)i1 * a.rt]) * 0.5f;
-            return v0;  // clipped window of ceil_mode: divisor 1
-        }
+            return v0;
+        case AVC_RES_AVGPOOL2:
+            return (2 * t + 1 < a.Tres) ? (v0 + v1) * 0.5f : v0;  // clipped window of ceil_mode: divisor 1
         case AVC_RES_POOLT: {
-            float gsrc = base[(long)(t >> 1) * a.rt];
-            bool single = (a.Tout & 1) && (t == a.Tout - 1);
-            return single ? gsrc : gsrc * 0.5f;
+            const bool single = (a.Tout & 1) && (t == a.Tout - 1);
+            return single ? v0 : v0 * 0.5f;
         }
         case AVC_RES_UPT:
-            return base[(long)(2 * t) * a.rt] + base[(long)(2 * t + 1) * a.rt];
+            return v0 + v1;
         default:
             return 0.f;
     }
+}
+// element offsets (inside a residual row) of the values conv_res_value combines; i1 < 0: one value only.  Always in range.
+static __device__ __forceinline__ void conv_res_index(const ConvEpi& a, int t, long& i0, long& i1) {
+    i1 = -1;
+    switch (a.res_mode) {
+        case AVC_RES_IDENTITY: i0 = (long)t * a.rt; break;
+        case AVC_RES_AVGPOOL2: {
+            const int j1 = 2 * t + 1;
+            i0 = (long)(2 * t) * a.rt;
+            i1 = (long)(j1 < a.Tres ? j1 : 2 * t) * a.rt;
+            break;
+        }
+        case AVC_RES_POOLT: i0 = (long)(t >> 1) * a.rt; break;
+        case AVC_RES_UPT: i0 = (long)(2 * t) * a.rt; i1 = (long)(2 * t + 1) * a.rt; break;
+        default: i0 = 0;
+    }
+}
+static inline __device__ float conv_load_res(const ConvEpi& a, const float* res, int b, int m, int t) {
+    const float* base = res + a.rbase + (long)b * a.rb + (long)m * a.rc;
+    long i0, i1;
+    conv_res_index(a, t, i0, i1);
+    return conv_res_value(a, base[i0], i1 >= 0 ? base[i1] : 0.f, t);
 }
 
 
@@ -92,99 +109,185 @@ static inline __device__ float conv_load_res(const ConvEpi& a, const float* res,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): bias, ReLU, pixel-shuffle store index, residual /
 // gradient join, secondary output and ReLU mask of the backward pass.  m_base = first output row of the
 // fragment, (b, t) = the lane's column.
+// Eight rows at a time in three phases: every global LOAD of the eight rows (bias, residual, mask; row indices clamped instead of
+// branched on, only launch-uniform conditions around them), ONE straight-line block that consumes them, then the stores.  Written
+// row by row (load bias - use - load residual - use - store - load mask - use - store, inside `m < M` conditionals) the compiler
+// drains the vector-memory counter in front of every use -- up to three exposed memory round trips per ROW, 16 rows per fragment:
+// invisible where four workgroups share a CU, most of the run time of the small-grid launches (T_l <= 32, B <= 16).
 static __device__ __forceinline__ void conv_store_frag(const ConvEpi& a, const ConvGroup& g, const f32x16& acc, int m_base, int h,
                                                        int b, int t) {
+    const bool has_res = a.res_mode != AVC_RES_NONE;
+    const bool has_mask = g.out2 && g.mask;
+    const bool res_two = a.res_mode == AVC_RES_AVGPOOL2 || a.res_mode == AVC_RES_UPT;   // (launch-uniform: two values per residual term)
+    long ri0 = 0, ri1 = -1;
+    if (has_res) conv_res_index(a, t, ri0, ri1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= a.M) continue;
-        float v = acc[r];
-        if (g.bias) v += g.bias[m];
-        if (a.act == 1) v = avc_act(v, a.slope);
-        long o;
-        if (a.ops == 1)
-            o = a.obase + (long)b * a.ob + (long)m * a.oc + (long)t * a.ot;
-        else
-            o = a.obase + (long)b * a.ob + (long)(m / a.ops) * a.oc + (long)(t * a.ops + (m % a.ops)) * a.ot;
-        float rr = 0.f;
-        if (a.res_mode != AVC_RES_NONE) rr = conv_load_res(a, g.res, b, m, t);
-        if (a.res_to_primary) v += rr;
-        if (g.out) g.out[o] = v;
-        if (g.out2) {
-            float v2 = a.res_to_primary ? v : v + rr;
-            if (g.mask) v2 = avc_act_grad(v2, g.mask[o] > 0.f, a.slope);
-            g.out2[o] = v2;
+    for (int half = 0; half < 2; ++half) {
+        float bs[8], q0[8], q1[8], mk[8];
+        long o[8];
+        // ---- loads
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = 8 * half + e;
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int mc = m < a.M ? m : a.M - 1;
+            if (a.ops == 1)
+                o[e] = a.obase + (long)b * a.ob + (long)mc * a.oc + (long)t * a.ot;
+            else
+                o[e] = a.obase + (long)b * a.ob + (long)(mc / a.ops) * a.oc + (long)(t * a.ops + (mc % a.ops)) * a.ot;
+            bs[e] = q0[e] = q1[e] = mk[e] = 0.f;
+        }
+        if (g.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * half + e;
+                const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                bs[e] = g.bias[m < a.M ? m : a.M - 1];
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * half + e;
+                const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float* base = g.res + a.rbase + (long)b * a.rb + (long)(m < a.M ? m : a.M - 1) * a.rc;
+                q0[e] = base[ri0];
+                if (res_two) q1[e] = base[ri1];
+            }
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mk[e] = g.mask[o[e]];
+        }
+        // ---- everything that depends on a load, in one straight-line block
+        float v[8], v2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = g.bias ? acc[8 * half + e] + bs[e] : acc[8 * half + e];
+            if (a.act == 1) x = avc_act(x, a.slope);
+            const float rr = has_res ? conv_res_value(a, q0[e], q1[e], t) : 0.f;
+            if (a.res_to_primary) x += rr;
+            float y = a.res_to_primary ? x : x + rr;
+            if (has_mask) y = avc_act_grad(y, mk[e] > 0.f, a.slope);
+            v[e] = x;
+            v2[e] = y;
+        }
+        // ---- stores
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = 8 * half + e;
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < a.M) {
+                if (g.out) g.out[o[e]] = v[e];
+                if (g.out2) g.out2[o[e]] = v2[e];
+            }
         }
     }
 }
 
 // ---- the same epilogue on bf16 PAIR tensors (bf16_pairs.h): rows m (even) and m + 1 of the lane's column are one dword.
 // Strides are dword strides of the [B][C/2][T] tensors; M is even; time stride 1.
-static inline __device__ void conv_load_res_pair(const ConvEpi& a, const float* res, int b, int m, int t, float& r0, float& r1) {
-    const unsigned* base = (const unsigned*)res + a.rbase + (long)b * a.rb + (long)(m >> 1) * a.rc;
+// the (up to two) dwords of a residual pair row that conv_res_value's modes combine, as element offsets inside the row (time stride 1)
+static __device__ __forceinline__ void conv_res_index_pair(const ConvEpi& a, int t, int& i0, int& i1) {
+    i1 = -1;
     switch (a.res_mode) {
-        case AVC_RES_IDENTITY: {
-            const unsigned d = base[t];
-            r0 = bh_lo(d); r1 = bh_hi(d);
-            return;
-        }
-        case AVC_RES_AVGPOOL2: {
-            const int i0 = 2 * t, i1 = 2 * t + 1;
-            const unsigned d0 = base[i0];
-            r0 = bh_lo(d0); r1 = bh_hi(d0);
-            if (i1 < a.Tres) {   // (a clipped window of ceil_mode divides by 1)
-                const unsigned d1 = base[i1];
-                r0 = (r0 + bh_lo(d1)) * 0.5f;
-                r1 = (r1 + bh_hi(d1)) * 0.5f;
-            }
-            return;
-        }
-        case AVC_RES_POOLT: {
-            const unsigned d = base[t >> 1];
-            const bool single = (a.Tout & 1) && (t == a.Tout - 1);
-            const float k = single ? 1.0f : 0.5f;
-            r0 = bh_lo(d) * k; r1 = bh_hi(d) * k;
-            return;
-        }
-        case AVC_RES_UPT: {
-            const unsigned d0 = base[2 * t], d1 = base[2 * t + 1];
-            r0 = bh_lo(d0) + bh_lo(d1);
-            r1 = bh_hi(d0) + bh_hi(d1);
-            return;
-        }
-        default:
-            r0 = r1 = 0.f;
+        case AVC_RES_IDENTITY: i0 = t; break;
+        case AVC_RES_AVGPOOL2: i0 = 2 * t; i1 = (2 * t + 1 < a.Tres) ? 2 * t + 1 : 2 * t; break;
+        case AVC_RES_POOLT: i0 = t >> 1; break;
+        case AVC_RES_UPT: i0 = 2 * t; i1 = 2 * t + 1; break;
+        default: i0 = 0;
     }
 }
+static inline __device__ void conv_load_res_pair(const ConvEpi& a, const float* res, int b, int m, int t, float& r0, float& r1) {
+    const unsigned* base = (const unsigned*)res + a.rbase + (long)b * a.rb + (long)(m >> 1) * a.rc;
+    int i0, i1;
+    conv_res_index_pair(a, t, i0, i1);
+    const unsigned d0 = base[i0], d1 = i1 >= 0 ? base[i1] : 0u;
+    r0 = conv_res_value(a, bh_lo(d0), bh_lo(d1), t);
+    r1 = conv_res_value(a, bh_hi(d0), bh_hi(d1), t);
+}
 
+// (phases as in conv_store_frag: the loads of four row pairs, one straight-line block, the stores)
 static __device__ __forceinline__ void conv_store_frag_pairs(const ConvEpi& a, const ConvGroup& g, const f32x16& acc, int m_base, int h,
                                                              int b, int t) {
     unsigned* out = (unsigned*)g.out;
     unsigned* out2 = (unsigned*)g.out2;
     const unsigned* mask = (const unsigned*)g.mask;
+    const bool has_res = a.res_mode != AVC_RES_NONE;
+    const bool has_mask = out2 && mask;
+    const bool res_two = a.res_mode == AVC_RES_AVGPOOL2 || a.res_mode == AVC_RES_UPT;
+    int ri0 = 0, ri1 = -1;
+    if (has_res) conv_res_index_pair(a, t, ri0, ri1);
 #pragma unroll
-    for (int rp = 0; rp < 8; ++rp) {
-        const int r = 2 * rp;                                     // accumulator rows r, r + 1 = output rows m, m + 1
-        const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;    // even
-        if (m >= a.M) continue;
-        float v0 = acc[r], v1 = acc[r + 1];
-        if (g.bias) { v0 += g.bias[m]; v1 += g.bias[m + 1]; }
-        if (a.act == 1) { v0 = avc_act(v0, a.slope); v1 = avc_act(v1, a.slope); }
-        float r0 = 0.f, r1 = 0.f;
-        if (a.res_mode != AVC_RES_NONE) conv_load_res_pair(a, g.res, b, m, t, r0, r1);
-        if (a.res_to_primary) { v0 += r0; v1 += r1; }
-        // (a pixel-shuffling layer, model.py:52-59, stores its conv-output pairs as they are: rows m, m + 1 are frames 2 t, 2 t + 1
-        // of channel m / 2, i.e. the natural [B][C][2 T] bf16 layout -- the InstanceNorm that follows reads such "planar" rows)
-        const long o = a.obase + (long)b * a.ob + (long)(m >> 1) * a.oc + t;
-        if (out) out[o] = bh_pack(v0, v1);
-        if (out2) {
-            float w0 = a.res_to_primary ? v0 : v0 + r0, w1 = a.res_to_primary ? v1 : v1 + r1;
-            if (mask) {
-                const unsigned md = mask[o];
-                w0 = avc_act_grad(w0, bh_lo(md) > 0.f, a.slope);
-                w1 = avc_act_grad(w1, bh_hi(md) > 0.f, a.slope);
+    for (int half = 0; half < 2; ++half) {
+        float b0[4], b1[4];
+        unsigned d0[4], d1[4], md[4];
+        long o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * (4 * half + e);                          // accumulator rows r, r + 1 = output rows m, m + 1
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;     // even
+            const int mc = m < a.M ? m : a.M - 2;
+            // (a pixel-shuffling layer, model.py:52-59, stores its conv-output pairs as they are: rows m, m + 1 are frames 2 t, 2 t + 1
+            // of channel m / 2, i.e. the natural [B][C][2 T] bf16 layout -- the InstanceNorm that follows reads such "planar" rows)
+            o[e] = a.obase + (long)b * a.ob + (long)(mc >> 1) * a.oc + t;
+            b0[e] = b1[e] = 0.f;
+            d0[e] = d1[e] = md[e] = 0u;
+        }
+        if (g.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 2 * (4 * half + e);
+                const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int mc = m < a.M ? m : a.M - 2;
+                b0[e] = g.bias[mc];
+                b1[e] = g.bias[mc + 1];
             }
-            out2[o] = bh_pack(w0, w1);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 2 * (4 * half + e);
+                const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int mc = m < a.M ? m : a.M - 2;
+                const unsigned* base = (const unsigned*)g.res + a.rbase + (long)b * a.rb + (long)(mc >> 1) * a.rc;
+                d0[e] = base[ri0];
+                if (res_two) d1[e] = base[ri1];
+            }
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) md[e] = mask[o[e]];
+        }
+        unsigned w[4], w2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * (4 * half + e);
+            float v0 = acc[r], v1 = acc[r + 1];
+            if (g.bias) { v0 += b0[e]; v1 += b1[e]; }
+            if (a.act == 1) { v0 = avc_act(v0, a.slope); v1 = avc_act(v1, a.slope); }
+            float r0 = 0.f, r1 = 0.f;
+            if (has_res) {
+                r0 = conv_res_value(a, bh_lo(d0[e]), bh_lo(d1[e]), t);
+                r1 = conv_res_value(a, bh_hi(d0[e]), bh_hi(d1[e]), t);
+            }
+            if (a.res_to_primary) { v0 += r0; v1 += r1; }
+            float w0 = a.res_to_primary ? v0 : v0 + r0, w1 = a.res_to_primary ? v1 : v1 + r1;
+            if (has_mask) {
+                w0 = avc_act_grad(w0, bh_lo(md[e]) > 0.f, a.slope);
+                w1 = avc_act_grad(w1, bh_hi(md[e]) > 0.f, a.slope);
+            }
+            w[e] = bh_pack(v0, v1);
+            w2[e] = bh_pack(w0, w1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * (4 * half + e);
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < a.M) {
+                if (out) out[o[e]] = w[e];
+                if (out2) out2[o[e]] = w2[e];
+            }
         }
     }
 }
