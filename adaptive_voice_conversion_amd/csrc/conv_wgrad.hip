@@ -576,15 +576,21 @@ __global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceAr
     const ReduceSeg s = a.seg[blockIdx.y];
     const int plane = s.n / s.KS;  // slab is [tap][rows*Cin]; dst is [rows*Cin][tap]
     for (int e = blockIdx.x * AVC_THREADS + threadIdx.x; e < s.n; e += gridDim.x * AVC_THREADS) {
-        // fixed summation order (deterministic); 4 independent loads in flight per thread
+        // fixed summation order (deterministic: v + slab 0 + slab 1 + ..., as ever); 16 independent loads in flight per thread -- a
+        // thread owns one or two elements, so the kernel's run time is (slabs / loads in flight) dependent HBM round trips: 4 in flight
+        // were 6-8 trips for 23-30 slabs, 16 are 2 (slots past the last slab re-read it and are not added)
         float v = 0.f;
-        int zz = 0;
-        for (; zz + 4 <= s.nsplit; zz += 4) {
-            const float* q = s.slab + (long)zz * s.stride + e;
-            float a0 = q[0], a1 = q[s.stride], a2 = q[2 * s.stride], a3 = q[3 * s.stride];
-            v = (((v + a0) + a1) + a2) + a3;
+        for (int zz = 0; zz < s.nsplit; zz += 16) {
+            float q[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = zz + k < s.nsplit ? zz + k : s.nsplit - 1;
+                q[k] = s.slab[(long)z * s.stride + e];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (zz + k < s.nsplit) v += q[k];
         }
-        for (; zz < s.nsplit; ++zz) v += s.slab[(long)zz * s.stride + e];
         if (s.KS == 1) {
             s.dst[e] = v;
         } else {

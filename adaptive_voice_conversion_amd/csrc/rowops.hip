@@ -66,18 +66,30 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdAr
     const int rr = rvalid ? row : 0;
     const int n4 = a.T >> 2;
     const float* yrow = a.y + (long)rr * a.T;
-    float4 v[NV];
+    float4 v[NV], rv[NV];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         int i4 = k * LPR + l;
-        if (i4 < n4) {
-            v[k] = *(const float4*)(yrow + 4 * i4);
-            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        } else {
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        v[k] = (i4 < n4) ? *(const float4*)(yrow + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // every other load of the row -- the AdaIN scale / shift and the residual -- goes out NOW, behind the row itself: written where they
+    // are used (after the two reductions) they are a second and a third dependent memory round trip of a 5-8 us kernel
+    float gamma = 1.f, beta = 0.f;
+    const int b = rr / a.C, c = rr - b * a.C;
+    if (a.cond) {
+        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
+        beta = cr[c];          // first half = shift   (model.py:81)
+        gamma = cr[a.C + c];   // second half = scale
+    }
+    const float* rrow = a.res ? a.res + (long)rr * a.Tres : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        rv[k] = (rrow && i4 < n4) ? res4(rrow, a.res_mode, 4 * i4, a.Tres) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     const float invT = 1.0f / (float)a.T;
     const float mean = group_sum<LPR>(s) * invT;
     float ss = 0.f;
@@ -91,20 +103,12 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdAr
     }
     const float var = group_sum<LPR>(ss) * invT;  // biased variance
     const float rstd = 1.0f / sqrtf(var + AVC_IN_EPS);
-    float gamma = 1.f, beta = 0.f;
-    const int b = rr / a.C, c = rr - b * a.C;
-    if (a.cond) {
-        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
-        beta = cr[c];          // first half = shift   (model.py:81)
-        gamma = cr[a.C + c];   // second half = scale
-    }
     if (rvalid && l == 0) {
         a.mean[row] = mean;
         a.rstd[row] = rstd;
     }
     if (!rvalid) return;
     float* orow = a.out + (long)row * a.T;
-    const float* rrow = a.res ? a.res + (long)row * a.Tres : nullptr;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         int i4 = k * LPR + l;
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdAr
                 o[e] = a.relu ? avc_act(w, a.slope) : w;
             }
             if (rrow) {
-                float4 r = res4(rrow, a.res_mode, 4 * i4, a.Tres);
+                const float4 r = rv[k];
                 o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
             }
             *(float4*)(orow + 4 * i4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -520,6 +524,44 @@ __global__ void __launch_bounds__(AVC_THREADS) clip_adam_kernel(const AdamArgs a
     if (a.max_norm <= 0.f) coef = 1.0f;
     coef *= a.grad_prescale;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.gnorm_out) a.gnorm_out[0] = gnorm;
+    // 16-byte path (the flat buffers of a plan: every tensor padded to four floats, 256-byte aligned allocations): the scalar loop below
+    // is one dependent memory round trip per ELEMENT and thread (19 of them at 4.9 M parameters), the same arithmetic on four elements
+    // per trip runs at the HBM rate
+    const bool vec = ((a.n & 3) == 0) && ((((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v | (size_t)a.vmax) & 15) == 0);
+    if (vec) {
+        const long n4 = a.n >> 2;
+        for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < n4; e += (long)gridDim.x * AVC_THREADS) {
+            const float4 p4 = ((const float4*)a.p)[e], g4 = ((const float4*)a.g)[e], m4 = ((const float4*)a.m)[e], v4 = ((const float4*)a.v)[e];
+            const float4 x4 = a.amsgrad ? ((const float4*)a.vmax)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float pp[4] = {p4.x, p4.y, p4.z, p4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+            float vv[4] = {v4.x, v4.y, v4.z, v4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float g = gg[k] * coef;
+                gg[k] = g;
+                g = g + a.weight_decay * pp[k];
+                const float m = a.beta1 * mm[k] + (1.0f - a.beta1) * g;
+                const float v = a.beta2 * vv[k] + (1.0f - a.beta2) * g * g;
+                float denom;
+                if (a.amsgrad) {
+                    const float vm = fmaxf(xx[k], v);
+                    xx[k] = vm;
+                    denom = sqrtf(vm) / a.sqrt_bc2 + a.eps;
+                } else {
+                    denom = sqrtf(v) / a.sqrt_bc2 + a.eps;
+                }
+                mm[k] = m;
+                vv[k] = v;
+                pp[k] = pp[k] - a.step_size * (m / denom);
+            }
+            if (a.write_clipped) ((float4*)a.g)[e] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+            if (a.amsgrad) ((float4*)a.vmax)[e] = make_float4(xx[0], xx[1], xx[2], xx[3]);
+            ((float4*)a.m)[e] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            ((float4*)a.v)[e] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            ((float4*)a.p)[e] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        }
+        return;
+    }
     for (long e = (long)blockIdx.x * AVC_THREADS + threadIdx.x; e < a.n; e += (long)gridDim.x * AVC_THREADS) {
         float p = a.p[e];
         float g = a.g[e] * coef;

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_pairs_kernel(const I
     const long rr = rvalid ? row : 0;
     const int n4 = a.T >> 2;
     const unsigned* y = (const unsigned*)a.y;
-    float vl[NV][4], vh[NV][4];
+    float vl[NV][4], vh[NV][4], rl[NV][4], rh[NV][4];
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -99,12 +99,36 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_pairs_kernel(const I
         if (i4 < n4) {
             if (a.planar) ld_planar4(y, rr, a.T, i4, vl[k], vh[k]);
             else ld_pairs4(y, rr, a.T, i4, vl[k], vh[k]);
-            s0 += (vl[k][0] + vl[k][1]) + (vl[k][2] + vl[k][3]);
-            s1 += (vh[k][0] + vh[k][1]) + (vh[k][2] + vh[k][3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) vl[k][e] = vh[k][e] = 0.f;
         }
+    }
+    // the AdaIN scale / shift and the residual are requested NOW, behind the row itself (rowops.hip instnorm_fwd_kernel: one memory
+    // round trip per launch instead of three)
+    const int C2 = a.C >> 1;
+    const int b = (int)(rr / C2), p = (int)(rr - (long)b * C2);
+    const int c0 = 2 * p;
+    float g0 = 1.f, g1 = 1.f, be0 = 0.f, be1 = 0.f;
+    if (a.cond) {
+        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
+        be0 = cr[c0]; be1 = cr[c0 + 1];               // first half = shift (model.py:81)
+        g0 = cr[a.C + c0]; g1 = cr[a.C + c0 + 1];     // second half = scale
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = k * LPR + l;
+        if (a.res && i4 < n4) {
+            res_pairs4((const unsigned*)a.res, rr, a.res_mode, i4, a.Tres, rl[k], rh[k]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rl[k][e] = rh[k][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        s0 += (vl[k][0] + vl[k][1]) + (vl[k][2] + vl[k][3]);
+        s1 += (vh[k][0] + vh[k][1]) + (vh[k][2] + vh[k][3]);
     }
     const float invT = 1.0f / (float)a.T;
     const float mean0 = group_sum<LPR>(s0) * invT, mean1 = group_sum<LPR>(s1) * invT;
@@ -123,15 +147,6 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_pairs_kernel(const I
     }
     const float rstd0 = 1.0f / sqrtf(group_sum<LPR>(q0) * invT + AVC_IN_EPS);   // biased variance
     const float rstd1 = 1.0f / sqrtf(group_sum<LPR>(q1) * invT + AVC_IN_EPS);
-    const int C2 = a.C >> 1;
-    const int b = (int)(rr / C2), p = (int)(rr - (long)b * C2);
-    const int c0 = 2 * p;
-    float g0 = 1.f, g1 = 1.f, be0 = 0.f, be1 = 0.f;
-    if (a.cond) {
-        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
-        be0 = cr[c0]; be1 = cr[c0 + 1];               // first half = shift (model.py:81)
-        g0 = cr[a.C + c0]; g1 = cr[a.C + c0 + 1];     // second half = scale
-    }
     if (rvalid && l == 0) {
         const long sr = (long)b * a.C + c0;
         a.mean[sr] = mean0; a.mean[sr + 1] = mean1;
@@ -152,10 +167,8 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_pairs_kernel(const I
                 o1[e] = a.relu ? avc_act(w1, a.slope) : w1;
             }
             if (a.res) {
-                float r0[4], r1[4];
-                res_pairs4((const unsigned*)a.res, rr, a.res_mode, i4, a.Tres, r0, r1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o0[e] += r0[e]; o1[e] += r1[e]; }
+                for (int e = 0; e < 4; ++e) { o0[e] += rl[k][e]; o1[e] += rh[k][e]; }
             }
             st_pairs4(out, rr, a.T, i4, o0, o1);
         }
