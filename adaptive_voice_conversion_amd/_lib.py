@@ -45,6 +45,7 @@ class Tuning(ctypes.Structure):
 PLAN_X3 = 4
 PLAN_RAGGED = 8
 PLAN_BF16S = 16
+ERR_PAIR_SHAPE = -12   # avc_plan_create*: the shape is outside the bf16 pair kernels (odd channel count / frames not a multiple of 4)
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 

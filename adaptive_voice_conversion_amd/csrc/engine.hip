@@ -365,7 +365,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         for (int l = 0; l < p->enc.n; ++l) ok = ok && (p->enc.T[l] <= 2048) && (p->spk.T[l] <= 2048);
         if (!ok) {
             delete p;
-            return fail(-2, "avc_plan_create: AVC_PLAN_BF16S needs even channel counts and frame counts that are multiples of 4 (<= 2048) at every level");
+            return fail(AVC_ERR_PAIR_SHAPE, "avc_plan_create: AVC_PLAN_BF16S needs even channel counts and frame counts that are multiples of 4 (<= 2048) at every level");
         }
     }
 

@@ -13,11 +13,28 @@ from ._lib import DecoderCfg, EncoderCfg, ModelCfg
 
 
 ACTS = {"relu": 0, "lrelu": 1}   # model.py:93-99 get_act: nn.ReLU / nn.LeakyReLU (slope 0.01)
+_warned = set()
+
+
+def _warn_once(key, msg):
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _act_code(name, c):
+    """model.py:93-99 get_act: 'relu' -> ReLU, 'lrelu' -> LeakyReLU, ANYTHING ELSE -> ReLU as well (the reference's fallback branch).
+    The same here, with a warning: a config with e.g. act: 'elu' trains as ReLU in the reference too."""
+    act = c.get("act", "relu")
+    if act not in ACTS:
+        _warn_once(("act", name, str(act)), f"{name}.act={act!r}: the reference's get_act (model.py:93-99) maps every string other than "
+                                            "'relu' / 'lrelu' to nn.ReLU(); so does this engine.")
+        return ACTS["relu"]
+    return ACTS[act]
 
 
 def _check_common(name, c):
-    if c.get("act", "relu") not in ACTS:
-        raise NotImplementedError(f"{name}.act={c['act']!r}: 'relu' or 'lrelu' (model.py:93-99)")
     if float(c.get("dropout_rate", 0)) != 0.0:
         raise NotImplementedError(f"{name}.dropout_rate={c['dropout_rate']}: only 0 (config.yaml default) is implemented")
 
@@ -31,7 +48,7 @@ def cfg_from_dict(config) -> ModelCfg:
         for f in ("c_in", "c_h", "c_out", "kernel_size", "bank_size", "bank_scale", "c_bank", "n_conv_blocks"):
             setattr(dst, f, int(c[f]))
         dst.n_dense_blocks = int(c["n_dense_blocks"]) if dense else 0
-        dst.act = ACTS[c.get("act", "relu")]
+        dst.act = _act_code(key, c)
         if dst.n_conv_blocks > _lib.MAX_BLOCKS:
             raise NotImplementedError("more than 8 conv blocks")
         for i, s in enumerate(list(c["subsample"])[: dst.n_conv_blocks]):
@@ -42,7 +59,7 @@ def cfg_from_dict(config) -> ModelCfg:
         raise NotImplementedError("Decoder.sn=True (spectral norm) is not implemented; config.yaml default is False")
     for f in ("c_in", "c_cond", "c_h", "c_out", "kernel_size", "n_conv_blocks"):
         setattr(m.dec, f, int(d[f]))
-    m.dec.act = ACTS[d.get("act", "relu")]
+    m.dec.act = _act_code("Decoder", d)
     for i, s in enumerate(list(d["upsample"])[: m.dec.n_conv_blocks]):
         m.dec.upsample[i] = int(s)
     return m
@@ -119,7 +136,13 @@ class Plan:
         with (torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()):
             rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags | (_lib.PLAN_BF16S if bh else 0),
                                                 ctypes.byref(tun), ctypes.byref(h))
-            if rc == -2 and bh and not strict:   # a shape outside the pair kernels: the operand-rounding bf16 mode takes any shape
+            if rc == _lib.ERR_PAIR_SHAPE and bh and not strict:
+                # a shape outside the pair kernels (and nothing else: every other failure is reported): the operand-rounding bf16 mode takes
+                # any shape.  The numerics (and the speed) of "bf16" then differ between shapes of the same model -- say so, once per shape class.
+                _warn_once(("bf16r", self.T % 4, self.T_cond % 4),
+                           f"compute_dtype 'bf16': B={self.B}, T={self.T}, T_cond={self.T_cond} is outside the bf16 storage engine "
+                           f"({self.lib.avc_last_error().decode()}); this plan runs 'bf16r' (fp32 storage, operands rounded to bf16) instead. "
+                           "Pass compute_dtype='bf16s' to make this an error.")
                 bh = False
                 rc = self.lib.avc_plan_create_tuned(ctypes.byref(self.cfg), self.B, self.T, self.T_cond, flags, ctypes.byref(tun), ctypes.byref(h))
         if rc != 0:

@@ -104,17 +104,36 @@ class _PlanCache:
         from collections import OrderedDict
         self.capacity = dict(capacity)
         self.d = {m: OrderedDict() for m in self.capacity}
+        self.zombies = []   # evicted while a pending backward still needed them: closed as soon as that backward ran (or its graph died)
+
+    def _retire(self, e):
+        if e.busy():
+            self.zombies.append(e)   # the plan (streams, events) and its workspace stay alive for the pending backward ...
+        else:
+            e.plan.close()
+            e.ws = None
+
+    def sweep(self):
+        """... and are released here, on the next cache access after that backward consumed them."""
+        live = []
+        for e in self.zombies:
+            if e.busy():
+                live.append(e)
+            else:
+                e.plan.close()
+                e.ws = None
+        self.zombies = live
 
     def get(self, mode, key, factory):
+        if self.zombies:
+            self.sweep()
         lru = self.d[mode]
         hit = lru.get(key)
         if hit is None:
             hit = lru[key] = factory()
             while len(lru) > self.capacity[mode]:
                 _, old = lru.popitem(last=False)
-                if not old.busy():          # (a workspace a pending backward still needs dies with its ctx instead)
-                    old.plan.close()
-                old.ws = None
+                self._retire(old)
         else:
             lru.move_to_end(key)
         return hit
@@ -122,9 +141,9 @@ class _PlanCache:
     def clear(self):
         for lru in self.d.values():
             for e in lru.values():
-                if not e.busy():
-                    e.plan.close()
+                self._retire(e)
             lru.clear()
+        self.sweep()
 
     def __len__(self):
         return sum(len(v) for v in self.d.values())

@@ -325,108 +325,158 @@ def pmc_class_traffic(cls):
     return (tot / launches, src) if launches else (None, None)
 
 
-def cpu_baseline_worker(n_mels, T):
-    """Child process of ``cpu_baseline``: prints one JSON line per finished measurement, most valuable first,
-    until the parent's deadline kills it."""
-    import statistics
-    from oracle import avc_oracle as O
+def _pick_cpus(n):
+    """n logical CPUs for a pinned CPU-baseline point: distinct physical cores of ONE NUMA node (node 0 first), in order."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        return None
+
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            out.extend(range(int(lo), int(hi or lo) + 1))
+        return out
+    nodes = []
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                nodes.append([c for c in parse(open(f"/sys/devices/system/node/{d}/cpulist").read()) if c in allowed])
+    except OSError:
+        pass
+    if not nodes:
+        nodes = [allowed]
+    pick = []
+    for cpus in nodes:          # fill one node; spill to the next only if it is too small
+        seen = set()
+        for c in cpus:
+            try:
+                sib = min(parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+            except OSError:
+                sib = c
+            if sib in seen:
+                continue
+            seen.add(sib)
+            pick.append(c)
+            if len(pick) == n:
+                return pick
+    return (pick + [c for c in allowed if c not in pick])[:n]
+
+
+def cpu_baseline_worker(n_mels, T, point):
+    """Child process of ``cpu_baseline``: ONE (batch, threads) point, pinned to `threads` physical cores of one NUMA node (the parent
+    sets OMP_PROC_BIND / OMP_PLACES); prints one JSON line per timed step until done or until the parent's deadline kills it."""
+    import statistics
+    Bc, threads, n_timed = point
+    try:
+        cpus = sorted(os.sched_getaffinity(0))   # (the OpenMP runtime may already have bound THIS thread to its first place)
+    except AttributeError:
+        cpus = []
+    cpus = [int(c) for c in os.environ.get("AVC_CPU_PIN", "").split(",") if c] or cpus
+    from oracle import avc_oracle as O
+    cores = os.cpu_count() or 1
     cfg = O.stock_config(n_mels)
     o = cfg["optimizer"]
     O.use_aten_ops(True)   # the reference's own op choices (F.pad reflect, F.instance_norm, ...): its cost profile
+    torch.set_num_threads(threads)
+    sd = O.make_state_dict(cfg, 0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"],
+                           weight_decay=o["weight_decay"])
+    x, eps = O.make_inputs(cfg, Bc, T, 0)
 
-    def make(Bc):
-        sd = O.make_state_dict(cfg, 0)
-        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-        opt = torch.optim.Adam(list(params.values()), lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"],
-                               weight_decay=o["weight_decay"])
-        x, eps = O.make_inputs(cfg, Bc, T, 0)
+    def step():   # solver.py:81-97 around the oracle's forward
+        mu, ls, emb, dec = O.ae_forward(x, eps, params, cfg)
+        loss_rec, loss_kl = O.losses(x, mu, ls, dec)
+        loss = cfg["lambda"]["lambda_rec"] * loss_rec + 1.0 * loss_kl
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=o["grad_norm"])
+        opt.step()
 
-        def step():   # solver.py:81-97 around the oracle's forward
-            mu, ls, emb, dec = O.ae_forward(x, eps, params, cfg)
-            loss_rec, loss_kl = O.losses(x, mu, ls, dec)
-            loss = cfg["lambda"]["lambda_rec"] * loss_rec + 1.0 * loss_kl
-            opt.zero_grad()
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=o["grad_norm"])
-            opt.step()
-        return step
-
-    def measure(Bc, threads, n_timed):
-        torch.set_num_threads(threads)
-        step = make(Bc)
-        step()  # warm-up
-        ts = []
-        for _ in range(n_timed):
-            t0 = time.perf_counter()
-            step()
-            ts.append(time.perf_counter() - t0)
-            print(json.dumps({"B": Bc, "threads": threads, "steps": len(ts), "median_step_s": statistics.median(ts),
-                              "seg_per_s": Bc / statistics.median(ts), "host_cores": cores}), flush=True)
-
-    # most promising points first (MKL / oneDNN stop scaling well before the core count of a GPU host, and 128+
-    # threads are catastrophically slow): B = 128 at 32, 16, 64, 8 threads, then B = 256 and B = 4
-    # The two points that won every sweep so far first, with the >= 5 timed steps BASELINE.md asks for; then the rest.
-    cands = [c for c in (32, 16, 64, 8) if c <= cores] or [cores]
-    best_t = 16 if 16 <= cores else cands[0]
-    measure(256, best_t, 5)
-    measure(128, best_t, 5)
-    for c in cands:
-        if c != best_t:
-            measure(128, c, 3)
-    for c in cands[:2]:
-        if c != best_t:
-            measure(256, c, 3)
-    measure(4, cands[0], 5)
-    measure(32, cands[0], 3)
+    step()  # warm-up
+    ts = []
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+        print(json.dumps({"B": Bc, "threads": threads, "steps": len(ts), "median_step_s": statistics.median(ts), "min_step_s": min(ts), "max_step_s": max(ts),
+                          "seg_per_s": Bc / statistics.median(ts), "host_cores": cores, "pinned_cpus": len(cpus) if cpus else 0}), flush=True)
 
 
 def cpu_baseline(n_mels, T, budget_s=45.0):
     """BASELINE.md §2 protocol on the host cores of this box with the oracle's forward (the same ATen CPU ops the
     reference issues; the reference itself cannot travel to the GPU box -> kind "port"): real in-place
-    ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77, 81-97), thread
-    counts {8, 16, 32, 64}, B in {4, 32, 128, 256}, one warm-up + median of the timed steps per point, best
-    segments/s reported.  The sweep runs in a child process under a HARD wall-clock budget: whatever points
-    finished by then are used (the line says which)."""
+    ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77, 81-97).  Every (batch, threads) point is
+    its own child process PINNED to `threads` physical cores of one NUMA node (sched_setaffinity + OMP_PROC_BIND=close): unpinned, the same
+    point moved by 2x between runs on a 256-core host (round 3).  The two points that won every sweep (B = 128 and 256 at 16 threads) run
+    first with 1 warm-up + 7 timed steps (median, min-max reported); the other (batch, threads) points follow with 3 steps each while the
+    HARD wall-clock budget lasts.  Best median segments/s among the points with >= 5 timed steps is the value."""
     import select
     import subprocess
     t0 = time.perf_counter()
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--mels", str(n_mels), "--frames", str(T)],
-                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1)
-    pts = {}
     try:
-        while True:
-            left = budget_s - (time.perf_counter() - t0)
-            if left <= 0:
-                break
-            r, _, _ = select.select([proc.stdout], [], [], left)
-            if not r:
-                break
-            line = proc.stdout.readline()
-            if not line:
-                break
-            try:
-                d = json.loads(line)
-                pts[(d["B"], d["threads"])] = d
-            except Exception:
-                continue
-    finally:
-        proc.kill()
-        proc.wait()
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    best_t = 16 if 16 <= cores else max(1, cores)
+    plan = [(128, best_t, 7), (256, best_t, 7)]
+    for c in (32, 8, 64):
+        if c <= cores and c != best_t:
+            plan.append((128, c, 3))
+    plan += [(4, min(32, cores), 5), (32, min(32, cores), 3), (256, min(32, cores), 3)]
+    env = dict(os.environ)
+    env.update(OMP_PROC_BIND="close", OMP_PLACES="cores", KMP_AFFINITY="granularity=fine,compact,1,0")
+    pts = {}
+    for (Bc, th, n) in plan:
+        left = budget_s - (time.perf_counter() - t0)
+        if left <= 2.0:
+            break
+        e = dict(env)
+        e["OMP_NUM_THREADS"] = str(th)
+        cpus = _pick_cpus(th)
+        e["AVC_CPU_PIN"] = ",".join(str(c) for c in (cpus or []))
+        pin = (lambda cpus=cpus: os.sched_setaffinity(0, cpus)) if cpus else None   # the child STARTS inside the mask: every OpenMP place lies in it
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-point", f"{Bc},{th},{n}",
+                                 "--mels", str(n_mels), "--frames", str(T)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1, env=e,
+                                preexec_fn=pin)
+        try:
+            while True:
+                left = budget_s - (time.perf_counter() - t0)
+                if left <= 0:
+                    break
+                r, _, _ = select.select([proc.stdout], [], [], left)
+                if not r:
+                    break
+                line = proc.stdout.readline()
+                if not line:
+                    break
+                try:
+                    d = json.loads(line)
+                    pts[(d["B"], d["threads"])] = d
+                except Exception:
+                    continue
+        finally:
+            proc.kill()
+            proc.wait()
     if not pts:
         raise RuntimeError(f"no CPU measurement finished within {budget_s:.0f} s")
     full = [d for d in pts.values() if d["steps"] >= 5]   # BASELINE.md: median of >= 5 timed steps
     best = max(full or pts.values(), key=lambda d: d["seg_per_s"])
     print(f"[bench] cpu_baseline: {len(pts)} points in {time.perf_counter() - t0:.1f}s, best {best}", file=sys.stderr, flush=True)
     return dict(value=best["seg_per_s"], unit="mel-segments/sec", cores=best["threads"], kind="port", host_cores=best["host_cores"],
+                spread={"min_seg_per_s": best["B"] / best["max_step_s"], "max_seg_per_s": best["B"] / best["min_step_s"],
+                        "rel": (best["max_step_s"] - best["min_step_s"]) / best["median_step_s"]},
+                pinning=f"each point: own process, sched_setaffinity to {best['threads']} physical cores of one NUMA node, OMP_PROC_BIND=close",
                 sample=(f"oracle forward issuing the reference's ATen ops (F.pad reflect, conv1d, F.instance_norm, avg_pool1d(ceil), interpolate) + autograd backward + in-place torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, "
-                        f"torch CPU fp32; sweep over (batch, threads) under a {budget_s:.0f} s wall-clock budget: "
+                        f"torch CPU fp32; (batch, threads) points under a {budget_s:.0f} s wall-clock budget: "
                         f"{len(pts)} points finished (1 warm-up + median of the timed steps each); best = B {best['B']}, "
                         f"{best['threads']} threads, median of {best['steps']} steps"),
-                points=[{"B": d["B"], "threads": d["threads"], "steps": d["steps"], "seg_per_s": round(d["seg_per_s"], 2)}
+                points=[{"B": d["B"], "threads": d["threads"], "steps": d["steps"], "seg_per_s": round(d["seg_per_s"], 2),
+                         "min_seg_per_s": round(d["B"] / d["max_step_s"], 2), "max_seg_per_s": round(d["B"] / d["min_step_s"], 2)}
                         for d in sorted(pts.values(), key=lambda d: (d["B"], d["threads"]))])
 
 
@@ -530,6 +580,56 @@ def dsp_bench(a, dev):
     print(json.dumps(out), flush=True)
 
 
+def config2_bf16_record(a, dev, g, x):
+    """The per-GPU share of BASELINE configs[2] (bf16, 256 segments per GPU) on ONE GPU: compute_dtype "bf16" = the bf16 storage engine
+    (DESIGN 3.4).  Same harness as the headline: `a.warmup` untimed steps, `a.steps` timed ones between synchronisations."""
+    from adaptive_voice_conversion_amd.solver import Solver
+    cfg = stock_config(a.mels)
+    cfg["compute_dtype"] = "bf16s"
+    B, T = a.batch, a.frames
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_bench_log", tuning={})
+    solver = Solver(cfg, args)
+    plan, _ = solver.model._plan(B, T, T, dev)
+    eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], plan.latent_len, generator=g).to(dev)
+    for _ in range(a.warmup):
+        solver.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        solver.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    meta = solver.ae_step(x, 1.0, eps=eps, sync=True)
+    rec = {"workload": f"BASELINE.json configs[2], one GPU's share: batch {B} x {a.mels}-mel x {T}, bf16 storage engine "
+                       "(bf16 activations / weight images, fp32 accumulation, statistics, master weights and optimizer state), recon+KL train step",
+           "baseline_config_index": 2, "dtype": "bf16", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "pair_storage": bool(getattr(plan, "pair_storage", False)),
+           "ms_per_step": 1e3 * el / a.steps, "value": B * a.steps / el, "unit": "mel-segments/sec", "final_losses": meta,
+           "note": "the 8-GPU data-parallel run of this configuration is the driver's (bench.py --gpus 8 --dtype bf16)"}
+    if not all(v == v and abs(v) < 1e6 for v in meta.values()):
+        rec["error"] = "non-finite training state"
+        return rec
+    if not a.no_profile:
+        prof = profile_classes(solver, x, eps, steps=3)
+        dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
+        d = prof[dom]
+        whole = TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3 / (el / a.steps)
+        rec["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": d["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_us": d["avg_us"],
+                           "ms_per_step": d["ms_per_step"], "whole_step": {"tflops": whole, "frac": whole / PEAK_BF16_MFMA_TFLOPS}}
+        C = cfg["ContentEncoder"]["c_h"]
+        dom_s = instnorm_dominant_shape(B, C, T, pairs=True)
+        bts = dom_s["fwd"]["bytes_per_launch"] + dom_s["bwd"]["bytes_per_launch"]
+        us = dom_s["fwd"]["avg_launch_us"] + dom_s["bwd"]["avg_launch_us"]
+        rec["roofline_instnorm"] = {"kernel": f"instnorm_fwd/bwd_pairs (bf16 pair rows) at [{B},{C},{T}]", "bound": "hbm", "achieved": bts / us / 1e3,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bts / us / 1e3 / PEAK_HBM_GBS, "algorithmic_bytes": bts,
+                                    "fwd": dom_s["fwd"], "bwd": dom_s["bwd"]}
+        rec["kernel_classes"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                     if kk in ("ms_per_step", "launches_per_step", "avg_us", "tflops", "gbs")} for k, v in prof.items()}
+    return rec
+
+
 def workload_label(a, world):
     """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
     prec = {"f32": "fp32", "bf16r": "bf16 matrix products on fp32 storage: operands rounded as they enter the matrix core (fp32 accumulate, fp32 master "
@@ -590,6 +690,7 @@ def main():
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-config2", action="store_true", help="skip the config2_bf16 sub-record of the default (configs[1]) line")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every kernel on the caller's stream")
     ap.add_argument("--feed", action="store_true", help="draw every batch from an HBM-resident synthetic corpus through the "
                                                         "device-side gather kernel (DeviceSegmentFeed) inside the timed loop")
@@ -603,9 +704,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
                     help="avc_tuning field captured by the plans (A/B measurements), e.g. wgrad_batch=1, kg_wgs=0")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-point", default="128,16,7", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
-        return cpu_baseline_worker(a.mels, a.frames)
+        return cpu_baseline_worker(a.mels, a.frames, tuple(int(v) for v in a.cpu_point.split(",")))
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_ranks(a)   # does not return
@@ -802,6 +904,14 @@ def main():
             if a.profile_json:
                 with open(a.profile_json, "w") as f:
                     json.dump(prof, f, indent=1)
+        if world == 1 and cfg_idx == 1 and a.dtype == "f32" and not a.no_config2 and not feed:
+            # BASELINE configs[2] is "8 x MI355X data-parallel, global batch 2048, bf16": its per-GPU half -- the bf16 STORAGE engine at 256
+            # segments per GPU -- is measured here with the same harness (same warm-up / step counts, same timing brackets), so that the
+            # driver's default run carries a driver-timed bf16 number.  `value` above stays the exact-fp32 step.
+            try:
+                out["config2_bf16"] = config2_bf16_record(a, dev, g, x)
+            except Exception as e:   # never lose the headline line to the sub-record
+                out["config2_bf16"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.mels, T)

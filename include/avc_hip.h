@@ -160,8 +160,10 @@ void avc_tuning_init(avc_tuning* t);
  * PAIR storage" below), conv / Linear products run on v_mfma_f32_32x32x16_bf16 from bf16 pair weight images, accumulation, InstanceNorm
  * statistics, mu / log_sigma, dec, emb, the AdaIN affine parameters, all parameter gradients and the optimizer stay fp32.  Inputs and
  * outputs of the entry points keep their fp32 types.  Needs even channel counts and frame counts that are multiples of 4 at every level
- * (-2 otherwise); avc_plan_compute_dtype reports 3; avc_plan_buffer offsets of activation tensors then address pair tensors. */
+ * (AVC_ERR_PAIR_SHAPE otherwise: a return code of its own, so that a caller can fall back to operand rounding -- avc_plan_set_compute_dtype(1) --
+ * for THAT reason only); avc_plan_compute_dtype reports 3; avc_plan_buffer offsets of activation tensors then address pair tensors. */
 #define AVC_PLAN_BF16S 16
+#define AVC_ERR_PAIR_SHAPE (-12)
 int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, const avc_tuning* tuning, avc_plan** out);
 /* profiling aid on an existing plan: 1 = every kernel of this plan on the caller's stream */
 int avc_plan_set_single_stream(avc_plan* p, int on);

@@ -43,6 +43,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A case that carries the `gpu` mark AND runs on the simulator (`kind == "emu"`: a gpu-sized parametrisation crossed with both
+    backends) is never useful: `-m "not gpu"` deselects it, and under `-m gpu` it would either skip as "gpu-sized" or run the CPU
+    simulator on the GPU box (71 skips of noise in the driver's log, and tests/emu/libavc_emu.so mapped into a GPU-test process).
+    Deselect it, so that a `-m gpu` run touches exactly one native library: the product's."""
+    keep, drop = [], []
+    for it in items:
+        cs = getattr(it, "callspec", None)
+        if cs is not None and cs.params.get("kind") == "emu" and it.get_closest_marker("gpu") is not None:
+            drop.append(it)
+        else:
+            keep.append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

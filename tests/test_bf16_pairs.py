@@ -393,7 +393,10 @@ def test_storage_engine_shape_rules_and_fallback(kind):
     cfg = _tiny()
     ok = Plan(cfg, 2, 32, lib=lib, compute_dtype="bf16")
     assert ok.compute_dtype == "bf16" and ok.pair_storage and lib.avc_plan_compute_dtype(ok.h) == 3
-    odd = Plan(cfg, 2, 34, lib=lib, compute_dtype="bf16")          # 34 -> 17 frames after the stride-2 block
+    from adaptive_voice_conversion_amd import engine as _engine
+    _engine._warned.clear()
+    with pytest.warns(RuntimeWarning, match="runs 'bf16r'"):       # (the fallback names itself and the offending shape, once)
+        odd = Plan(cfg, 2, 34, lib=lib, compute_dtype="bf16")      # 34 -> 17 frames after the stride-2 block
     assert odd.compute_dtype == "bf16r" and not odd.pair_storage and lib.avc_plan_compute_dtype(odd.h) == 1
     with pytest.raises(RuntimeError, match="multiples of 4"):
         Plan(cfg, 2, 34, lib=lib, compute_dtype="bf16s")

@@ -42,9 +42,12 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         AE(cfg, lib=lib)
     cfg = O.tiny_config()
-    cfg["ContentEncoder"]["act"] = "gelu"        # get_act (model.py:93-99) knows 'relu' and 'lrelu' only
-    with pytest.raises(NotImplementedError):
-        AE(cfg, lib=lib)
+    cfg["ContentEncoder"]["act"] = "gelu"        # get_act (model.py:93-99) maps every other string to nn.ReLU(): same here, with a warning
+    from adaptive_voice_conversion_amd import engine as _engine
+    _engine._warned.clear()
+    with pytest.warns(RuntimeWarning, match="maps every string other than"):
+        ae = AE(cfg, lib=lib)
+    assert _engine.cfg_from_dict(cfg).enc.act == 0
     cfg = O.tiny_config()
     cfg["ContentEncoder"]["dropout_rate"] = 0.1
     with pytest.raises(NotImplementedError):
@@ -305,3 +308,22 @@ def test_plan_cache_is_bounded_and_releases_plans():
     train_ws = ae._plan(2, 32, 32, dev)[1]
     infer_ws = ae._plan(2, 32, 32, dev, "inference")[1]
     assert infer_ws.numel() < train_ws.numel() and infer_ws.data_ptr() != train_ws.data_ptr()
+
+
+def test_plan_evicted_under_a_pending_backward_is_closed_after_it():
+    """a training plan evicted while an autograd backward still needs its saved activations must outlive that
+    backward -- and be destroyed (helper streams, events) on the next cache access after it, not leak."""
+    cfg = O.tiny_config()
+    ae, dev, lib = make_ae("emu", cfg)
+    ae.set_plan_cache_size(train=1)
+    x, eps = O.make_inputs(cfg, 2, 32, 0)
+    out = ae(x, eps=eps)
+    first = ae._plans.d["train"][next(iter(ae._plans.d["train"]))].plan
+    x2, eps2 = O.make_inputs(cfg, 2, 48, 1)
+    out2 = ae(x2, eps=eps2)                     # evicts the (2, 32) plan while its backward is pending
+    assert first.h is not None and len(ae._plans.zombies) == 1
+    (out[3].abs().mean() + out[0].pow(2).mean()).backward()    # ... which still works
+    assert all(torch.isfinite(p.grad).all() for p in ae.parameters())
+    (out2[3].abs().mean()).backward()
+    ae._plan(2, 48, 48, dev)                    # next cache access: the zombie is swept
+    assert first.h is None and not ae._plans.zombies
