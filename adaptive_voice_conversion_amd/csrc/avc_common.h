@@ -104,26 +104,45 @@ struct ConvArgs {
     ConvGroup g[AVC_MAX_GROUPS];
 };
 
-// One layer of a weight-gradient launch.  Several layers that share a kernel instance (taps, tile shape,
-// addressing form) run as ONE batched launch: workgroup ids [wg_begin, wg_begin + tiles * nsplit) belong to
-// this layer, every workgroup of the launch walks the same number of 32-column K-chunks (balanced).
+// One layer of a weight-gradient launch (conv_wgrad.hip).  A launch is a STREAM-K split of all its layers: the K-chunks (32 columns of
+// the (b, t) axis) of every (co, ci) tile of every layer form one sequence, weighted by chunk_cost; workgroup w of `grid` owns the chunks
+// whose start cost lies in [ceil(w C / grid), ceil((w + 1) C / grid)) -- exactly `grid` workgroups (one per CU), balanced to one chunk,
+// whatever the layers' shapes are.  A workgroup that leaves a tile stores its partial sum (accumulator layout) into that tile's slot
+// z = (its index among the tile's workgroups) and takes a ticket on the tile's arrival counter; the LAST workgroup to arrive sums the
+// slots in the fixed order z = 0, 1, ... (bit-deterministic whatever the arrival order was) and writes the finished gradient tile --
+// and the bias gradient -- straight into the flat gradient buffer.  No second launch.
 struct WgradArgs {
     ConvSrc x;    // conv input  [B, Cin, Tin]   (reflect padded on the fly)
     ConvSrc dy;   // output grad [B, Cout, Tout]
     int B, Cin, Cout, Tin, Tout;
     int KS, padL, stride;
-    int chunks_per_sample, total_chunks, chunks_per_wg, Tc, spc;  // K-split geometry (32 columns per chunk)
-    float* slab;   // [nsplit][KS][Cout][Cin] partial sums (tap-major)
-    float* dbslab; // [nsplit][Cout] partial bias sums (may be null)
-    long slab_stride, db_stride;
+    int chunks_per_sample, total_chunks, Tc, spc;  // K-chunk geometry (32 columns per chunk)
     int bf16;      // AVC_COMPUTE_*
-    int nsplit, tiles, wg_begin;  // filled by avc_wgrad_plan_batch / the launcher
+    int tiles;     // (co, ci) tiles of this layer
+    // ---- filled by avc_wgrad_plan_batch
+    int grp;          // launch (kernel instance) of the planned batch this layer belongs to
+    int grid;         // workgroups of that launch
+    int chunk_cost;   // cost units of one K-chunk of this layer (taps + a fixed part)
+    int slots;        // slab slots per tile (>= the number of workgroups any tile of this layer is split over)
+    int ctr_base;     // first arrival counter of this layer (index into WgradBatch.counters)
+    int rows_per_src; // stacked layers (heads, AdaIN affines): output rows per parameter tensor
+    long cost_begin;  // cost units in front of this layer inside its launch
+    long cost_total;  // ... of the whole launch
+    long slab_need, dbslab_need;   // floats the caller must provide at slab / dbslab
+    // ---- filled by the caller
+    float* slab;   // [tiles][slots][tile floats] partial tiles, accumulator layout
+    float* dbslab; // [co tiles][slots][co rows]  partial bias sums (null: no bias gradient)
+    float* dw;     // finished weight gradient [Cout][Cin][KS] (parameter layout); source s of a stacked layer at dw + s * dw_src_stride
+    float* db;     // finished bias gradient (may be null)
+    long dw_src_stride, db_src_stride;
 };
 #define AVC_WGRAD_MAXL 16
 struct WgradBatch {
     int nlayers;
     int dbg;   // ablation switches of the micro-benchmarks (0 in the product path)
-    int pad_[2];
+    int lds_flag;    // int index (in the dynamic LDS segment) of the "last arriver" flag word
+    int pad_;
+    int* counters;   // arrival counters (zero before the launch; the last arriver of a tile resets its counter)
     WgradArgs L[AVC_WGRAD_MAXL];
 };
 

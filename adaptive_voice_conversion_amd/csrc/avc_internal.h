@@ -46,13 +46,9 @@ int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
-void avc_wgrad_plan(const avc_tuning& tun, int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
-                    int* chunks_per_wg, int* nsplit);
 void avc_wgrad_geometry(WgradArgs& a);
-void avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);
-int avc_launch_wgrad_batch(const WgradArgs* layers, int n, hipStream_t stream, int ablation = 0);
-#define AVC_REDUCE_MAXSEG 32
-int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream);
+int avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);   // returns the number of arrival counters the batch needs
+int avc_launch_wgrad_batch(const WgradArgs* layers, int n, int* counters, hipStream_t stream, int ablation = 0);
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);
@@ -80,7 +76,6 @@ int avc_launch_loss(const float* dec, const float* x, long sxb, long sxc, int sx
 int avc_adam_blocks(long n);
 int avc_launch_sumsq(const float* g, long n, float* partial, hipStream_t s);
 int avc_launch_clip_adam(const AdamArgs& a, hipStream_t s);
-int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream);
 struct avc_plan;
 int avc_backward_impl(const avc_plan*, const float*, const float*, long, long, int, const float*, long, long, int,
                       const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t, bool,

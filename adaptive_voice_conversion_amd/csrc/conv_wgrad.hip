@@ -1,12 +1,12 @@
 // Weight gradient of the reflect-padded Conv1d on the fp32 MFMA
 // (reference: autograd of model.py:21-32; dW[co,ci,j] = sum_{b,t} dy[b,co,t] * xpad[b,ci,t*s+j]).
 //
-// GEMM view: M = co, N = (ci, tap), K = (b, t).  A workgroup owns a 64co x 64ci
-// x KS tile (4 waves, each 32co x 32ci x KS accumulators) and a contiguous range
-// of 32-column K-chunks; partial tiles go to a slab [split][Cout][Cin][KS] that a
-// second kernel sums in a fixed order (deterministic, no atomics).  The bias
-// gradient (row sums of dy) is produced by the ci-tile-0 workgroups from the dy
-// tile they already hold in LDS.
+// GEMM view: M = co, N = (ci, tap), K = (b, t).  A workgroup holds a 64co x 64ci x KS (or 128 x 32, 128 x 128) tile in
+// accumulator registers and walks 32-column K-chunks of it.  Since round 4 a launch is a STREAM-K split of ALL its layers
+// (avc_common.h, WgradArgs): exactly `grid` persistent workgroups, each owning one contiguous run of the launch's
+// (layer, tile, chunk) sequence; a workgroup that leaves a tile publishes its partial sum and takes a ticket, the LAST
+// arriver of the tile sums the partials in a fixed order (deterministic) and writes the finished gradient -- weights in the
+// parameter layout, plus the bias gradient -- straight into the flat gradient buffer.  There is no reduce launch.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,245 +33,314 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
 }
 
-// KS taps, NB 32-wide ci blocks per wave, WCO waves along co (4/WCO along ci):
-//   workgroup tile = (32*WCO) co  x  (32*NB*(4/WCO)) ci  x  KS taps.
-// <5,1,2> is the 64x64 tile of the k=5 layers; WCO=4 (128co x 32ci) suits Cin that is not a multiple
-// of 64 (the 80-mel bank convs); <1,4,4> (128co x 128ci) gives the 1x1 convs / Linears four
-// accumulators per wave, i.e. the arithmetic intensity per staged element that the taps give k=5.
-//
-// Warp-specialised: with ~80 accumulator registers per wave the kernel runs one MFMA wave per SIMD,
-// and a wave issues in order -- every DMA address computation or exposed LDS round trip inside the
-// k-loop is matrix-pipe idle time (measured: 62 % MFMA duty even with DMA and barriers removed).
-// So waves 0-3 (consumers) execute nothing but fragment reads and MFMAs, and waves 4-7 (producers)
-// issue the next chunk's global->LDS DMAs, drain them and meet the consumers at one barrier per chunk.
-//
-// X3 (LIN layers -- whole 32-column chunks of a stride-1 conv, k = 1..8; opt-in, avc_set_tuning("wgrad_x3", 1)): the consumers form the products from three bf16 terms per
-// operand on v_mfma_f32_32x32x16_bf16 (conv_x3_shared.h: fp32-level accuracy in 2.7x fewer matrix-pipe cycles).  Both operands are
-// activations here, so both are split in registers: per 16 columns a lane reads its 8 dy values and the 12 x values that its
-// KS shifted windows cover, splits each ONCE, and assembles the KS B fragments by pairing registers (v_perm) -- 20 splits and
-// 30 MFMAs per block where the fp32 path issues 40 MFMAs of twice the length.  Producers, tiles, slabs: unchanged.
-//
-// BF == 2 (bf16 PAIR storage, bf16_pairs.h): x and dy are dword tensors [B][C/2][T].  The producers stage PAIR rows -- the same code
-// over half as many rows, every DMA'd dword brings two channels -- and the consumers feed v_mfma_f32_32x32x16_bf16: a lane's
-// 8 k-values are 8 consecutive columns of ITS channel, i.e. one half of 8 consecutive dwords of its pair row, gathered with one
-// v_perm_b32 per two columns (lanes 2p and 2p + 1 read the same LDS words: a broadcast, no extra bandwidth).
+// ---- inter-workgroup hand-off of the partial tiles (cdna_hip_programming.md, Guideline 16 in its counter form): plain 16-byte
+// slab stores -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane: agent-scope release, ticket; the workgroup that
+// draws the last ticket: ONE lane agent-scope acquire -> barrier -> plain loads.  Placement-independent.
 #ifndef AVC_EMU
+static __device__ __forceinline__ void wg_drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+static __device__ __forceinline__ int wg_ticket(int* ctr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restates the wait behind buffer_wbl2 where the compiler cannot drop it)
+    return __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+static __device__ __forceinline__ void wg_ctr_reset(int* ctr) { __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) { return __builtin_amdgcn_perm(d1, d0, sel); }
 #else
+static inline void wg_drain_vm() {}
+static inline int wg_ticket(int* ctr) { int o = *ctr; *ctr = o + 1; return o; }
+static inline void wg_acquire() {}
+static inline void wg_ctr_reset(int* ctr) { *ctr = 0; }
 static inline unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) {   // sel = 0x05040100 (low halves) or 0x07060302 (high halves)
     return sel == 0x05040100u ? ((d0 & 0xffffu) | (d1 << 16)) : ((d0 >> 16) | (d1 & 0xffff0000u));
 }
 #endif
-template <int KS, int NB, int WCO, bool LIN, int BF, bool X3 = false>
-__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
-    // which layer of the batch this workgroup works for (wave-uniform scan of <= 16 entries)
-    int layer = 0;
-    for (int i = 1; i < bt.nlayers; ++i) layer = ((int)blockIdx.x >= bt.L[i].wg_begin) ? i : layer;
-    const WgradArgs& a = bt.L[layer];
+
+template <int K>
+struct KTag {
+    static constexpr int value = K;
+};
+
+// ---- one workgroup's walk through the launch's (layer, tile, chunk) sequence.  Pure arithmetic on launch constants and the
+// workgroup index: both roles of a workgroup (and every workgroup that shares a tile) derive the same numbers.
+struct WgSeg {
+    int layer, tile, c_begin, c_end;   // K-chunks [c_begin, c_end) of (co, ci) tile `tile` of layer `layer`
+    int nsplit, z;                     // workgroups that share the tile, this one's index among them
+};
+struct WgSegIter {
+    long b0, b1, G, Ctot;
+    int w, layer;
+    long g, g_end;   // chunk sequence numbers (tile * total_chunks + chunk) of the current layer still to do
+    __device__ WgSegIter(const WgradBatch& bt) {
+        Ctot = bt.L[0].cost_total;
+        G = gridDim.x;
+        w = blockIdx.x;
+        b0 = ((long)w * Ctot + G - 1) / G;
+        b1 = ((long)(w + 1) * Ctot + G - 1) / G;
+        layer = -1;
+        g = g_end = 0;
+    }
+    __device__ bool next(const WgradBatch& bt, WgSeg& s) {
+        while (g >= g_end) {
+            if (++layer >= bt.nlayers) return false;
+            const WgradArgs& a = bt.L[layer];
+            const int cc = a.chunk_cost;
+            const long lay_end = a.cost_begin + (long)a.tiles * a.total_chunks * cc;
+            if (b1 <= a.cost_begin || b0 >= lay_end) continue;
+            // chunks of this layer whose start cost lies in [b0, b1)
+            const long lo = b0 > a.cost_begin ? b0 - a.cost_begin : 0, hi = (b1 < lay_end ? b1 : lay_end) - a.cost_begin;
+            g = (lo + cc - 1) / cc;
+            g_end = (hi + cc - 1) / cc;
+        }
+        const WgradArgs& a = bt.L[layer];
+        const int cc = a.chunk_cost;
+        s.layer = layer;
+        s.tile = (int)(g / a.total_chunks);
+        s.c_begin = (int)(g - (long)s.tile * a.total_chunks);
+        const long tile_last = (long)(s.tile + 1) * a.total_chunks;
+        s.c_end = (int)((g_end < tile_last ? g_end : tile_last) - (long)s.tile * a.total_chunks);
+        g += s.c_end - s.c_begin;
+        // which workgroups share this tile: owner(chunk with start cost c) = floor(c G / C)
+        const long cs = a.cost_begin + (long)s.tile * a.total_chunks * cc;
+        const int w_first = (int)((cs * G) / Ctot), w_last = (int)(((cs + (long)(a.total_chunks - 1) * cc) * G) / Ctot);
+        s.nsplit = w_last - w_first + 1;
+        s.z = w - w_first;
+        return true;
+    }
+};
+
+// KS taps (RT: the layer's own tap count 1..KS is a run-time value -- the eight conv-bank members k = 1..8 share ONE launch; the
+// chunk body is still straight-line code per tap count, selected by a wave-uniform switch), NB 32-wide ci blocks per wave, WCO
+// waves along co (4/WCO along ci):   workgroup tile = (32*WCO) co  x  (32*NB*(4/WCO)) ci  x  taps.
+// <5,false,1,2> is the 64x64 tile of the k=5 layers; WCO=4 (128co x 32ci) suits Cin that is not a multiple of 64 (the 80-mel bank
+// convs); <1,false,4,4> (128co x 128ci) gives the 1x1 convs / Linears four accumulators per wave.
+//
+// Warp-specialised: with ~80 accumulator registers per wave the kernel runs one MFMA wave per SIMD, and a wave issues in order --
+// every DMA address computation or exposed LDS round trip inside the k-loop is matrix-pipe idle time.  So waves 0-3 (consumers)
+// execute nothing but fragment reads and MFMAs, and waves 4-7 (producers) issue the next chunk's global->LDS DMAs, drain them and
+// meet the consumers at one barrier per chunk.  The two roles are two separate functions that walk the same segment sequence and
+// meet at the same number of barriers (the barrier counts wave arrivals, not call sites): their registers do not add up.
+//
+// X3 (LIN layers; opt-in, avc_set_tuning("wgrad_x3", 1)): the consumers form the products from three bf16 terms per operand on
+// v_mfma_f32_32x32x16_bf16 (conv_x3_shared.h: fp32-level accuracy in 2.7x fewer matrix-pipe cycles).
+//
+// BF == 2 (bf16 PAIR storage, bf16_pairs.h): x and dy are dword tensors [B][C/2][T].  The producers stage PAIR rows and the consumers
+// feed v_mfma_f32_32x32x16_bf16: a lane's 8 k-values are 8 consecutive columns of ITS channel, i.e. one half of 8 consecutive dwords of
+// its pair row, gathered with one v_perm_b32 per two columns.
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF>
+struct WgCfg {
+    static constexpr int WCI = 4 / WCO;            // waves along ci
+    static constexpr int TCO = 32 * WCO;           // co rows per workgroup
+    static constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
+    static constexpr int NACC = KS * NB;
+    static constexpr bool BH = BF == 2;
+    static constexpr int RCO = BH ? TCO / 2 : TCO, RCI = BH ? TCI / 2 : TCI;   // LDS / source rows of the two operand tiles (pair rows with BH)
+    static constexpr int WG_DYROW = wg_dyrow(LIN);
+    static constexpr int NPD = (RCO * WG_DYROW + 255) / 256;  // dy pieces per producer wave
+    static constexpr int NPX = (RCI * (LIN ? wg_xrow_lin(KS) : (KS == 1 ? 33 : 71)) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
+    static constexpr int TPR = 256 / RCO;  // producer threads per dy row in the bias-gradient partial sum
+    static constexpr int CPT = 32 / TPR;
+    static constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
+};
+
+// the inter-workgroup part of a segment's end, executed by all eight waves: returns true in the LAST arriver of the tile
+static __device__ __forceinline__ bool wg_arrive(const WgradBatch& bt, const WgradArgs& a, const WgSeg& sg, float* smem, int tid) {
+    wg_drain_vm();     // every storing wave: its slab stores have left
+    __syncthreads();
+    int* flag = (int*)smem + bt.lds_flag;   // the "I am the last arriver" word lives behind the stages
+    if (tid == 0) {
+        int* ctr = bt.counters + a.ctr_base + sg.tile;
+        const int old = wg_ticket(ctr);
+        const int last = (old == sg.nsplit - 1) ? 1 : 0;
+        if (last) {
+            wg_acquire();
+            wg_ctr_reset(ctr);   // (the next launch finds a zero; the per-call memset covers a fresh workspace / an aborted call)
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// ---------------- producers: waves 4-7.  Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
+// reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1 lands while chunk c multiplies.
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF>
+static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
+    using C = WgCfg<KS, RT, NB, WCO, LIN, BF>;
+    constexpr int TCO = C::TCO, TCI = C::TCI, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NPD = C::NPD, NPX = C::NPX, TPR = C::TPR, CPT = C::CPT;
+    constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
-    constexpr int WCI = 4 / WCO;            // waves along ci
-    constexpr int TCO = 32 * WCO;           // co rows per workgroup
-    constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
-    constexpr int NACC = KS * NB;
-    constexpr bool BH = BF == 2;
-    constexpr int RCO = BH ? TCO / 2 : TCO, RCI = BH ? TCI / 2 : TCI;   // LDS / source rows of the two operand tiles (pair rows with BH)
-    HIP_DYNAMIC_SHARED(float, smem)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
-    const bool producer = wave8 >= 4;
-    const int wave = wave8 & 3;   // consumer: tile position; producer: which pieces of a chunk it stages
-    const int ptid = tid & 255;   // thread index inside its role group
-    const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
-    const int ci_tiles = avc_cdiv(a.Cin, TCI);
-    const int local = (int)blockIdx.x - a.wg_begin;
-    const int z = local / a.tiles, tile = local - z * a.tiles;   // split index, (co, ci) tile
-    const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
-    const int co0r = BH ? co0 >> 1 : co0, ci0r = BH ? ci0 >> 1 : ci0;                   // ... in source rows
-    const int CoutR = BH ? a.Cout >> 1 : a.Cout, CinR = BH ? a.Cin >> 1 : a.Cin;
-    const float* xptr = a.x.ptr;
-    const float* dyptr = a.dy.ptr;
-    float* slabp = a.slab;
-    float* dbp = a.dbslab;
-    const int Tc = a.Tc, spc = a.spc;
-    const int lgTc = 31 - __builtin_clz(Tc);
-    const int XSEG = (Tc - 1) * a.stride + KS;
-    constexpr int WG_DYROW = wg_dyrow(LIN);
-    const int XROW = LIN ? wg_xrow_lin(KS) : ((spc * XSEG) | 1);
-    const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
-    const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
-    float* dyT = smem;             // [2][RCO][WG_DYROW]
-    float* xT = smem + 2 * DYSP;   // [2][RCI][XROW]
-    const bool do_db = (dbp != nullptr) && (ci0 == 0);
-    const float inv_xrow = 1.0f / (float)XROW;
-
-    float dbsum = 0.f, dbsum1 = 0.f;
-
-    // Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
-    // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1
-    // lands while chunk c multiplies.  Both stages are zero-filled once.
-    for (int e = tid; e < 2 * (DYSP + XSP); e += WG_THREADS) smem[e] = 0.f;
-
-    // Fast path (one sample per chunk, whole chunks): every lane of every DMA piece always loads --
-    // LDS positions that hold no tile element (row padding, rows past Cout / Cin) get a clamped,
-    // valid address instead of an exec-masked branch; they are never read, or feed accumulator rows
-    // that are never stored.  The chunk-invariant byte offsets live in producer registers, the
-    // chunk origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
-    constexpr int NPD = (RCO * WG_DYROW + 255) / 256;  // dy pieces per wave
-    constexpr int NPX = (RCI * (LIN ? wg_xrow_lin(KS) : (KS == 1 ? 33 : 71)) + 255) / 256;  // x pieces per wave (XROW <= 71, or 33 for stride-1 1x1)
-    // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the
-    // reflection is chunk-invariant, so the x offsets are complete and only the base moves.
-    const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
-    const bool fastp = fastm || ((spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256));
+    const int ptid = tid & 255;   // thread index inside the role group
     unsigned dyo[NPD], xo[NPX];
     int xq[NPX];
-    if (fastm && producer) {
-#pragma unroll
-        for (int i = 0; i < NPD; ++i) {
-            const int f = (wave + 4 * i) * 64 + lane;
-            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            row = row < RCO ? row : RCO - 1;
-            qcol = qcol < 32 ? qcol : 31;
-            int co = co0r + row;
-            co = co < CoutR ? co : CoutR - 1;
-            const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
-            dyo[i] = 4u * (unsigned)((long)sl * a.dy.sb + src_chan_off(a.dy, co) + (long)tl * a.dy.st);
-        }
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-            const int f = (wave + 4 * i) * 64 + lane;
-            int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
-            row = row < RCI ? row : RCI - 1;
-            int sl = pp / XSEG, p = pp - sl * XSEG;
-            if (sl >= spc) { sl = spc - 1; p = XSEG - 1; }  // the odd-stride padding column
-            int ci = ci0r + row;
-            ci = ci < CinR ? ci : CinR - 1;
-            int r = avc_reflect(p - a.padL, a.Tin);
-            r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);
-            xo[i] = 4u * (unsigned)((long)sl * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st);
-            xq[i] = 0;
-        }
-    } else if (fastp && producer) {
-#pragma unroll
-        for (int i = 0; i < NPD; ++i) {
-            const int f = (wave + 4 * i) * 64 + lane;
-            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            row = row < RCO ? row : RCO - 1;
-            qcol = qcol < 32 ? qcol : 31;
-            int co = co0r + row;
-            co = co < CoutR ? co : CoutR - 1;
-            dyo[i] = 4u * (unsigned)(src_chan_off(a.dy, co) + (long)qcol * a.dy.st);
-        }
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-            const int f = (wave + 4 * i) * 64 + lane;
-            int row = avc_fastdiv(f, XROW, inv_xrow), p = f - row * XROW;
-            row = row < RCI ? row : RCI - 1;
-            p = p < XSEG ? p : XSEG - 1;
-            int ci = ci0r + row;
-            ci = ci < CinR ? ci : CinR - 1;
-            xo[i] = 4u * (unsigned)src_chan_off(a.x, ci);
-            xq[i] = p;
-        }
-    }
-    auto issue_fast = [&](int chunk, int buf) {
-        float* dd = dyT + buf * DYSP;
-        float* xd = xT + buf * XSP;
+    WgSegIter it(bt);
+    WgSeg sg;
+    while (it.next(bt, sg)) {
+        const WgradArgs& a = bt.L[sg.layer];
+        const int KSr = RT ? a.KS : KS;
+        const int ci_tiles = avc_cdiv(a.Cin, TCI);
+        const int CoutR = BH ? a.Cout >> 1 : a.Cout, CinR = BH ? a.Cin >> 1 : a.Cin;
+        const float* xptr = a.x.ptr;
+        const float* dyptr = a.dy.ptr;
+        const int Tc = a.Tc, spc = a.spc;
+        const int lgTc = 31 - __builtin_clz(Tc);
+        const int XSEG = (Tc - 1) * a.stride + KSr;
+        const int XROW = LIN ? wg_xrow_lin(KSr) : ((spc * XSEG) | 1);
+        const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
+        const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
+        float* dyT = smem;             // [2][RCO][WG_DYROW]
+        float* xT = smem + 2 * DYSP;   // [2][RCI][XROW]
+        const float inv_xrow = 1.0f / (float)XROW;
+        const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
+        const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
+        const int co0r = BH ? co0 >> 1 : co0, ci0r = BH ? ci0 >> 1 : ci0;                   // ... in source rows
+        const bool do_db = (a.db != nullptr) && (ci0 == 0);
+        float dbsum = 0.f, dbsum1 = 0.f;
+        // Fast path (one sample per chunk, whole chunks): every lane of every DMA piece always loads -- LDS positions that hold no
+        // tile element (row padding, rows past Cout / Cin) get a clamped, valid address instead of an exec-masked branch; they are never
+        // read, or feed accumulator rows that are never stored.  The chunk-invariant byte offsets live in producer registers, the chunk
+        // origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
+        // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the reflection is chunk-invariant,
+        // so the x offsets are complete and only the base moves.
+        const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
+        const bool fastp = fastm || ((spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256));
         if (fastm) {
-            const float* dyb = dyptr + (long)chunk * spc * a.dy.sb;
-            const float* xb = xptr + (long)chunk * spc * a.x.sb;
+#pragma unroll
+            for (int i = 0; i < NPD; ++i) {
+                const int f = (wave + 4 * i) * 64 + lane;
+                int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+                row = row < RCO ? row : RCO - 1;
+                qcol = qcol < 32 ? qcol : 31;
+                int co = co0r + row;
+                co = co < CoutR ? co : CoutR - 1;
+                const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
+                dyo[i] = 4u * (unsigned)((long)sl * a.dy.sb + src_chan_off(a.dy, co) + (long)tl * a.dy.st);
+            }
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int f = (wave + 4 * i) * 64 + lane;
+                int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
+                row = row < RCI ? row : RCI - 1;
+                int sl = pp / XSEG, p = pp - sl * XSEG;
+                if (sl >= spc) { sl = spc - 1; p = XSEG - 1; }  // the odd-stride padding column
+                int ci = ci0r + row;
+                ci = ci < CinR ? ci : CinR - 1;
+                int r = avc_reflect(p - a.padL, a.Tin);
+                r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);
+                xo[i] = 4u * (unsigned)((long)sl * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st);
+                xq[i] = 0;
+            }
+        } else if (fastp) {
+#pragma unroll
+            for (int i = 0; i < NPD; ++i) {
+                const int f = (wave + 4 * i) * 64 + lane;
+                int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+                row = row < RCO ? row : RCO - 1;
+                qcol = qcol < 32 ? qcol : 31;
+                int co = co0r + row;
+                co = co < CoutR ? co : CoutR - 1;
+                dyo[i] = 4u * (unsigned)(src_chan_off(a.dy, co) + (long)qcol * a.dy.st);
+            }
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int f = (wave + 4 * i) * 64 + lane;
+                int row = avc_fastdiv(f, XROW, inv_xrow), p = f - row * XROW;
+                row = row < RCI ? row : RCI - 1;
+                p = p < XSEG ? p : XSEG - 1;
+                int ci = ci0r + row;
+                ci = ci < CinR ? ci : CinR - 1;
+                xo[i] = 4u * (unsigned)src_chan_off(a.x, ci);
+                xq[i] = p;
+            }
+        }
+        auto issue_fast = [&](int chunk, int buf) {
+            float* dd = dyT + buf * DYSP;
+            float* xd = xT + buf * XSP;
+            if (fastm) {
+                const float* dyb = dyptr + (long)chunk * spc * a.dy.sb;
+                const float* xb = xptr + (long)chunk * spc * a.x.sb;
+#pragma unroll
+                for (int i = 0; i < NPD; ++i)
+                    if ((wave + 4 * i) * 64 < DYSP) avc_glds4_s(dyb, dyo[i], dd + (wave + 4 * i) * 64);
+#pragma unroll
+                for (int i = 0; i < NPX; ++i)
+                    if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xb, xo[i], xd + (wave + 4 * i) * 64);
+                return;
+            }
+            const int cb = chunk / a.chunks_per_sample;
+            const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
+            const float* dyb = dyptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);
+            const float* xb = xptr + (long)cb * a.x.sb;
+            const int v0 = t0 * a.stride - a.padL;
+            const unsigned st4 = 4u * (unsigned)a.x.st;
 #pragma unroll
             for (int i = 0; i < NPD; ++i)
                 if ((wave + 4 * i) * 64 < DYSP) avc_glds4_s(dyb, dyo[i], dd + (wave + 4 * i) * 64);
+            if (v0 >= 0 && v0 + XSEG <= a.Tin) {  // interior chunk: no reflection anywhere in the tile
+                const float* xbv = xb + (long)v0 * a.x.st;
 #pragma unroll
-            for (int i = 0; i < NPX; ++i)
-                if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xb, xo[i], xd + (wave + 4 * i) * 64);
-            return;
-        }
-        const int cb = chunk / a.chunks_per_sample;
-        const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
-        const float* dyb = dyptr + ((long)cb * a.dy.sb + (long)t0 * a.dy.st);
-        const float* xb = xptr + (long)cb * a.x.sb;
-        const int v0 = t0 * a.stride - a.padL;
-        const unsigned st4 = 4u * (unsigned)a.x.st;
+                for (int i = 0; i < NPX; ++i)
+                    if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xbv, xo[i] + (unsigned)xq[i] * st4, xd + (wave + 4 * i) * 64);
+            } else {
 #pragma unroll
-        for (int i = 0; i < NPD; ++i)
-            if ((wave + 4 * i) * 64 < DYSP) avc_glds4_s(dyb, dyo[i], dd + (wave + 4 * i) * 64);
-        if (v0 >= 0 && v0 + XSEG <= a.Tin) {  // interior chunk: no reflection anywhere in the tile
-            const float* xbv = xb + (long)v0 * a.x.st;
-#pragma unroll
-            for (int i = 0; i < NPX; ++i)
-                if ((wave + 4 * i) * 64 < XSP) avc_glds4_s(xbv, xo[i] + (unsigned)xq[i] * st4, xd + (wave + 4 * i) * 64);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPX; ++i)
-                if ((wave + 4 * i) * 64 < XSP) {
-                    int r = avc_reflect(v0 + xq[i], a.Tin);
-                    r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);  // (only positions no valid dy column multiplies)
-                    avc_glds4_s(xb, xo[i] + (unsigned)r * st4, xd + (wave + 4 * i) * 64);
+                for (int i = 0; i < NPX; ++i)
+                    if ((wave + 4 * i) * 64 < XSP) {
+                        int r = avc_reflect(v0 + xq[i], a.Tin);
+                        r = r < 0 ? 0 : (r >= a.Tin ? a.Tin - 1 : r);  // (only positions no valid dy column multiplies)
+                        avc_glds4_s(xb, xo[i] + (unsigned)r * st4, xd + (wave + 4 * i) * 64);
+                    }
+            }
+        };
+        auto issue = [&](int chunk, int buf) {
+            if (fastp) {
+                issue_fast(chunk, buf);
+                return;
+            }
+            float* dd = dyT + buf * DYSP;
+            float* xd = xT + buf * XSP;
+            int cb, t0;
+            if (spc == 1) {
+                cb = chunk / a.chunks_per_sample;
+                t0 = (chunk - cb * a.chunks_per_sample) * 32;
+            } else {
+                cb = chunk * spc;
+                t0 = 0;
+            }
+            for (int piece = wave; piece * 64 < DYS; piece += 4) {
+                int f = piece * 64 + lane;
+                int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
+                if (f < DYS && qcol < 32) {
+                    int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
+                    int b = cb + sl, t = t0 + tl, co = co0r + row;
+                    if (b < a.B && t < a.Tout && co < CoutR)
+                        avc_glds4(dyptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
+                    else
+                        dd[f] = 0.f;
                 }
-        }
-    };
-
-    auto issue = [&](int chunk, int buf) {
-        if (fastp) {
-            issue_fast(chunk, buf);
-            return;
-        }
-        float* dd = dyT + buf * DYSP;
-        float* xd = xT + buf * XSP;
-        int cb, t0;
-        if (spc == 1) {
-            cb = chunk / a.chunks_per_sample;
-            t0 = (chunk - cb * a.chunks_per_sample) * 32;
-        } else {
-            cb = chunk * spc;
-            t0 = 0;
-        }
-        for (int piece = wave; piece * 64 < DYS; piece += 4) {
-            int f = piece * 64 + lane;
-            int row = f / WG_DYROW, qcol = f - row * WG_DYROW;
-            if (f < DYS && qcol < 32) {
-                int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
-                int b = cb + sl, t = t0 + tl, co = co0r + row;
-                if (b < a.B && t < a.Tout && co < CoutR)
-                    avc_glds4(dyptr + ((long)b * a.dy.sb + src_chan_off(a.dy, co) + (long)t * a.dy.st), dd + piece * 64);
-                else
-                    dd[f] = 0.f;
             }
-        }
-        for (int piece = wave; piece * 64 < XS; piece += 4) {
-            int f = piece * 64 + lane;
-            if (f < XS) {
-                int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
-                int sl = pp / XSEG, p = pp - sl * XSEG;
-                int b = cb + sl, ci = ci0r + row;
-                int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
-                if (sl < spc && b < a.B && ci < CinR && r >= 0 && r < a.Tin)
-                    avc_glds4(xptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
-                else
-                    xd[f] = 0.f;
+            for (int piece = wave; piece * 64 < XS; piece += 4) {
+                int f = piece * 64 + lane;
+                if (f < XS) {
+                    int row = avc_fastdiv(f, XROW, inv_xrow), pp = f - row * XROW;
+                    int sl = pp / XSEG, p = pp - sl * XSEG;
+                    int b = cb + sl, ci = ci0r + row;
+                    int r = avc_reflect(t0 * a.stride + p - a.padL, a.Tin);
+                    if (sl < spc && b < a.B && ci < CinR && r >= 0 && r < a.Tin)
+                        avc_glds4(xptr + ((long)b * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st), xd + piece * 64);
+                    else
+                        xd[f] = 0.f;
+                }
             }
-        }
-    };
+        };
 
-    const int c_begin = z * a.chunks_per_wg;
-    int c_end = c_begin + a.chunks_per_wg;
-    if (c_end > a.total_chunks) c_end = a.total_chunks;
-
-    __syncthreads();  // zero fill complete before the first DMA lands
-    if (producer && c_begin < c_end) issue(c_begin, 0);
-    __syncthreads();
-    constexpr int TPR = 256 / RCO;  // producer threads per dy row in the bias-gradient partial sum
-    constexpr int CPT = 32 / TPR;
-    // The two roles run separate loops that meet at one s_barrier per chunk (the barrier counts wave
-    // arrivals, not call sites).  Producer side of the barrier: the next stage has landed (the DMA is
-    // drained by the s_waitcnt in front of it); consumer side: the current stage is free again.
-    if (producer) {
+        __syncthreads();  // the zero fill / the previous segment's last reads are complete before the first DMA of this one lands
+        issue(c_begin, 0);
+        __syncthreads();  // (drains the DMA: the compiler's barrier waits for vmcnt(0))
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const int buf = (chunk - c_begin) & 1;
             const bool more = (chunk + 1 < c_end) && !((dbg & 1) && chunk > c_begin);
             if (more) issue(chunk + 1, buf ^ 1);
-            if (do_db) {
+            if (do_db) {   // bias gradient = row sums of the dy tile that is in LDS anyway
                 const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
@@ -286,318 +355,428 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
             }
             if (!(dbg & 4)) __syncthreads();
         }
+        // ---- segment end
+        auto store_db = [&](float v0, float v1) {   // finished bias gradient of this workgroup's co rows
+            const int rows = a.rows_per_src;
+            if ((ptid % TPR) != 0) return;
+            if constexpr (BH) {
+                const int co = co0 + 2 * (ptid / TPR);
+                if (co < a.Cout) {
+                    a.db[(long)(co / rows) * a.db_src_stride + co % rows] = v0;
+                    a.db[(long)((co + 1) / rows) * a.db_src_stride + (co + 1) % rows] = v1;
+                }
+            } else {
+                const int co = co0 + ptid / TPR;
+                if (co < a.Cout) a.db[(long)(co / rows) * a.db_src_stride + co % rows] = v0;
+            }
+        };
         if (do_db) {
 #pragma unroll
             for (int o = 1; o < TPR; o <<= 1) {
                 dbsum += __shfl_xor(dbsum, o);
                 if (BH) dbsum1 += __shfl_xor(dbsum1, o);
             }
+        }
+        if (dbg & 8) continue;   // (ablation: no stores, no reduce)
+        if (sg.nsplit == 1) {    // this workgroup walked the tile's whole K range
+            if (do_db) store_db(dbsum, dbsum1);
+            continue;
+        }
+        float* dbs_t = do_db ? a.dbslab + ((long)(tile / ci_tiles) * a.slots) * TCO : nullptr;
+        if (do_db && (ptid % TPR) == 0) {
             if constexpr (BH) {
-                const int co = co0 + 2 * (ptid / TPR);
-                if ((ptid % TPR) == 0 && co < a.Cout) {
-                    dbp[(long)z * a.db_stride + co] = dbsum;
-                    dbp[(long)z * a.db_stride + co + 1] = dbsum1;
-                }
+                dbs_t[(long)sg.z * TCO + 2 * (ptid / TPR)] = dbsum;
+                dbs_t[(long)sg.z * TCO + 2 * (ptid / TPR) + 1] = dbsum1;
             } else {
-                const int co = co0 + ptid / TPR;
-                if ((ptid % TPR) == 0 && co < a.Cout) dbp[(long)z * a.db_stride + co] = dbsum;
+                dbs_t[(long)sg.z * TCO + ptid / TPR] = dbsum;
             }
         }
-        return;
-    }
-
-    {
-    f32x16 acc[NACC];
-#pragma unroll
-    for (int j = 0; j < NACC; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const int buf = (chunk - c_begin) & 1;
-        if (!(dbg & 2)) {
-            const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * WG_DYROW;
-            const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * XROW;
-            constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
-            // fragments of k-step s+1 are requested before the MFMAs of step s are queued.  LIN (template): whole
-            // 32-column chunks of a stride-1 layer -- column 2s+h of the chunk is element 2s+h of both
-            // LDS rows, so every fragment address is base + immediate (the general form costs ~30
-            // hoisted address registers, which decides whether two workgroups fit on a CU).
-            {
-                const float* arow_h = arow + h;
-                const float* brow_h = brow + h;
-                auto ldfrag = [&](int s, float& av, float (&bv)[NACC]) {
-                    const float* bp;
-                    if constexpr (LIN) {
-                        av = arow_h[2 * s];
-                        bp = brow_h + 2 * s;
-                    } else {
-                        const int qcol = 2 * s + h;
-                        const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
-                        av = arow[qcol];
-                        bp = brow + sl * XSEG + tl * a.stride;
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int j = 0; j < KS; ++j) bv[nb * KS + j] = bp[nb * 32 * XROW + j];
-                };
+        if (!wg_arrive(bt, a, sg, smem, tid)) continue;
+        // last arriver: the slots in the fixed order z = 0 .. nsplit - 1
+        if (do_db && (ptid % TPR) == 0) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int zz = 0; zz < sg.nsplit; ++zz) {
                 if constexpr (BH) {
-                    // two blocks of 16 columns per chunk; lane-half h owns columns 16 kb + 8 h .. + 7 in BOTH operands
-                    const unsigned sel = (li & 1) ? 0x07060302u : 0x05040100u;   // this lane's channel = low / high half of its pair row
-                    constexpr int NX = 8 + KS - 1;
-                    auto fetch = [&](int kb, unsigned (&ad)[8], unsigned (&xd)[NB][LIN ? NX : 8 * KS]) {
-                        if constexpr (LIN) {   // 16-byte aligned rows: ds_read_b128
+                    s0 += dbs_t[(long)zz * TCO + 2 * (ptid / TPR)];
+                    s1 += dbs_t[(long)zz * TCO + 2 * (ptid / TPR) + 1];
+                } else {
+                    s0 += dbs_t[(long)zz * TCO + ptid / TPR];
+                }
+            }
+            store_db(s0, s1);
+        }
+    }
+}
+
+// ---------------- consumers: waves 0-3 -- fragment reads, MFMAs, and at a segment's end the partial tile / the finished gradient
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3>
+static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
+    using C = WgCfg<KS, RT, NB, WCO, LIN, BF>;
+    constexpr int WCI = C::WCI, TCO = C::TCO, TCI = C::TCI, NACC = C::NACC, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NBROW = C::NBROW;
+    constexpr bool BH = C::BH;
+    const int dbg = bt.dbg;
+    const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
+    f32x16 acc[NACC];
+    WgSegIter it(bt);
+    WgSeg sg;
+    while (it.next(bt, sg)) {
+        const WgradArgs& a = bt.L[sg.layer];
+        const int KSr = RT ? a.KS : KS;
+        const int ci_tiles = avc_cdiv(a.Cin, TCI);
+        const int Tc = a.Tc, spc = a.spc;
+        const int lgTc = 31 - __builtin_clz(Tc);
+        const int XSEG = (Tc - 1) * a.stride + KSr;
+        const int XROW = LIN ? wg_xrow_lin(KSr) : ((spc * XSEG) | 1);
+        const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
+        const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;
+        const float* dyT = smem;
+        const float* xT = smem + 2 * DYSP;
+        const long tile_floats = (long)4 * KSr * NB * 1024;   // 4 consumer waves x (taps x blocks) accumulators x 16 registers x 64 lanes
+        const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
+        const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        __syncthreads();
+        __syncthreads();   // the first chunk has landed
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const int buf = (chunk - c_begin) & 1;
+            if (!(dbg & 2)) {
+                const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * WG_DYROW;
+                const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * XROW;
+                // one straight-line chunk body.  RT: it is compiled for K = 8 taps and every tap's loads / MFMAs sit behind a WAVE-UNIFORM
+                // test of the layer's own tap count (a scalar branch per MFMA group: nothing beside a 64-cycle MFMA).  (A switch over eight
+                // per-tap-count bodies made the register allocator keep two copies of accumulators at the merge: spills in the loop.)
+                auto body = [&](auto ktag) {
+                    constexpr int K = decltype(ktag)::value;
+                    auto tap_on = [&](int j) { return !RT || j < KSr; };
+                    const float* arow_h = arow + h;
+                    const float* brow_h = brow + h;
+                    // fragments of k-step s+1 are requested before the MFMAs of step s are queued.  LIN: column 2s+h of the
+                    // chunk is element 2s+h of both LDS rows, so every fragment address is base + immediate.
+                    auto ldfrag = [&](int s, float& av, float (&bv)[NB * K]) {
+                        const float* bp;
+                        if constexpr (LIN) {
+                            av = arow_h[2 * s];
+                            bp = brow_h + 2 * s;
+                        } else {
+                            const int qcol = 2 * s + h;
+                            const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);  // Tc is a power of two
+                            av = arow[qcol];
+                            bp = brow + sl * XSEG + tl * a.stride;
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int j = 0; j < K; ++j)
+                                if (tap_on(j)) bv[nb * K + j] = bp[nb * 32 * XROW + j];
+                    };
+                    if constexpr (BH) {
+                        // two blocks of 16 columns per chunk; lane-half h owns columns 16 kb + 8 h .. + 7 in BOTH operands
+                        const unsigned sel = (li & 1) ? 0x07060302u : 0x05040100u;   // this lane's channel = low / high half of its pair row
+                        constexpr int NX = 8 + K - 1;
+                        auto fetch = [&](int kb, unsigned (&ad)[8], unsigned (&xd)[NB][LIN ? NX : 8 * K]) {
+                            if constexpr (LIN) {   // 16-byte aligned rows: ds_read_b128
+                                const float* ap = arow + 16 * kb + 8 * h;
+                                const float* bp = brow + 16 * kb + 8 * h;
+#pragma unroll
+                                for (int i4 = 0; i4 < 2; ++i4) {
+                                    const f32x4 v = *(const f32x4*)(ap + 4 * i4);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) ad[4 * i4 + i] = bh_as_u32(v[i]);
+                                }
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                    for (int i4 = 0; i4 < (NX + 3) / 4; ++i4) {
+                                        const f32x4 v = *(const f32x4*)(bp + nb * NBROW * XROW + 4 * i4);
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i)
+                                            if (4 * i4 + i < NX) xd[nb][4 * i4 + i] = bh_as_u32(v[i]);   // (RT: values past the layer's own 8 + k - 1 feed skipped taps only)
+                                    }
+                            } else {               // short samples / strided layers: every column has its own window
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const int qcol = 16 * kb + 8 * h + i;
+                                    const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
+                                    ad[i] = bh_as_u32(arow[qcol]);
+                                    const float* bp = brow + sl * XSEG + tl * a.stride;
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                        for (int j = 0; j < K; ++j)
+                                            if (tap_on(j)) xd[nb][i * K + j] = bh_as_u32(bp[nb * NBROW * XROW + j]);
+                                }
+                            }
+                        };
+                        auto block = [&](const unsigned (&ad)[8], const unsigned (&xd)[NB][LIN ? NX : 8 * K]) {
+                            avc_u32x4 at;
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) at[q4] = bh_sel(ad[2 * q4], ad[2 * q4 + 1], sel);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int j = 0; j < K; ++j) {
+                                    if (!tap_on(j)) continue;
+                                    avc_u32x4 bq;
+#pragma unroll
+                                    for (int q4 = 0; q4 < 4; ++q4) {
+                                        if constexpr (LIN) bq[q4] = bh_sel(xd[nb][j + 2 * q4], xd[nb][j + 2 * q4 + 1], sel);
+                                        else bq[q4] = bh_sel(xd[nb][(2 * q4) * K + j], xd[nb][(2 * q4 + 1) * K + j], sel);
+                                    }
+                                    acc[nb * KS + j] = avc_mfma_bf16x8(at, bq, acc[nb * KS + j]);
+                                }
+                        };
+                        unsigned a0[8], x0[NB][LIN ? NX : 8 * K], a1[8], x1[NB][LIN ? NX : 8 * K];
+                        fetch(0, a0, x0);
+                        fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
+                        block(a0, x0);
+                        block(a1, x1);
+                    } else if constexpr (X3 && LIN && !BF) {
+                        // two blocks of 16 columns: lane-half h owns columns 16 kb + 8 h .. + 7 of the chunk
+                        constexpr int NX = 8 + K - 1;   // x values under the K shifted windows of 8 columns
+                        auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {   // 16-byte aligned rows (LIN): ds_read_b128
                             const float* ap = arow + 16 * kb + 8 * h;
                             const float* bp = brow + 16 * kb + 8 * h;
 #pragma unroll
                             for (int i4 = 0; i4 < 2; ++i4) {
                                 const f32x4 v = *(const f32x4*)(ap + 4 * i4);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) ad[4 * i4 + i] = bh_as_u32(v[i]);
+                                for (int i = 0; i < 4; ++i) av[4 * i4 + i] = v[i];
                             }
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                                 for (int i4 = 0; i4 < (NX + 3) / 4; ++i4) {
-                                    const f32x4 v = *(const f32x4*)(bp + nb * NBROW * XROW + 4 * i4);
+                                    const f32x4 v = *(const f32x4*)(bp + nb * 32 * XROW + 4 * i4);
 #pragma unroll
                                     for (int i = 0; i < 4; ++i)
-                                        if (4 * i4 + i < NX) xd[nb][4 * i4 + i] = bh_as_u32(v[i]);
+                                        if (4 * i4 + i < NX) xv[nb][4 * i4 + i] = v[i];
                                 }
-                        } else {               // short samples / strided layers: every column has its own window
+                        };
+                        auto block = [&](const float (&av)[8], const float (&xv)[NB][NX]) {
+                            unsigned ah[8], am[8], al[8];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const int qcol = 16 * kb + 8 * h + i;
-                                const int sl = qcol >> lgTc, tl = qcol & (Tc - 1);
-                                ad[i] = bh_as_u32(arow[qcol]);
-                                const float* bp = brow + sl * XSEG + tl * a.stride;
+                            for (int i = 0; i < 8; ++i) x3_split(av[i], ah[i], am[i], al[i]);
+                            avc_u32x4 at[3];
 #pragma unroll
-                                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                                    for (int j = 0; j < KS; ++j) xd[nb][i * KS + j] = bh_as_u32(bp[nb * NBROW * XROW + j]);
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                at[0][q4] = x3_pair(ah[2 * q4], ah[2 * q4 + 1]);
+                                at[1][q4] = x3_pair(am[2 * q4], am[2 * q4 + 1]);
+                                at[2][q4] = x3_pair(al[2 * q4], al[2 * q4 + 1]);
                             }
-                        }
-                    };
-                    auto block = [&](const unsigned (&ad)[8], const unsigned (&xd)[NB][LIN ? NX : 8 * KS]) {
-                        avc_u32x4 at;
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) at[q4] = bh_sel(ad[2 * q4], ad[2 * q4 + 1], sel);
+                            for (int nb = 0; nb < NB; ++nb) {
+                                unsigned xh[NX], xm[NX], xl[NX];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
+                                for (int i = 0; i < NX; ++i) x3_split(xv[nb][i], xh[i], xm[i], xl[i]);
 #pragma unroll
-                            for (int j = 0; j < KS; ++j) {
-                                avc_u32x4 b;
+                                for (int j = 0; j < K; ++j) {
+                                    if (!tap_on(j)) continue;
+                                    avc_u32x4 q0, q1, q2;
 #pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) {
-                                    if constexpr (LIN) b[q4] = bh_sel(xd[nb][j + 2 * q4], xd[nb][j + 2 * q4 + 1], sel);
-                                    else b[q4] = bh_sel(xd[nb][(2 * q4) * KS + j], xd[nb][(2 * q4 + 1) * KS + j], sel);
+                                    for (int q4 = 0; q4 < 4; ++q4) {
+                                        q0[q4] = x3_pair(xh[j + 2 * q4], xh[j + 2 * q4 + 1]);
+                                        q1[q4] = x3_pair(xm[j + 2 * q4], xm[j + 2 * q4 + 1]);
+                                        q2[q4] = x3_pair(xl[j + 2 * q4], xl[j + 2 * q4 + 1]);
+                                    }
+                                    f32x16& c = acc[nb * KS + j];
+                                    // small terms first
+                                    c = avc_mfma_bf16x8(at[2], q0, c);
+                                    c = avc_mfma_bf16x8(at[0], q2, c);
+                                    c = avc_mfma_bf16x8(at[1], q1, c);
+                                    c = avc_mfma_bf16x8(at[1], q0, c);
+                                    c = avc_mfma_bf16x8(at[0], q1, c);
+                                    c = avc_mfma_bf16x8(at[0], q0, c);
                                 }
-                                acc[nb * KS + j] = avc_mfma_bf16x8(at, b, acc[nb * KS + j]);
                             }
-                    };
-                    unsigned a0[8], x0[NB][LIN ? NX : 8 * KS], a1[8], x1[NB][LIN ? NX : 8 * KS];
-                    fetch(0, a0, x0);
-                    fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
-                    block(a0, x0);
-                    block(a1, x1);
-                } else if constexpr (X3 && LIN && !BF) {
-                    // two blocks of 16 columns: lane-half h owns columns 16 kb + 8 h .. + 7 of the chunk
-                    constexpr int NX = 8 + KS - 1;   // x values under the KS shifted windows of 8 columns
-                    auto fetch = [&](int kb, float (&av)[8], float (&xv)[NB][NX]) {   // 16-byte aligned rows (LIN): ds_read_b128
-                        const float* ap = arow + 16 * kb + 8 * h;
-                        const float* bp = brow + 16 * kb + 8 * h;
-#pragma unroll
-                        for (int i4 = 0; i4 < 2; ++i4) {
-                            const f32x4 v = *(const f32x4*)(ap + 4 * i4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) av[4 * i4 + i] = v[i];
-                        }
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                            for (int i4 = 0; i4 < (NX + 3) / 4; ++i4) {
-                                const f32x4 v = *(const f32x4*)(bp + nb * 32 * XROW + 4 * i4);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (4 * i4 + i < NX) xv[nb][4 * i4 + i] = v[i];
-                            }
-                    };
-                    auto block = [&](const float (&av)[8], const float (&xv)[NB][NX]) {
-                        unsigned ah[8], am[8], al[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x3_split(av[i], ah[i], am[i], al[i]);
-                        avc_u32x4 at[3];
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            at[0][q4] = x3_pair(ah[2 * q4], ah[2 * q4 + 1]);
-                            at[1][q4] = x3_pair(am[2 * q4], am[2 * q4 + 1]);
-                            at[2][q4] = x3_pair(al[2 * q4], al[2 * q4 + 1]);
-                        }
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            unsigned xh[NX], xm[NX], xl[NX];
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) x3_split(xv[nb][i], xh[i], xm[i], xl[i]);
-#pragma unroll
-                            for (int j = 0; j < KS; ++j) {
-                                avc_u32x4 b0, b1, b2;
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) {
-                                    b0[q4] = x3_pair(xh[j + 2 * q4], xh[j + 2 * q4 + 1]);
-                                    b1[q4] = x3_pair(xm[j + 2 * q4], xm[j + 2 * q4 + 1]);
-                                    b2[q4] = x3_pair(xl[j + 2 * q4], xl[j + 2 * q4 + 1]);
-                                }
-                                f32x16& c = acc[nb * KS + j];
-                                // small terms first
-                                c = avc_mfma_bf16x8(at[2], b0, c);
-                                c = avc_mfma_bf16x8(at[0], b2, c);
-                                c = avc_mfma_bf16x8(at[1], b1, c);
-                                c = avc_mfma_bf16x8(at[1], b0, c);
-                                c = avc_mfma_bf16x8(at[0], b1, c);
-                                c = avc_mfma_bf16x8(at[0], b0, c);
-                            }
-                        }
-                    };
-                    float a0[8], x0[NB][NX], a1[8], x1[NB][NX];
-                    fetch(0, a0, x0);
-                    fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
-                    block(a0, x0);
-                    block(a1, x1);
-                } else if constexpr (LIN) {
-                    // Four groups of 8 columns per chunk; in group g lane-half h owns columns 8 g + 4 h + u, u = k-step 0..3, in BOTH
-                    // operands (the sum over columns does not care about the order).  Its four dy values are ONE ds_read_b128, and the
-                    // 4 + KS - 1 x values under its KS shifted windows are (KS + 6) / 4 more: 3 reads per 20 MFMAs at k = 5, where
-                    // round 2 issued 6 ds_read_b32 per 5 (the consumer waves run alone on their SIMD: every read they issue is
-                    // matrix-pipe idle time, profiles/r02_mfma_probe.log).  BF: the same fragments rounded to bf16, one
-                    // v_mfma_f32_32x32x8_bf16 per tap and group.
-                    constexpr int NX4 = (KS + 6) / 4;          // 16-byte reads covering 4 + KS - 1 values
-                    auto ldgrp = [&](int g, f32x4& av, f32x4 (&xv)[NB][NX4]) {
-                        const int c = 8 * g + 4 * h;
-                        av = *(const f32x4*)(arow + c);
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                            for (int i4 = 0; i4 < NX4; ++i4) xv[nb][i4] = *(const f32x4*)(brow + nb * 32 * XROW + c + 4 * i4);
-                    };
-                    f32x4 av[2], xv[2][NB][NX4];
-                    ldgrp(0, av[0], xv[0]);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cur = g & 1;
-                        if (g + 1 < 4) ldgrp(g + 1, av[cur ^ 1], xv[cur ^ 1]);
-                        __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay in front of the MFMAs they overlap with ...
-                        if constexpr (BF) {
-                            const avc_s16x4 ap = avc_pack_bf16x4(av[cur][0], av[cur][1], av[cur][2], av[cur][3]);
+                        };
+                        float a0[8], x0[NB][NX], a1[8], x1[NB][NX];
+                        fetch(0, a0, x0);
+                        fetch(1, a1, x1);   // (requested before the first block's MFMAs are issued)
+                        block(a0, x0);
+                        block(a1, x1);
+                    } else if constexpr (LIN) {
+                        // Four groups of 8 columns per chunk; in group g lane-half h owns columns 8 g + 4 h + u, u = k-step 0..3, in
+                        // BOTH operands (the sum over columns does not care about the order).  Its four dy values are ONE
+                        // ds_read_b128, and the 4 + K - 1 x values under its K shifted windows are (K + 6) / 4 more: 3 reads per 20
+                        // MFMAs at k = 5.  BF: the same fragments rounded to bf16, one v_mfma_f32_32x32x8_bf16 per tap and group.
+                        constexpr int NX4 = (K + 6) / 4;          // 16-byte reads covering 4 + K - 1 values
+                        auto ldgrp = [&](int gq, f32x4& av, f32x4 (&xv)[NB][NX4]) {
+                            const int c = 8 * gq + 4 * h;
+                            av = *(const f32x4*)(arow + c);
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                                for (int j = 0; j < KS; ++j) {
-                                    const avc_s16x4 bp = avc_pack_bf16x4(xv[cur][nb][j >> 2][j & 3], xv[cur][nb][(j + 1) >> 2][(j + 1) & 3],
-                                                                         xv[cur][nb][(j + 2) >> 2][(j + 2) & 3], xv[cur][nb][(j + 3) >> 2][(j + 3) & 3]);
-                                    acc[nb * KS + j] = avc_mfma_bf16(ap, bp, acc[nb * KS + j]);
-                                }
-                        } else {
+                                for (int i4 = 0; i4 < NX4; ++i4)
+                                    if (!RT || 4 * i4 < 3 + KSr) xv[nb][i4] = *(const f32x4*)(brow + nb * 32 * XROW + c + 4 * i4);
+                        };
+                        f32x4 av[2], xv[2][NB][NX4];
+                        ldgrp(0, av[0], xv[0]);
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int cur = gq & 1;
+                            if (gq + 1 < 4) ldgrp(gq + 1, av[cur ^ 1], xv[cur ^ 1]);
+                            __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay in front of the MFMAs they overlap with ...
+                            if constexpr (BF != 0) {
+                                const avc_s16x4 ap = avc_pack_bf16x4(av[cur][0], av[cur][1], av[cur][2], av[cur][3]);
 #pragma unroll
                                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                                    for (int j = 0; j < KS; ++j)
-                                        acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], xv[cur][nb][(u + j) >> 2][(u + j) & 3], acc[nb * KS + j], 0, 0, 0);
+                                    for (int j = 0; j < K; ++j) {
+                                        if (!tap_on(j)) continue;
+                                        const avc_s16x4 bp = avc_pack_bf16x4(xv[cur][nb][j >> 2][j & 3], xv[cur][nb][(j + 1) >> 2][(j + 1) & 3],
+                                                                             xv[cur][nb][(j + 2) >> 2][(j + 2) & 3], xv[cur][nb][(j + 3) >> 2][(j + 3) & 3]);
+                                        acc[nb * KS + j] = avc_mfma_bf16(ap, bp, acc[nb * KS + j]);
+                                    }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                        for (int j = 0; j < K; ++j)
+                                            if (tap_on(j)) acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], xv[cur][nb][(u + j) >> 2][(u + j) & 3], acc[nb * KS + j], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);  // ... and one group ahead only
                         }
-                        __builtin_amdgcn_sched_barrier(0);  // ... and one group ahead only
-                    }
-                } else if constexpr (BF) {
-                    // four k-steps (8 columns) per v_mfma_f32_32x32x8_bf16: slot j of lane-half h carries
-                    // column 2(4g + j) + h of the chunk in both operands; operands are rounded to bf16 here
-                    float av4[2][4], bv4[2][4][NACC];
+                    } else if constexpr (BF != 0) {
+                        // four k-steps (8 columns) per v_mfma_f32_32x32x8_bf16: slot j of lane-half h carries
+                        // column 2(4g + j) + h of the chunk in both operands; operands are rounded to bf16 here
+                        float av4[2][4], bv4[2][4][NB * K];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ldfrag(j, av4[0][j], bv4[0][j]);
+                        for (int j = 0; j < 4; ++j) ldfrag(j, av4[0][j], bv4[0][j]);
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int cur = g4 & 1;
-                        if (g4 + 1 < 4) {
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int cur = g4 & 1;
+                            if (g4 + 1 < 4) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) ldfrag(4 * (g4 + 1) + j, av4[cur ^ 1][j], bv4[cur ^ 1][j]);
+                                for (int j = 0; j < 4; ++j) ldfrag(4 * (g4 + 1) + j, av4[cur ^ 1][j], bv4[cur ^ 1][j]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            const avc_s16x4 ap = avc_pack_bf16x4(av4[cur][0], av4[cur][1], av4[cur][2], av4[cur][3]);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int j = 0; j < K; ++j) {
+                                    if (!tap_on(j)) continue;
+                                    const int k = nb * K + j;
+                                    acc[nb * KS + j] = avc_mfma_bf16(ap, avc_pack_bf16x4(bv4[cur][0][k], bv4[cur][1][k], bv4[cur][2][k], bv4[cur][3][k]), acc[nb * KS + j]);
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        const avc_s16x4 ap = avc_pack_bf16x4(av4[cur][0], av4[cur][1], av4[cur][2], av4[cur][3]);
+                    } else {
+                        float av[2], bv[2][NB * K];
+                        ldfrag(0, av[0], bv[0]);
 #pragma unroll
-                        for (int k = 0; k < NACC; ++k)
-                            acc[k] = avc_mfma_bf16(ap, avc_pack_bf16x4(bv4[cur][0][k], bv4[cur][1][k], bv4[cur][2][k], bv4[cur][3][k]), acc[k]);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int s = 0; s < 16; ++s) {
+                            const int cur = s & 1;
+                            if (s + 1 < 16) ldfrag(s + 1, av[cur ^ 1], bv[cur ^ 1]);
+                            __builtin_amdgcn_sched_barrier(0);  // reads stay in front of the MFMAs they overlap with ...
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int j = 0; j < K; ++j)
+                                    if (tap_on(j)) acc[nb * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][nb * K + j], acc[nb * KS + j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
+                        }
                     }
-                } else {
-                float av[2], bv[2][NACC];
-                ldfrag(0, av[0], bv[0]);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int cur = s & 1;
-                    if (s + 1 < 16) ldfrag(s + 1, av[cur ^ 1], bv[cur ^ 1]);
-                    __builtin_amdgcn_sched_barrier(0);  // reads stay in front of the MFMAs they overlap with ...
-#pragma unroll
-                    for (int k = 0; k < NACC; ++k)
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][k], acc[k], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);  // ... and one step ahead only (hoisting all 16 steps' reads spills)
-                }
-                }
+                };
+                static_assert(!RT || KS == 8, "run-time tap counts are built for up to 8 taps");
+                body(KTag<KS>{});
             }
+            if (!(dbg & 4)) __syncthreads();
         }
-        if (!(dbg & 4)) __syncthreads();
-    }
 
-    // ---- epilogue: partial tile -> slab[z][tap][co][ci]  (tap-major: the 32 lanes of a half-wave
-    // hold 32 consecutive ci of one (tap, co) row -> 128-byte coalesced stores; the reduce kernel
-    // restores the [co][ci][tap] parameter layout)
-    float* slab = slabp + (long)z * a.slab_stride;
-    if (!(dbg & 8))
+        // ---------------- segment end
+        // thread (wave, lane) owns, per ci block nb and tap j, the 16 accumulator registers of output rows
+        // co = co0 + wave_m 32 + (r & 3) + 8 (r >> 2) + 4 h, column ci = ci0 + (wave_n NB + nb) 32 + li
+        auto store_final = [&]() {
+            const int rows = a.rows_per_src;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int ci = ci0 + (wave_n * NB + nb) * 32 + li;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int ci = ci0 + (wave_n * NB + nb) * 32 + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < a.Cout && ci < a.Cin) {
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (co < a.Cout && ci < a.Cin) {
+                        const int src = co / rows, rr = co - src * rows;
+                        float* d = a.dw + (long)src * a.dw_src_stride + ((long)rr * a.Cin + ci) * KSr;
 #pragma unroll
-                for (int j = 0; j < KS; ++j) slab[((long)j * a.Cout + co) * a.Cin + ci] = acc[nb * KS + j][r];
+                        for (int j = 0; j < KS; ++j)
+                            if (j < KSr) d[j] = acc[nb * KS + j][r];
+                    }
+                }
             }
+        };
+        if (dbg & 8) continue;   // (ablation: no stores, no reduce)
+        if (sg.nsplit == 1) {    // this workgroup walked the tile's whole K range: the accumulators ARE the gradient
+            store_final();
+            continue;
         }
-    }
+        // partial tile -> slot z of the tile, accumulator layout [consumer wave][accumulator][register quad][lane][4]: every store
+        // instruction of a wave is 1 KiB contiguous, and the last arriver's thread (wave, lane) reads exactly what it will own
+        float* slab_t = a.slab + ((long)tile * a.slots) * tile_floats + (long)wave * (KSr * NB * 1024) + lane * 4;
+        {
+            float* sp = slab_t + (long)sg.z * tile_floats;   // (a running pointer: one address register pair, 1 KiB steps)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+                    if (j < KSr) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = {acc[nb * KS + j][4 * q], acc[nb * KS + j][4 * q + 1], acc[nb * KS + j][4 * q + 2], acc[nb * KS + j][4 * q + 3]};
+                            *(f32x4*)sp = v;
+                            sp += 256;
+                        }
+                    }
+        }
+        if (!wg_arrive(bt, a, sg, smem, tid)) continue;
+        // ---- last arriver: sum the tile's slots in the fixed order z = 0 .. nsplit - 1 (bit-deterministic whichever workgroup
+        // this is), write the gradient in the parameter layout
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int zz = 0; zz < sg.nsplit; ++zz) {
+            const float* spz = slab_t + (long)zz * tile_floats;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+                    if (j < KSr) {
+                        f32x4 v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = *(const f32x4*)spz;
+                            spz += 256;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[nb * KS + j][4 * q] += v[q][0];
+                            acc[nb * KS + j][4 * q + 1] += v[q][1];
+                            acc[nb * KS + j][4 * q + 2] += v[q][2];
+                            acc[nb * KS + j][4 * q + 3] += v[q][3];
+                        }
+                        if constexpr (NACC > 5) __builtin_amdgcn_sched_barrier(0);   // (128 accumulator registers: do not hoist every tap's loads)
+                    }
+        }
+        store_final();
     }
 }
 
-// out[e] = sum_z slab[z*stride + e]   (fixed order -> deterministic)
-struct ReduceArgs {
-    ReduceSeg seg[AVC_REDUCE_MAXSEG];
-    int nseg;
-};
-
-__global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceArgs a) {
-    const ReduceSeg s = a.seg[blockIdx.y];
-    const int plane = s.n / s.KS;  // slab is [tap][rows*Cin]; dst is [rows*Cin][tap]
-    for (int e = blockIdx.x * AVC_THREADS + threadIdx.x; e < s.n; e += gridDim.x * AVC_THREADS) {
-        // fixed summation order (deterministic: v + slab 0 + slab 1 + ..., as ever); 16 independent loads in flight per thread -- a
-        // thread owns one or two elements, so the kernel's run time is (slabs / loads in flight) dependent HBM round trips: 4 in flight
-        // were 6-8 trips for 23-30 slabs, 16 are 2 (slots past the last slab re-read it and are not added)
-        float v = 0.f;
-        for (int zz = 0; zz < s.nsplit; zz += 16) {
-            float q[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int z = zz + k < s.nsplit ? zz + k : s.nsplit - 1;
-                q[k] = s.slab[(long)z * s.stride + e];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (zz + k < s.nsplit) v += q[k];
-        }
-        if (s.KS == 1) {
-            s.dst[e] = v;
-        } else {
-            int j = e / plane, rem = e - j * plane;
-            s.dst[(long)rem * s.KS + j] = v;
-        }
-    }
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3 = false>
+__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
+    // both stages start as zeros (the general staging path stores explicit zeros afterwards, the fast paths overwrite every position
+    // they read; positions nobody reads may hold an earlier layer's finite data)
+    for (int e = tid; e < bt.lds_flag; e += WG_THREADS) smem[e] = 0.f;
+    if (wave8 >= 4) wg_producer<KS, RT, NB, WCO, LIN, BF>(bt, smem, tid, lane, wave8 & 3);
+    else wg_consumer<KS, RT, NB, WCO, LIN, BF, X3>(bt, smem, tid, lane, wave8);
 }
 
 // --------------------------------------------------------------------------
@@ -605,35 +784,37 @@ __global__ void __launch_bounds__(AVC_THREADS) slab_reduce_kernel(const ReduceAr
 static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
     if (KS == 1 && Cin >= 96) {
         *NB = 4; *WCO = 4;      // 128 x 128
-    } else if (Cin % 64 == 0 || KS == 1) {
+    } else if (Cin % 64 == 0) {
         *NB = 1; *WCO = 2;      // 64 x 64
     } else {
         *NB = 1; *WCO = 4;      // 128 x 32: Cin = 80 wastes 17 % instead of 38 %
     }
 }
 
-static size_t wgrad_lds_bytes(const WgradArgs& a, int NB, int WCO) {
+// kernel instance a layer runs on; layers with equal keys share a launch.  KST: the tap count the instance is compiled for -- 1 and 5
+// (the model's own sizes on the 64 x 64 tile) have their own instances, every other case runs on the run-time-taps instance (KST = 8)
+struct WgradKey {
+    int KST, rt, NB, WCO, lin;
+    bool operator==(const WgradKey& o) const { return KST == o.KST && rt == o.rt && NB == o.NB && WCO == o.WCO && lin == o.lin; }
+};
+static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO) {
     const int half = a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1;   // pair rows
     const int TCO = 32 * WCO / half, TCI = 32 * NB * (4 / WCO) / half;
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
-    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 16;
+    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;   // + the last-arriver flag word
 }
-
-// kernel instance a layer runs on: (KS, NB, WCO, LIN); layers with equal keys can share a launch
-struct WgradKey {
-    int KS, NB, WCO, lin;
-    bool operator==(const WgradKey& o) const { return KS == o.KS && NB == o.NB && WCO == o.WCO && lin == o.lin; }
-};
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;
-    k.KS = a.KS;
     wgrad_shape(a.Cin, a.Cout, a.KS, &k.NB, &k.WCO);
-    if (k.KS == 1 && k.NB == 4 && wgrad_lds_bytes(a, 4, 4) > 158 * 1024) {  // LDS too small for the wide tile (many short samples)
+    if (a.KS == 1 && k.NB == 4 && wgrad_lds_bytes_for(a, 4, 4) > 158 * 1024) {  // LDS too small for the wide tile (many short samples)
         k.NB = 1;
         k.WCO = 2;
     }
+    if (a.KS == 1) { k.KST = 1; k.rt = 0; }
+    else if (a.KS == 5 && k.WCO == 2) { k.KST = 5; k.rt = 0; }
+    else { k.KST = 8; k.rt = 1; }
     k.lin = (a.Tc == 32 && a.stride == 1) ? 1 : 0;
     return k;
 }
@@ -657,160 +838,132 @@ void avc_wgrad_geometry(WgradArgs& a) {
     a.tiles = avc_cdiv(a.Cout, 32 * k.WCO) * avc_cdiv(a.Cin, 32 * k.NB * (4 / k.WCO));
 }
 
-// Split-K factors of a batch.  Layers that share a kernel instance share a launch and get the SAME number
-// of K-chunks per workgroup (every chunk costs the same there, so the launch is balanced); the count is
-// chosen so that the launch has about `target_wgs` workgroups, but at least 4 chunks (128 columns) per
-// workgroup so that the slab write + fixed-order reduce stay a small fraction of the work.
-void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
+// Plans a batch: layers that share a kernel instance (and an operand dtype) form ONE launch (<= AVC_WGRAD_MAXL layers), a stream-K
+// split over `target_wgs` workgroups -- fewer when the launch is small: a workgroup walks at least 4 chunks, and never less than one
+// chunk of the most expensive layer (so that every workgroup between a tile's first and last owner owns a chunk of it).
+// Fills grp / grid / chunk_cost / cost_begin / cost_total / slots / ctr_base (relative to the batch's first counter) / slab_need /
+// dbslab_need of every layer; returns the number of arrival counters the batch needs.
+int avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
     if (target_wgs < 1) target_wgs = 256;
-    for (int i = 0; i < n; ++i) avc_wgrad_geometry(L[i]);
-    std::vector<char> done((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
-        if (done[i]) continue;
-        const WgradKey k = wgrad_key(L[i]);
-        long units = 0;
-        for (int j = i; j < n; ++j)
-            if (!done[j] && wgrad_key(L[j]) == k) units += (long)L[j].tiles * L[j].total_chunks;
-        int cpw = (int)((units + target_wgs - 1) / target_wgs);
-        if (cpw < 4) cpw = 4;
-        // the launch must FIT the target (one workgroup per CU is resident: a 257th workgroup is a second round
-        // that doubles the launch time): grow the chunk run until the per-layer round-ups fit
-        for (;; ++cpw) {
-            long wgs = 0;
-            for (int j = i; j < n; ++j)
-                if (!done[j] && wgrad_key(L[j]) == k) wgs += (long)L[j].tiles * avc_cdiv(L[j].total_chunks, cpw);
-            if (wgs <= target_wgs || cpw >= (1 << 20)) break;
-        }
-        for (int j = i; j < n; ++j)
-            if (!done[j] && wgrad_key(L[j]) == k) {
-                int c = cpw < L[j].total_chunks ? cpw : L[j].total_chunks;
-                L[j].chunks_per_wg = c;
-                L[j].nsplit = avc_cdiv(L[j].total_chunks, c);
-                done[j] = 1;
-            }
+        avc_wgrad_geometry(L[i]);
+        L[i].grp = -1;
     }
+    int ngrp = 0, nctr = 0;
+    for (int i = 0; i < n; ++i) {
+        if (L[i].grp >= 0) continue;
+        const WgradKey k = wgrad_key(L[i]);
+        std::vector<int> mem;
+        for (int j = i; j < n && (int)mem.size() < AVC_WGRAD_MAXL; ++j)
+            if (L[j].grp < 0 && wgrad_key(L[j]) == k && L[j].bf16 == L[i].bf16) mem.push_back(j);
+        long C = 0;
+        int ccmax = 1;
+        for (int j : mem) {
+            WgradArgs& a = L[j];
+            a.grp = ngrp;
+            // cost of one chunk: its MFMAs (taps x ci blocks) + a fixed part (staging, barrier) worth about one tap
+            a.chunk_cost = a.KS * k.NB + 1;
+            ccmax = a.chunk_cost > ccmax ? a.chunk_cost : ccmax;
+            a.cost_begin = C;
+            C += (long)a.tiles * a.total_chunks * a.chunk_cost;
+        }
+        long grid = C / ((long)4 * ccmax);
+        if (grid > target_wgs) grid = target_wgs;
+        if (grid < 1) grid = 1;
+        const int TCOv = 32 * k.WCO;
+        for (int j : mem) {
+            WgradArgs& a = L[j];
+            a.grid = (int)grid;
+            a.cost_total = C;
+            a.ctr_base = nctr;
+            nctr += a.tiles;
+            int slots = 1;
+            for (int t = 0; t < a.tiles; ++t) {
+                const long cs = a.cost_begin + (long)t * a.total_chunks * a.chunk_cost;
+                const long wf = (cs * grid) / C, wl = ((cs + (long)(a.total_chunks - 1) * a.chunk_cost) * grid) / C;
+                slots = (int)(wl - wf + 1) > slots ? (int)(wl - wf + 1) : slots;
+            }
+            a.slots = slots;
+            const long tile_floats = (long)4 * a.KS * k.NB * 1024;
+            a.slab_need = slots > 1 ? (long)a.tiles * slots * tile_floats : 0;
+            a.dbslab_need = slots > 1 ? (long)avc_cdiv(a.Cout, TCOv) * slots * TCOv : 0;
+        }
+        ++ngrp;
+    }
+    return nctr;
 }
 
-void avc_wgrad_plan(const avc_tuning& tun, int B, int Cin, int Cout, int Tout, int KS, int* Tc, int* spc, int* chunks_per_sample, int* total_chunks,
-                    int* chunks_per_wg, int* nsplit) {
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tout = Tout; a.KS = KS; a.stride = 1;
-    avc_wgrad_plan_batch(&a, 1, tun.wgrad_target_wgs);
-    *Tc = a.Tc; *spc = a.spc; *chunks_per_sample = a.chunks_per_sample; *total_chunks = a.total_chunks;
-    *chunks_per_wg = a.chunks_per_wg; *nsplit = a.nsplit;
-}
-
-
-template <int KS, int NB, int WCO>
-static int launch_wgrad_t(const WgradBatch& bt, int total_wgs, bool lin, int bf, bool x3, size_t lds, double flops, hipStream_t stream) {
+template <int KS, bool RT, int NB, int WCO>
+static int launch_wgrad_t(const WgradBatch& bt, int grid_wgs, bool lin, int bf, bool x3, size_t lds, double flops, hipStream_t stream) {
     if (lds > 158 * 1024) return -3;
-    dim3 grid(total_wgs);
+    dim3 grid(grid_wgs);
     ProfScope ps(AVC_K_CONV_WGRAD, flops, 0.0, stream);
     if (bf == 2) {
-        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, true, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, false, 2>), grid, dim3(WG_THREADS), lds, stream, bt);
     } else if (bf) {
-        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, true, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, false, 1>), grid, dim3(WG_THREADS), lds, stream, bt);
     } else if (lin) {
         if constexpr (KS * NB <= 8) {
             if (x3) {
-                hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 0, true>), grid, dim3(WG_THREADS), lds, stream, bt);
+                hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, true, 0, true>), grid, dim3(WG_THREADS), lds, stream, bt);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, true, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
-    } else hipLaunchKernelGGL((conv_wgrad_kernel<KS, NB, WCO, false, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, true, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
+    } else hipLaunchKernelGGL((conv_wgrad_kernel<KS, RT, NB, WCO, false, 0>), grid, dim3(WG_THREADS), lds, stream, bt);
     return (int)hipGetLastError();
 }
 
-template <int KS>
-static int launch_wgrad_ks(const WgradBatch& bt, int total_wgs, const WgradKey& k, int bf, bool x3, size_t lds, double flops, hipStream_t stream) {
-    return k.WCO == 4 ? launch_wgrad_t<KS, 1, 4>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream)
-                      : launch_wgrad_t<KS, 1, 2>(bt, total_wgs, k.lin, bf, x3, lds, flops, stream);
-}
-
-// launches every layer of the batch (planned by avc_wgrad_plan_batch, slabs assigned): one launch per kernel
-// instance present, <= AVC_WGRAD_MAXL layers per launch
+// launches every layer of the batch (planned by avc_wgrad_plan_batch; slab / dbslab / dw / db assigned by the caller): one launch per
+// group.  `counters`: the batch's arrival counters, ZERO on entry (the caller's per-call memset; the kernels leave them zero).
 // ablation: timing-experiment bits of scripts/wgrad_ablate.py (results are wrong by construction when set)
-int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ablation) {
-    std::vector<char> done((size_t)n, 0);
-    for (int i = 0; i < n; ++i) {
-        if (done[i]) continue;
-        const WgradArgs& a0 = L[i];
-        if (a0.KS < 1 || a0.KS > 8) return -1;
-        const WgradKey k = wgrad_key(a0);
+int avc_launch_wgrad_batch(const WgradArgs* L, int n, int* counters, hipStream_t stream, int ablation) {
+    int ngrp = 0;
+    for (int i = 0; i < n; ++i) ngrp = L[i].grp + 1 > ngrp ? L[i].grp + 1 : ngrp;
+    for (int grp = 0; grp < ngrp; ++grp) {
         WgradBatch bt;
         memset(&bt, 0, sizeof(bt));
         bt.dbg = ablation;
-        int wgs = 0;
+        bt.counters = counters;
         size_t lds = 0;
         double flops = 0;
-        for (int j = i; j < n && bt.nlayers < AVC_WGRAD_MAXL; ++j) {
-            if (done[j] || !(wgrad_key(L[j]) == k) || L[j].bf16 != a0.bf16) continue;
-            if (L[j].padL >= L[j].Tin) return -6;
-            WgradArgs& d = bt.L[bt.nlayers++];
-            d = L[j];
-            d.wg_begin = wgs;
-            wgs += d.tiles * d.nsplit;
-            size_t l = wgrad_lds_bytes(d, k.NB, k.WCO);
+        WgradKey k;
+        memset(&k, 0, sizeof(k));
+        for (int j = 0; j < n; ++j) {
+            if (L[j].grp != grp) continue;
+            const WgradArgs& a0 = L[j];
+            if (a0.KS < 1 || a0.KS > 8) return -1;
+            if (a0.padL >= a0.Tin) return -6;
+            if (bt.nlayers == 0) k = wgrad_key(a0);
+            if (bt.nlayers >= AVC_WGRAD_MAXL) return -1;
+            if (a0.slots > 1 && (!a0.slab || (a0.db && !a0.dbslab))) return -1;
+            bt.L[bt.nlayers++] = a0;
+            size_t l = wgrad_lds_bytes_for(a0, k.NB, k.WCO);
             lds = l > lds ? l : lds;
-            flops += 2.0 * d.Cout * d.Cin * d.KS * (double)d.B * d.Tout;
-            done[j] = 1;
+            flops += 2.0 * a0.Cout * a0.Cin * a0.KS * (double)a0.B * a0.Tout;
         }
+        if (bt.nlayers == 0) continue;
+        const WgradArgs& a0 = bt.L[0];
         const int bf = a0.bf16 == AVC_COMPUTE_BF16 ? 1 : (a0.bf16 == AVC_COMPUTE_BF16S ? 2 : 0);
         const bool x3 = a0.bf16 == AVC_COMPUTE_F32X3;
         if (bf == 2)
             for (int j = 0; j < bt.nlayers; ++j)
                 if ((bt.L[j].Cin & 1) || (bt.L[j].Cout & 1) || bt.L[j].x.st != 1 || bt.L[j].dy.st != 1 || bt.L[j].x.ps != 1 || bt.L[j].dy.ps != 1) return -2;
+        bt.lds_flag = (int)(lds / 4) - 4;   // float index of the "I am the last arriver" word (behind the stages)
         int rc;
-        if (k.KS == 1 && k.NB == 4) rc = launch_wgrad_t<1, 4, 4>(bt, wgs, k.lin, bf, x3, lds, flops, stream);
-        else switch (k.KS) {
-            case 1: rc = launch_wgrad_ks<1>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 2: rc = launch_wgrad_ks<2>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 3: rc = launch_wgrad_ks<3>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 4: rc = launch_wgrad_ks<4>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 5: rc = launch_wgrad_ks<5>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 6: rc = launch_wgrad_ks<6>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            case 7: rc = launch_wgrad_ks<7>(bt, wgs, k, bf, x3, lds, flops, stream); break;
-            default: rc = launch_wgrad_ks<8>(bt, wgs, k, bf, x3, lds, flops, stream); break;
+        if (k.KST == 1) {
+            if (k.NB == 4) rc = launch_wgrad_t<1, false, 4, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+            else if (k.WCO == 4) rc = launch_wgrad_t<1, false, 1, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+            else rc = launch_wgrad_t<1, false, 1, 2>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+        } else if (k.KST == 5) {
+            rc = launch_wgrad_t<5, false, 1, 2>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+        } else {
+            if (k.WCO == 4) rc = launch_wgrad_t<8, true, 1, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+            else rc = launch_wgrad_t<8, true, 1, 2>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
         }
         if (rc) return rc;
-        // (layers of this key beyond AVC_WGRAD_MAXL stay !done and open their own launch when the outer loop reaches them)
     }
     return 0;
-}
-
-int avc_launch_reduce_segs(const ReduceSeg* segs, int n, hipStream_t stream) {
-    if (n < 1 || n > AVC_REDUCE_MAXSEG) return -1;
-    ReduceArgs r;
-    r.nseg = n;
-    int maxn = 0;
-    for (int i = 0; i < n; ++i) {
-        r.seg[i] = segs[i];
-        maxn = segs[i].n > maxn ? segs[i].n : maxn;
-    }
-    int blocks = avc_cdiv(maxn, AVC_THREADS);
-    if (blocks > 256) blocks = 256;
-    double rb = 0;
-    for (int i = 0; i < n; ++i) rb += 4.0 * segs[i].n * (segs[i].nsplit + 1);
-    ProfScope ps(AVC_K_REDUCE, 0.0, rb, stream);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, n), dim3(AVC_THREADS), 0, stream, r);
-    return (int)hipGetLastError();
-}
-
-int avc_launch_reduce(const float* slab, long stride, int nsplit, int n, float* dst, int KS, hipStream_t stream) {
-    ReduceArgs r;
-    r.nseg = 1;
-    r.seg[0].slab = slab;
-    r.seg[0].dst = dst;
-    r.seg[0].stride = stride;
-    r.seg[0].n = n;
-    r.seg[0].nsplit = nsplit;
-    r.seg[0].KS = KS;
-    int blocks = avc_cdiv(n, AVC_THREADS);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1), dim3(AVC_THREADS), 0, stream, r);
-    return (int)hipGetLastError();
 }

@@ -123,6 +123,8 @@ struct avc_plan {
     mutable hipEvent_t ev_spk_grads = nullptr;   // ... the speaker encoder's
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
+    long wg_ctr = -1;            // arrival counters of the stream-K weight-gradient launches (ints), zeroed at the top of every backward call
+    int wg_ctr_n = 0;
     int flags = 0;            // AVC_PLAN_*
     // ragged inference plans (avc_plan_create_ragged): per-level length / offset / tile tables
     struct RagLevel {
@@ -564,7 +566,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     // ---- split-K slabs, dy arena and the event pool: sized with a dry run of the backward pass
     if (!infer) {
         p->slab = p->ws_top;
-        long need[3] = {0, 0, 0};
+        long need[4] = {0, 0, 0, 0};
         avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
                           nullptr, nullptr, true, need);
         p->slab_floats = need[0];
@@ -573,6 +575,8 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->dyarena_floats = need[1];
         p->ws_top += (need[1] + 63) / 64 * 64;
         p->nev_need = (int)need[2];
+        p->wg_ctr_n = (int)need[3];
+        p->wg_ctr = p->alloc(p->wg_ctr_n);
     }
     // helper streams / events belong to the plan from here on (created on the device that is current NOW;
     // a process without a GPU -- host-only plan queries -- simply gets a single-stream plan)
@@ -774,23 +778,6 @@ static void set_res(ConvArgs& a, const float* res, int mode, long rb, long rc, i
     a.rb = rb; a.rc = rc; a.rt = rt; a.Tres = Tres;
 }
 
-struct Reducer {
-    std::vector<ReduceSeg> segs;
-    hipStream_t s;
-    bool dry;
-    int flush(hipStream_t st) {
-        for (size_t i = 0; i < segs.size(); i += AVC_REDUCE_MAXSEG) {
-            int n = (int)std::min<size_t>(AVC_REDUCE_MAXSEG, segs.size() - i);
-            if (!dry) {
-                int rc = avc_launch_reduce_segs(&segs[i], n, st);
-                if (rc) return rc;
-            }
-        }
-        segs.clear();
-        return 0;
-    }
-};
-
 struct BwdCtx {
     const avc_plan* p;
     const float* params;
@@ -799,7 +786,7 @@ struct BwdCtx {
     hipStream_t s;
     bool dry;
     long slab_used;
-    Reducer red;
+    int ctr_used;          // arrival counters handed out so far (ints at ws + p->wg_ctr)
     hipStream_t wstream;   // stream of the weight-gradient kernels of the current branch (== s when not overlapping)
     int nev;
     long dy_used;
@@ -832,53 +819,36 @@ static hipStream_t wgrad_edge(BwdCtx& c) {
     return c.wstream;
 }
 
-// Launch the pending weight gradients of this branch as batched launches on the branch's wgrad stream (ordered
-// behind everything queued on c.s so far: their dy operands are final), followed by the fixed-order slab
-// reduces into the flat gradient buffer.  Runs beside the dgrad / InstanceNorm-backward chain.
+// Launch the pending weight gradients of this branch on the branch's wgrad stream (ordered behind everything queued on c.s so far:
+// their dy operands are final): one stream-K launch per kernel instance present (conv_wgrad.hip), each writing its finished
+// gradients -- weights and biases -- straight into the flat gradient buffer.  Runs beside the dgrad / InstanceNorm-backward chain.
 static int flush_wgrads(BwdCtx& c) {
     if (c.pend.empty()) return 0;
     hipStream_t ls = wgrad_edge(c);
     const int n = (int)c.pend.size();
     std::vector<WgradArgs> L((size_t)n);
     for (int i = 0; i < n; ++i) L[i] = c.pend[i].a;
-    avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
+    const int nctr = avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
+    const int ctr0 = c.ctr_used;
+    c.ctr_used += nctr;
     for (int i = 0; i < n; ++i) {
         WgradArgs& a = L[i];
-        const long wsz = (long)a.Cout * a.Cin * a.KS;
-        const long need = (long)a.nsplit * (wsz + a.Cout);
         const long off = c.slab_used;
-        c.slab_used += (need + 63) / 64 * 64;
+        c.slab_used += (a.slab_need + a.dbslab_need + 63) / 64 * 64;
         if (c.dry) continue;
         a.slab = c.ws + c.p->slab + off;
-        a.slab_stride = wsz;
-        a.dbslab = a.slab + (long)a.nsplit * wsz;
-        a.db_stride = a.Cout;
+        a.dbslab = a.slab + a.slab_need;
         const LayerP& Lp = *c.pend[i].L;
-        for (int s = 0; s < Lp.nsrc; ++s) {
-            ReduceSeg w;
-            w.slab = a.slab + (long)s * Lp.rows * Lp.Cin * Lp.KS;
-            w.dst = c.grads + c.p->params[Lp.w[s]].off;
-            w.stride = a.slab_stride;
-            w.n = (int)((long)Lp.rows * Lp.Cin * Lp.KS);
-            w.nsplit = a.nsplit;
-            w.KS = Lp.KS;
-            ReduceSeg b;
-            b.slab = a.dbslab + (long)s * Lp.rows;
-            b.dst = c.grads + c.p->params[Lp.b[s]].off;
-            b.stride = a.db_stride;
-            b.n = Lp.rows;
-            b.nsplit = a.nsplit;
-            b.KS = 1;
-            c.red.segs.push_back(w);
-            c.red.segs.push_back(b);
-        }
+        a.rows_per_src = Lp.rows;
+        a.dw = c.grads + c.p->params[Lp.w[0]].off;
+        a.db = c.grads + c.p->params[Lp.b[0]].off;
+        a.dw_src_stride = Lp.nsrc > 1 ? c.p->params[Lp.w[1]].off - c.p->params[Lp.w[0]].off : 0;
+        a.db_src_stride = Lp.nsrc > 1 ? c.p->params[Lp.b[1]].off - c.p->params[Lp.b[0]].off : 0;
     }
     c.pend.clear();
     c.pend_units = 0;
     if (c.dry) return 0;
-    int rc = avc_launch_wgrad_batch(L.data(), n, ls, c.p->tun.wgrad_ablation);
-    if (rc) return rc;
-    return c.red.flush(ls);
+    return avc_launch_wgrad_batch(L.data(), n, (int*)(c.ws + c.p->wg_ctr) + ctr0, ls, c.p->tun.wgrad_ablation);
 }
 
 // weight + bias gradient of layer L: x = forward input view, dy = output-gradient view (recorded; see flush_wgrads)
@@ -1265,10 +1235,12 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                       long* slab_need) {
     BwdCtx c;
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
-    c.nev = 0; c.dy_used = 0; c.pend_units = 0;
+    c.nev = 0; c.dy_used = 0; c.pend_units = 0; c.ctr_used = 0;
+    // arrival counters of the weight-gradient launches: zero before every call (a memset node; the kernels leave them zero, this covers
+    // a fresh workspace and an aborted call).  Every wgrad launch is ordered behind this point (wgrad_edge / the side-stream fork).
+    if (!dry && p->wg_ctr_n > 0) RUN((int)hipMemsetAsync(ws + p->wg_ctr, 0, (size_t)p->wg_ctr_n * sizeof(int), s));
     const bool overlap = !dry && side_ready(p);
     c.wstream = overlap ? p->wstream[0] : s;
-    c.red.s = s; c.red.dry = dry;
     const int B = p->B;
     const bool bh = p->bh;
     const int NV = (int)p->tun.in_pairs_nv;
@@ -1396,16 +1368,18 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             w.dy.ptr = ws + La.wplain; w.dy.sb = 0; w.dy.sc = La.Mp_f; w.dy.st = 1; w.dy.ps = 1;
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
             w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = bh ? AVC_COMPUTE_BF16 : p->compute;   // (fp32-stored operands either way)
-            avc_wgrad_plan_batch(&w, 1, 256);
-            const long wsz = (long)w.Cout * w.Cin;
+            w.rows_per_src = w.Cout;
+            const int nctr = avc_wgrad_plan_batch(&w, 1, 256);
             const long off = c.slab_used;
-            c.slab_used += ((long)w.nsplit * wsz + 63) / 64 * 64;
+            c.slab_used += (w.slab_need + 63) / 64 * 64;
+            const int ctr0 = c.ctr_used;
+            c.ctr_used += nctr;
             if (!dry) {
                 w.slab = ws + p->slab + off;
-                w.slab_stride = wsz;
                 w.dbslab = nullptr;
-                RUN(avc_launch_wgrad_batch(&w, 1, s, p->tun.wgrad_ablation));
-                RUN(avc_launch_reduce(w.slab, wsz, w.nsplit, (int)wsz, ws + p->demb, 1, s));  // demb: channel-major [c_cond][B]
+                w.dw = ws + p->demb;   // demb: channel-major [c_cond][B]
+                w.db = nullptr;
+                RUN(avc_launch_wgrad_batch(&w, 1, (int*)(ws + p->wg_ctr) + ctr0, s, p->tun.wgrad_ablation));
                 if (d_emb_up) RUN(avc_launch_add_transposed(ws + p->demb, d_emb_up, B, d.c.c_cond, s));
             }
         }
@@ -1573,12 +1547,12 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             hipStreamWaitEvent(mainS, p->wjoin[i], 0);
         }
     }
-    RUN(c.red.flush(s));
     if (!dry && p->side_state == 1) hipEventRecord(p->ev_all_grads, s);
     if (slab_need) {
         slab_need[0] = c.slab_used;
         slab_need[1] = c.dy_used;
         slab_need[2] = c.nev;
+        slab_need[3] = c.ctr_used;
     }
     return 0;
 }

@@ -181,35 +181,41 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
 
-// workspace (floats) needed by avc_conv1d_wgrad for the split-K slabs
+// workspace (floats) needed by avc_conv1d_wgrad: the partial-tile slots of the stream-K launch + its arrival counters
+static void op_wgrad_args(WgradArgs& a, int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride) {
+    memset(&a, 0, sizeof(a));
+    const avc_tuning& t = avc_op_tuning();
+    a.bf16 = (t.op_compute_dtype == AVC_COMPUTE_F32 && t.wgrad_x3) ? AVC_COMPUTE_F32X3 : (op_bh() ? AVC_COMPUTE_BF16S : t.op_compute_dtype);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
+    a.KS = KS; a.padL = KS / 2; a.stride = stride;
+    a.x.ps = 1; a.dy.ps = 1;
+}
 long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
-    int Tc, spc, cps, tot, cpw, nsplit;
-    avc_wgrad_plan(avc_op_tuning(), B, Cin, Cout, Tout, KS, &Tc, &spc, &cps, &tot, &cpw, &nsplit);
-    return (long)nsplit * ((long)Cout * Cin * KS + Cout);
+    long need = 0;
+    for (int stride = 1; stride <= 2; ++stride) {   // (the query does not know the stride: both geometries fit)
+        WgradArgs a;
+        op_wgrad_args(a, B, Cin, Cout, Tout * stride, Tout, KS, stride);
+        const int nctr = avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
+        const long n = a.slab_need + a.dbslab_need + 64 + nctr;
+        need = n > need ? n : need;
+    }
+    return need;
 }
 int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* dy, long syb, long syc, int syt, int yps,
                      int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride, float* dW, float* db, float* ws,
                      void* stream) {
     WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    {
-        const avc_tuning& t = avc_op_tuning();
-        a.bf16 = (t.op_compute_dtype == AVC_COMPUTE_F32 && t.wgrad_x3) ? AVC_COMPUTE_F32X3 : (op_bh() ? AVC_COMPUTE_BF16S : t.op_compute_dtype);
-    }
+    op_wgrad_args(a, B, Cin, Cout, Tin, Tout, KS, stride);
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
-    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tout;
-    a.KS = KS; a.padL = KS / 2; a.stride = stride;
-    avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
-    const int nsplit = a.nsplit;
-    long wsz = (long)Cout * Cin * KS;
-    a.slab = ws; a.slab_stride = wsz;
-    a.dbslab = db ? ws + (long)nsplit * wsz : nullptr; a.db_stride = Cout;
-    int rc = avc_launch_wgrad_batch(&a, 1, (hipStream_t)stream, avc_op_tuning().wgrad_ablation);
+    const int nctr = avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
+    a.slab = ws;
+    a.dbslab = db ? ws + a.slab_need : nullptr;
+    int* ctr = (int*)(ws + ((a.slab_need + a.dbslab_need + 63) / 64 * 64));
+    a.dw = dW; a.db = db; a.rows_per_src = Cout;
+    int rc = (int)hipMemsetAsync(ctr, 0, (size_t)nctr * sizeof(int), (hipStream_t)stream);
     if (rc) return rc;
-    rc = avc_launch_reduce(a.slab, a.slab_stride, nsplit, (int)wsz, dW, KS, (hipStream_t)stream);
-    if (rc || !db) return rc;
-    return avc_launch_reduce(a.dbslab, a.db_stride, nsplit, Cout, db, 1, (hipStream_t)stream);
+    return avc_launch_wgrad_batch(&a, 1, ctr, (hipStream_t)stream, avc_op_tuning().wgrad_ablation);
 }
 
 // out = relu((y - mean_T)/sqrt(var_T + 1e-5) * gamma + beta) [+ resmap(res)]; saves mean/rstd

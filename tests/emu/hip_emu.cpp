@@ -98,9 +98,19 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     gridDim = grid;
     blockDim = block;
     g_smem.assign(smem + 64, 0);
+    // Workgroups run one after the other.  Real hardware promises no order, so kernels that hand data from workgroup to workgroup
+    // (the last-arriver reduce of conv_wgrad.hip) are also tested in REVERSED and in an interleaved order: AVC_EMU_BLOCK_ORDER = reverse | stride
+    const char* ord = getenv("AVC_EMU_BLOCK_ORDER");
+    const int order = !ord ? 0 : (strcmp(ord, "reverse") == 0 ? 1 : (strcmp(ord, "stride") == 0 ? 2 : 0));
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+            for (unsigned bi = 0; bi < grid.x; ++bi) {
+                unsigned bx = bi;
+                if (order == 1) bx = grid.x - 1 - bi;
+                if (order == 2) {   // 0, 3, 6, ..., 1, 4, 7, ..., 2, 5, 8, ...
+                    const unsigned n0 = (grid.x + 2) / 3, n1 = (grid.x + 1) / 3;
+                    bx = bi < n0 ? 3 * bi : (bi < n0 + n1 ? 3 * (bi - n0) + 1 : 3 * (bi - n0 - n1) + 2);
+                }
                 blockIdx = dim3(bx, by, bz);
                 // poison dynamic LDS with NaNs so that uninitialised reads show up
                 for (size_t i = 0; i + 4 <= g_smem.size(); i += 4) {

@@ -451,3 +451,30 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     print(f"[{kind} x3 dgrad] max |err| vs fp64: split-bf16 {e_x3:.2e}, fp32 conv {e_32:.2e}")
     assert e_x3 <= bar * e_32 + 1e-7, (e_x3, e_32)
     torch.testing.assert_close(dx.cpu(), dx32, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", [(4, 16, 32, 64, 5, 1), (6, 80, 32, 64, 7, 1), (8, 16, 32, 32, 5, 2), (3, 130, 40, 96, 1, 1)])
+def test_conv_wgrad_last_arriver_reduce_is_order_independent(B, Cin, Cout, T, KS, stride, monkeypatch):
+    """The stream-K launch hands partial tiles from workgroup to workgroup; the LAST workgroup to arrive at a tile sums the tile's slots
+    in the fixed order z = 0, 1, ... -- so the gradient must be bit-identical whichever workgroup that is.  The simulator runs the
+    workgroups in ascending, reversed and interleaved order (hardware promises none)."""
+    lib, dev = backend("emu")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, T, generator=g)
+    To = (T + 2 * (KS // 2) - (1 if KS % 2 == 0 else 0) - KS) // stride + 1
+    dy = torch.randn(B, Cout, To, generator=g)
+    res = []
+    for order in ("", "reverse", "stride"):
+        monkeypatch.setenv("AVC_EMU_BLOCK_ORDER", order)
+        ws = torch.full((lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, To, KS),), float("nan"))
+        dW = torch.full((Cout, Cin, KS), float("nan"))
+        db = torch.full((Cout,), float("nan"))
+        assert lib.avc_conv1d_wgrad(P(x), x.stride(0), x.stride(1), 1, P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cin, Cout, T, To, KS, stride,
+                                    P(dW), P(db), P(ws), None) == 0
+        res.append((dW, db))
+    w = (torch.randn(Cout, Cin, KS, generator=g)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    dw_ref, db_ref = torch.autograd.grad(O.pad_conv(x, w, b, stride), [w, b], dy)
+    torch.testing.assert_close(res[0][0], dw_ref, rtol=1e-4, atol=1e-4)
+    for dW, db in res[1:]:
+        assert torch.equal(dW, res[0][0]) and torch.equal(db, res[0][1])
