@@ -107,10 +107,9 @@ struct ConvArgs {
 // One layer of a weight-gradient launch (conv_wgrad.hip).  A launch is a STREAM-K split of all its layers: the K-chunks (32 columns of
 // the (b, t) axis) of every (co, ci) tile of every layer form one sequence, weighted by chunk_cost; workgroup w of `grid` owns the chunks
 // whose start cost lies in [ceil(w C / grid), ceil((w + 1) C / grid)) -- exactly `grid` workgroups (one per CU), balanced to one chunk,
-// whatever the layers' shapes are.  A workgroup that leaves a tile stores its partial sum (accumulator layout) into that tile's slot
-// z = (its index among the tile's workgroups) and takes a ticket on the tile's arrival counter; the LAST workgroup to arrive sums the
-// slots in the fixed order z = 0, 1, ... (bit-deterministic whatever the arrival order was) and writes the finished gradient tile --
-// and the bias gradient -- straight into the flat gradient buffer.  No second launch.
+// whatever the layers' shapes are.  A workgroup that walked a tile's whole K range stores the finished gradient tile; otherwise it
+// stores its partial sum (accumulator layout) into that tile's slot z = (its index among the tile's workgroups), and the batch's reduce
+// launch sums the slots in the fixed order z = 0, 1, ... (bit-deterministic) into the flat gradient buffer, bias gradients included.
 struct WgradArgs {
     ConvSrc x;    // conv input  [B, Cin, Tin]   (reflect padded on the fly)
     ConvSrc dy;   // output grad [B, Cout, Tout]
@@ -124,8 +123,8 @@ struct WgradArgs {
     int grid;         // workgroups of that launch
     int chunk_cost;   // cost units of one K-chunk of this layer (taps + a fixed part)
     int slots;        // slab slots per tile (>= the number of workgroups any tile of this layer is split over)
-    int ctr_base;     // first arrival counter of this layer (index into WgradBatch.counters)
-    int rows_per_src; // stacked layers (heads, AdaIN affines): output rows per parameter tensor
+    int tNB, tWCO;    // tile shape of the layer's kernel instance: (32 tWCO) co x (32 tNB 4 / tWCO) ci
+    int rows_per_src; // (caller) stacked layers (heads, AdaIN affines): output rows per parameter tensor
     long cost_begin;  // cost units in front of this layer inside its launch
     long cost_total;  // ... of the whole launch
     long slab_need, dbslab_need;   // floats the caller must provide at slab / dbslab
@@ -140,20 +139,11 @@ struct WgradArgs {
 struct WgradBatch {
     int nlayers;
     int dbg;   // ablation switches of the micro-benchmarks (0 in the product path)
-    int lds_flag;    // int index (in the dynamic LDS segment) of the "last arriver" flag word
+    int lds_floats;  // floats of the dynamic LDS segment (zero-filled once per workgroup)
     int pad_;
-    int* counters;   // arrival counters (zero before the launch; the last arriver of a tile resets its counter)
     WgradArgs L[AVC_WGRAD_MAXL];
 };
 
-struct ReduceSeg {
-    const float* slab;
-    float* dst;
-    long stride;
-    int n, nsplit;
-    int KS;  // > 1: slab is tap-major [KS][n/KS], dst is [n/KS][KS]
-    int pad_;
-};
 #define AVC_DENSE_MAXL 17
 struct DenseLayer {
     const float* wp;    // packed weight image [Kp][Mp] (forward image, or the dgrad image for the backward kernel)

@@ -47,8 +47,8 @@ int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
 
 void avc_wgrad_geometry(WgradArgs& a);
-int avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);   // returns the number of arrival counters the batch needs
-int avc_launch_wgrad_batch(const WgradArgs* layers, int n, int* counters, hipStream_t stream, int ablation = 0);
+void avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);
+int avc_launch_wgrad_batch(const WgradArgs* layers, int n, hipStream_t stream, int ablation = 0);   // the stream-K launches + the batch's reduce launch
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s);
 int avc_launch_in_bwd(const INBwdArgs& a, hipStream_t s);

@@ -4,9 +4,11 @@
 // GEMM view: M = co, N = (ci, tap), K = (b, t).  A workgroup holds a 64co x 64ci x KS (or 128 x 32, 128 x 128) tile in
 // accumulator registers and walks 32-column K-chunks of it.  Since round 4 a launch is a STREAM-K split of ALL its layers
 // (avc_common.h, WgradArgs): exactly `grid` persistent workgroups, each owning one contiguous run of the launch's
-// (layer, tile, chunk) sequence; a workgroup that leaves a tile publishes its partial sum and takes a ticket, the LAST
-// arriver of the tile sums the partials in a fixed order (deterministic) and writes the finished gradient -- weights in the
-// parameter layout, plus the bias gradient -- straight into the flat gradient buffer.  There is no reduce launch.
+// (layer, tile, chunk) sequence.  A workgroup that walked a tile's WHOLE K range writes the finished gradient (parameter
+// layout) itself; otherwise it stores its partial tile into the tile's slot z, and ONE chip-wide reduce launch behind the
+// batch's launches sums every tile's slots in the fixed order z = 0, 1, ... (bit-deterministic) into the flat gradient buffer.
+// (An in-kernel reduce by the last workgroup to arrive at a tile was built first and measured SLOWER -- one workgroup reading
+// nsplit x 80..131 KB serially, 44 GB/s: profiles/r04_wgrad_inkernel_reduce_ablate.log.)
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,24 +35,9 @@ static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
 }
 
-// ---- inter-workgroup hand-off of the partial tiles (cdna_hip_programming.md, Guideline 16 in its counter form): plain 16-byte
-// slab stores -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane: agent-scope release, ticket; the workgroup that
-// draws the last ticket: ONE lane agent-scope acquire -> barrier -> plain loads.  Placement-independent.
 #ifndef AVC_EMU
-static __device__ __forceinline__ void wg_drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-static __device__ __forceinline__ int wg_ticket(int* ctr) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restates the wait behind buffer_wbl2 where the compiler cannot drop it)
-    return __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-static __device__ __forceinline__ void wg_ctr_reset(int* ctr) { __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) { return __builtin_amdgcn_perm(d1, d0, sel); }
 #else
-static inline void wg_drain_vm() {}
-static inline int wg_ticket(int* ctr) { int o = *ctr; *ctr = o + 1; return o; }
-static inline void wg_acquire() {}
-static inline void wg_ctr_reset(int* ctr) { *ctr = 0; }
 static inline unsigned bh_sel(unsigned d0, unsigned d1, unsigned sel) {   // sel = 0x05040100 (low halves) or 0x07060302 (high halves)
     return sel == 0x05040100u ? ((d0 & 0xffffu) | (d1 << 16)) : ((d0 >> 16) | (d1 & 0xffff0000u));
 }
@@ -142,25 +129,6 @@ struct WgCfg {
     static constexpr int CPT = 32 / TPR;
     static constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
 };
-
-// the inter-workgroup part of a segment's end, executed by all eight waves: returns true in the LAST arriver of the tile
-static __device__ __forceinline__ bool wg_arrive(const WgradBatch& bt, const WgradArgs& a, const WgSeg& sg, float* smem, int tid) {
-    wg_drain_vm();     // every storing wave: its slab stores have left
-    __syncthreads();
-    int* flag = (int*)smem + bt.lds_flag;   // the "I am the last arriver" word lives behind the stages
-    if (tid == 0) {
-        int* ctr = bt.counters + a.ctr_base + sg.tile;
-        const int old = wg_ticket(ctr);
-        const int last = (old == sg.nsplit - 1) ? 1 : 0;
-        if (last) {
-            wg_acquire();
-            wg_ctr_reset(ctr);   // (the next launch finds a zero; the per-call memset covers a fresh workspace / an aborted call)
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
 
 // ---------------- producers: waves 4-7.  Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
 // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1 lands while chunk c multiplies.
@@ -390,20 +358,6 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
             } else {
                 dbs_t[(long)sg.z * TCO + ptid / TPR] = dbsum;
             }
-        }
-        if (!wg_arrive(bt, a, sg, smem, tid)) continue;
-        // last arriver: the slots in the fixed order z = 0 .. nsplit - 1
-        if (do_db && (ptid % TPR) == 0) {
-            float s0 = 0.f, s1 = 0.f;
-            for (int zz = 0; zz < sg.nsplit; ++zz) {
-                if constexpr (BH) {
-                    s0 += dbs_t[(long)zz * TCO + 2 * (ptid / TPR)];
-                    s1 += dbs_t[(long)zz * TCO + 2 * (ptid / TPR) + 1];
-                } else {
-                    s0 += dbs_t[(long)zz * TCO + ptid / TPR];
-                }
-            }
-            store_db(s0, s1);
         }
     }
 }
@@ -716,7 +670,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
             continue;
         }
         // partial tile -> slot z of the tile, accumulator layout [consumer wave][accumulator][register quad][lane][4]: every store
-        // instruction of a wave is 1 KiB contiguous, and the last arriver's thread (wave, lane) reads exactly what it will own
+        // instruction of a wave is 1 KiB contiguous, and thread (wave, lane) of the reduce launch reads exactly what it will own
         float* slab_t = a.slab + ((long)tile * a.slots) * tile_floats + (long)wave * (KSr * NB * 1024) + lane * 4;
         {
             float* sp = slab_t + (long)sg.z * tile_floats;   // (a running pointer: one address register pair, 1 KiB steps)
@@ -733,48 +687,28 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
                         }
                     }
         }
-        if (!wg_arrive(bt, a, sg, smem, tid)) continue;
-        // ---- last arriver: sum the tile's slots in the fixed order z = 0 .. nsplit - 1 (bit-deterministic whichever workgroup
-        // this is), write the gradient in the parameter layout
-#pragma unroll
-        for (int j = 0; j < NACC; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        for (int zz = 0; zz < sg.nsplit; ++zz) {
-            const float* spz = slab_t + (long)zz * tile_floats;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int j = 0; j < KS; ++j)
-                    if (j < KSr) {
-                        f32x4 v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q] = *(const f32x4*)spz;
-                            spz += 256;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[nb * KS + j][4 * q] += v[q][0];
-                            acc[nb * KS + j][4 * q + 1] += v[q][1];
-                            acc[nb * KS + j][4 * q + 2] += v[q][2];
-                            acc[nb * KS + j][4 * q + 3] += v[q][3];
-                        }
-                        if constexpr (NACC > 5) __builtin_amdgcn_sched_barrier(0);   // (128 accumulator registers: do not hoist every tap's loads)
-                    }
-        }
-        store_final();
     }
 }
 
+// Register budget = co-residency: a weight-gradient workgroup sits on its CU for the whole launch (hundreds of microseconds, on a
+// low-priority stream) while the latency-critical dgrad / InstanceNorm chain of the same backward pass needs slots on the same CUs.
+// At 2 waves per SIMD x ~200 registers (what the compiler takes when nothing stops it) a CU has no room left for a second kernel's
+// waves and the chain's small launches queue behind the persistent workgroups (traced in round 4: a 25-us dgrad launch took 440 us).
+// The second __launch_bounds__ argument (minimum waves per SIMD) caps the allocation: 128 registers for the k = 5 whole-chunk
+// instance (no spill), 168 for the instances with up to 128 accumulator registers.
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3>
+struct WgWaves {
+    static constexpr int value = (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
+                                 : (((RT && BF == 0 && !X3) || (KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);
+};
 template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3 = false>
-__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch bt) {
+__global__ void __launch_bounds__(WG_THREADS, (WgWaves<KS, RT, NB, WCO, LIN, BF, X3>::value)) conv_wgrad_kernel(const WgradBatch bt) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
     // both stages start as zeros (the general staging path stores explicit zeros afterwards, the fast paths overwrite every position
     // they read; positions nobody reads may hold an earlier layer's finite data)
-    for (int e = tid; e < bt.lds_flag; e += WG_THREADS) smem[e] = 0.f;
+    for (int e = tid; e < bt.lds_floats; e += WG_THREADS) smem[e] = 0.f;
     if (wave8 >= 4) wg_producer<KS, RT, NB, WCO, LIN, BF>(bt, smem, tid, lane, wave8 & 3);
     else wg_consumer<KS, RT, NB, WCO, LIN, BF, X3>(bt, smem, tid, lane, wave8);
 }
@@ -782,8 +716,9 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgradBatch
 // --------------------------------------------------------------------------
 // tile shape per layer: returns (NB, WCO); tile = (32*WCO) co x (32*NB*(4/WCO)) ci
 static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
-    if (KS == 1 && Cin >= 96) {
-        *NB = 4; *WCO = 4;      // 128 x 128
+    if (KS == 1 && Cin >= 256) {
+        *NB = 4; *WCO = 4;      // 128 x 128 (the 1x1 over the 1104-channel concat buffer; a 128-channel 1x1 has too few such tiles: each
+                                // would be shared by ~100 workgroups and its reduce would be one long dependent chain)
     } else if (Cin % 64 == 0) {
         *NB = 1; *WCO = 2;      // 64 x 64
     } else {
@@ -803,7 +738,7 @@ static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO) {
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
-    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;   // + the last-arriver flag word
+    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;
 }
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;
@@ -841,15 +776,14 @@ void avc_wgrad_geometry(WgradArgs& a) {
 // Plans a batch: layers that share a kernel instance (and an operand dtype) form ONE launch (<= AVC_WGRAD_MAXL layers), a stream-K
 // split over `target_wgs` workgroups -- fewer when the launch is small: a workgroup walks at least 4 chunks, and never less than one
 // chunk of the most expensive layer (so that every workgroup between a tile's first and last owner owns a chunk of it).
-// Fills grp / grid / chunk_cost / cost_begin / cost_total / slots / ctr_base (relative to the batch's first counter) / slab_need /
-// dbslab_need of every layer; returns the number of arrival counters the batch needs.
-int avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
+// Fills grp / grid / chunk_cost / cost_begin / cost_total / slots / slab_need / dbslab_need / tile shape of every layer.
+void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
     if (target_wgs < 1) target_wgs = 256;
     for (int i = 0; i < n; ++i) {
         avc_wgrad_geometry(L[i]);
         L[i].grp = -1;
     }
-    int ngrp = 0, nctr = 0;
+    int ngrp = 0;
     for (int i = 0; i < n; ++i) {
         if (L[i].grp >= 0) continue;
         const WgradKey k = wgrad_key(L[i]);
@@ -871,26 +805,37 @@ int avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
         if (grid > target_wgs) grid = target_wgs;
         if (grid < 1) grid = 1;
         const int TCOv = 32 * k.WCO;
+        // no tile is shared by more than 64 workgroups (its reduce is a dependent chain of slot reads): a launch of very few tiles gets
+        // fewer workgroups instead
+        for (int pass = 0; pass < 4; ++pass) {
+            int worst = 1;
+            for (int j : mem) {
+                WgradArgs& a = L[j];
+                int slots = 1;
+                for (int t = 0; t < a.tiles; ++t) {
+                    const long cs = a.cost_begin + (long)t * a.total_chunks * a.chunk_cost;
+                    const long wf = (cs * grid) / C, wl = ((cs + (long)(a.total_chunks - 1) * a.chunk_cost) * grid) / C;
+                    slots = (int)(wl - wf + 1) > slots ? (int)(wl - wf + 1) : slots;
+                }
+                a.slots = slots;
+                worst = slots > worst ? slots : worst;
+            }
+            if (worst <= 64 || grid <= 1) break;
+            grid = grid * 62 / worst;
+            if (grid < 1) grid = 1;
+        }
         for (int j : mem) {
             WgradArgs& a = L[j];
             a.grid = (int)grid;
             a.cost_total = C;
-            a.ctr_base = nctr;
-            nctr += a.tiles;
-            int slots = 1;
-            for (int t = 0; t < a.tiles; ++t) {
-                const long cs = a.cost_begin + (long)t * a.total_chunks * a.chunk_cost;
-                const long wf = (cs * grid) / C, wl = ((cs + (long)(a.total_chunks - 1) * a.chunk_cost) * grid) / C;
-                slots = (int)(wl - wf + 1) > slots ? (int)(wl - wf + 1) : slots;
-            }
-            a.slots = slots;
+            a.tNB = k.NB;
+            a.tWCO = k.WCO;
             const long tile_floats = (long)4 * a.KS * k.NB * 1024;
-            a.slab_need = slots > 1 ? (long)a.tiles * slots * tile_floats : 0;
-            a.dbslab_need = slots > 1 ? (long)avc_cdiv(a.Cout, TCOv) * slots * TCOv : 0;
+            a.slab_need = a.slots > 1 ? (long)a.tiles * a.slots * tile_floats : 0;
+            a.dbslab_need = a.slots > 1 ? (long)avc_cdiv(a.Cout, TCOv) * a.slots * TCOv : 0;
         }
         ++ngrp;
     }
-    return nctr;
 }
 
 template <int KS, bool RT, int NB, int WCO>
@@ -916,17 +861,147 @@ static int launch_wgrad_t(const WgradBatch& bt, int grid_wgs, bool lin, int bf, 
     return (int)hipGetLastError();
 }
 
+// ---------------- the reduce launch of a batch: every tile that more than one workgroup worked on.  One 256-thread block per (tile,
+// accumulator, consumer wave) sums that wave's registers over the tile's slots in a fixed order and stores the gradient in the
+// parameter layout; one more block per co tile does the bias rows.
+struct WgReduceItem {
+    const float* slab;
+    const float* dbslab;
+    float* dw;
+    float* db;
+    long dw_src_stride, db_src_stride, cost_begin, cost_total;
+    int tiles, slots, total_chunks, chunk_cost, grid;
+    int KS, NB, WCO, Cin, Cout, rows_per_src;
+    int blk_begin, nblk_w;   // first block of this layer in the launch, its weight blocks (tiles x taps x ci blocks x 4 consumer waves)
+};
+struct WgReduceArgs {
+    int n, pad_;
+    WgReduceItem it[AVC_WGRAD_MAXL];
+};
+static __device__ __forceinline__ int wg_tile_nsplit(const WgReduceItem& a, int tile) {
+    const long cs = a.cost_begin + (long)tile * a.total_chunks * a.chunk_cost;
+    const long G = a.grid;
+    return (int)(((cs + (long)(a.total_chunks - 1) * a.chunk_cost) * G) / a.cost_total) - (int)((cs * G) / a.cost_total) + 1;
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduceArgs ra) {
+    int li_ = 0;
+    for (int i = 1; i < ra.n; ++i) li_ = ((int)blockIdx.x >= ra.it[i].blk_begin) ? i : li_;
+    const WgReduceItem& a = ra.it[li_];
+    const int blk = (int)blockIdx.x - a.blk_begin;
+    const int tid = threadIdx.x;
+    const int WCI = 4 / a.WCO, TCO = 32 * a.WCO, TCI = 32 * a.NB * WCI;
+    const int ci_tiles = avc_cdiv(a.Cin, TCI);
+    if (blk >= a.nblk_w) {   // bias rows of one co tile
+        const int cot = blk - a.nblk_w;
+        const int nsplit = wg_tile_nsplit(a, cot * ci_tiles);
+        if (nsplit == 1 || tid >= TCO) return;
+        const float* p = a.dbslab + ((long)cot * a.slots) * TCO + tid;
+        float v = 0.f;
+        for (int z = 0; z < nsplit; ++z) v += p[(long)z * TCO];
+        const int co = cot * TCO + tid;
+        if (co < a.Cout) a.db[(long)(co / a.rows_per_src) * a.db_src_stride + co % a.rows_per_src] = v;
+        return;
+    }
+    // weight block = (tile, accumulator, consumer wave): its 64 lanes' 16 registers each.  The block's four waves each sum a QUARTER of the
+    // tile's slots (contiguous z ranges, ascending), the quarters are combined through LDS as ((q0 + q1) + q2) + q3: a fixed order,
+    // and a tile that 200 workgroups share (a lone 1x1 layer's only tile) is four times fewer dependent round trips
+    const int nacc = a.KS * a.NB;
+    const int cw = blk & 3, ta = blk >> 2;           // consumer wave whose registers these are
+    const int tile = ta / nacc, ai = ta - tile * nacc;
+    const int nsplit = wg_tile_nsplit(a, tile);
+    if (nsplit == 1) return;   // the workgroup that walked the whole K range wrote the gradient itself
+    const int zq = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave_m = cw / WCI, wave_n = cw % WCI;
+    const int nb = ai / a.KS, j = ai - nb * a.KS;
+    const long tile_floats = (long)4 * nacc * 1024;
+    const float* p = a.slab + ((long)tile * a.slots) * tile_floats + (long)cw * (nacc * 1024) + (long)ai * 1024 + lane * 4;
+    const int per = (nsplit + 3) >> 2;
+    const int z_lo = zq * per, z_hi = (z_lo + per < nsplit) ? z_lo + per : nsplit;
+    f32x4 s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = z_lo; z0 < z_hi; z0 += 4) {   // four slots' loads (16 x 16 bytes per thread) in flight at a time
+        f32x4 v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = z0 + k < z_hi ? z0 + k : z_hi - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k][q] = *(const f32x4*)(p + (long)z * tile_floats + q * 256);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (z0 + k < z_hi) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += v[k][q];
+            }
+    }
+    __shared__ f32x4 part[3][4][64];
+    if (zq > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[zq - 1][q][lane] = s[q];
+    }
+    __syncthreads();
+    if (zq > 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if ((k + 1) * per < nsplit) {   // (an empty quarter holds zeros: skipping it or adding it is the same sum)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] += part[k][q][lane];
+        }
+    const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
+    const int ci = ci0 + (wave_n * a.NB + nb) * 32 + li;
+    if (ci >= a.Cin) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout) {
+            const int src = co / a.rows_per_src, rr = co - src * a.rows_per_src;
+            a.dw[(long)src * a.dw_src_stride + ((long)rr * a.Cin + ci) * a.KS + j] = s[r >> 2][r & 3];
+        }
+    }
+}
+
+int avc_launch_wgrad_reduce(const WgradArgs* L, int n, hipStream_t stream) {
+    for (int i0 = 0; i0 < n;) {
+        WgReduceArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        int blocks = 0;
+        double bytes = 0;
+        int i = i0;
+        for (; i < n && ra.n < AVC_WGRAD_MAXL; ++i) {
+            const WgradArgs& a = L[i];
+            if (a.slots <= 1) continue;   // every tile of this layer had one owner
+            WgReduceItem& t = ra.it[ra.n++];
+            t.slab = a.slab; t.dbslab = a.dbslab; t.dw = a.dw; t.db = a.dbslab ? a.db : nullptr;
+            t.dw_src_stride = a.dw_src_stride; t.db_src_stride = a.db_src_stride;
+            t.cost_begin = a.cost_begin; t.cost_total = a.cost_total;
+            t.tiles = a.tiles; t.slots = a.slots; t.total_chunks = a.total_chunks; t.chunk_cost = a.chunk_cost; t.grid = a.grid;
+            t.KS = a.KS; t.NB = a.tNB; t.WCO = a.tWCO; t.Cin = a.Cin; t.Cout = a.Cout; t.rows_per_src = a.rows_per_src;
+            t.blk_begin = blocks;
+            t.nblk_w = a.tiles * a.KS * a.tNB * 4;
+            blocks += t.nblk_w + (t.db ? avc_cdiv(a.Cout, 32 * a.tWCO) : 0);
+            bytes += 4.0 * ((double)a.slab_need + (double)a.Cout * a.Cin * a.KS);
+        }
+        i0 = i;
+        if (ra.n == 0) continue;
+        ProfScope ps(AVC_K_REDUCE, 0.0, bytes, stream);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ra);
+        int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // launches every layer of the batch (planned by avc_wgrad_plan_batch; slab / dbslab / dw / db assigned by the caller): one launch per
-// group.  `counters`: the batch's arrival counters, ZERO on entry (the caller's per-call memset; the kernels leave them zero).
+// group, then the batch's reduce launch.
 // ablation: timing-experiment bits of scripts/wgrad_ablate.py (results are wrong by construction when set)
-int avc_launch_wgrad_batch(const WgradArgs* L, int n, int* counters, hipStream_t stream, int ablation) {
+int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ablation) {
     int ngrp = 0;
     for (int i = 0; i < n; ++i) ngrp = L[i].grp + 1 > ngrp ? L[i].grp + 1 : ngrp;
     for (int grp = 0; grp < ngrp; ++grp) {
         WgradBatch bt;
         memset(&bt, 0, sizeof(bt));
         bt.dbg = ablation;
-        bt.counters = counters;
         size_t lds = 0;
         double flops = 0;
         WgradKey k;
@@ -951,7 +1026,7 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, int* counters, hipStream_t
         if (bf == 2)
             for (int j = 0; j < bt.nlayers; ++j)
                 if ((bt.L[j].Cin & 1) || (bt.L[j].Cout & 1) || bt.L[j].x.st != 1 || bt.L[j].dy.st != 1 || bt.L[j].x.ps != 1 || bt.L[j].dy.ps != 1) return -2;
-        bt.lds_flag = (int)(lds / 4) - 4;   // float index of the "I am the last arriver" word (behind the stages)
+        bt.lds_floats = (int)(lds / 4);
         int rc;
         if (k.KST == 1) {
             if (k.NB == 4) rc = launch_wgrad_t<1, false, 4, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
@@ -965,5 +1040,6 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, int* counters, hipStream_t
         }
         if (rc) return rc;
     }
-    return 0;
+    if (ablation & 8) return 0;   // (timing experiment: no slab stores -> nothing to reduce)
+    return avc_launch_wgrad_reduce(L, n, stream);
 }

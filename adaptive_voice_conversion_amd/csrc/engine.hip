@@ -119,12 +119,11 @@ struct avc_plan {
     mutable std::vector<hipEvent_t> wev;   // sized by the dry run of the backward pass (one per ordering edge)
     mutable hipEvent_t wjoin[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_pack[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_dense = nullptr;       // recorded behind the dense-stack backward kernel (the decoder's weight gradients wait for it)
     mutable hipEvent_t ev_dec_grads = nullptr;   // recorded when the decoder's parameter gradients are final
     mutable hipEvent_t ev_spk_grads = nullptr;   // ... the speaker encoder's
     mutable hipEvent_t ev_all_grads = nullptr;   // recorded at the end of avc_backward
     long dyarena = -1, dyarena_floats = 0;
-    long wg_ctr = -1;            // arrival counters of the stream-K weight-gradient launches (ints), zeroed at the top of every backward call
-    int wg_ctr_n = 0;
     int flags = 0;            // AVC_PLAN_*
     // ragged inference plans (avc_plan_create_ragged): per-level length / offset / tile tables
     struct RagLevel {
@@ -566,7 +565,7 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
     // ---- split-K slabs, dy arena and the event pool: sized with a dry run of the backward pass
     if (!infer) {
         p->slab = p->ws_top;
-        long need[4] = {0, 0, 0, 0};
+        long need[3] = {0, 0, 0};
         avc_backward_impl(p, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
                           nullptr, nullptr, true, need);
         p->slab_floats = need[0];
@@ -575,8 +574,6 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->dyarena_floats = need[1];
         p->ws_top += (need[1] + 63) / 64 * 64;
         p->nev_need = (int)need[2];
-        p->wg_ctr_n = (int)need[3];
-        p->wg_ctr = p->alloc(p->wg_ctr_n);
     }
     // helper streams / events belong to the plan from here on (created on the device that is current NOW;
     // a process without a GPU -- host-only plan queries -- simply gets a single-stream plan)
@@ -598,6 +595,7 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
     }
     for (hipEvent_t e : p->wev)
         if (e) hipEventDestroy(e);
+    if (p->ev_dense) hipEventDestroy(p->ev_dense);
     if (p->ev_dec_grads) hipEventDestroy(p->ev_dec_grads);
     if (p->ev_spk_grads) hipEventDestroy(p->ev_spk_grads);
     if (p->ev_all_grads) hipEventDestroy(p->ev_all_grads);
@@ -633,6 +631,7 @@ static void plan_init_streams(avc_plan* p) {
     }
     bool ok = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_dense, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_dec_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_spk_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
@@ -786,7 +785,6 @@ struct BwdCtx {
     hipStream_t s;
     bool dry;
     long slab_used;
-    int ctr_used;          // arrival counters handed out so far (ints at ws + p->wg_ctr)
     hipStream_t wstream;   // stream of the weight-gradient kernels of the current branch (== s when not overlapping)
     int nev;
     long dy_used;
@@ -798,6 +796,7 @@ struct BwdCtx {
         const LayerP* L;
     };
     std::vector<PendW> pend;
+    bool hold = false;     // keep recording (no automatic flush): the decoder's layers go out together, behind the dense-stack kernel
     long pend_units = 0;   // (co, ci) tiles x K-chunks of the pending layers
     // every gradient tensor a (possibly still running) wgrad kernel reads gets its own buffer
     float* fresh(long n) {
@@ -820,17 +819,15 @@ static hipStream_t wgrad_edge(BwdCtx& c) {
 }
 
 // Launch the pending weight gradients of this branch on the branch's wgrad stream (ordered behind everything queued on c.s so far:
-// their dy operands are final): one stream-K launch per kernel instance present (conv_wgrad.hip), each writing its finished
-// gradients -- weights and biases -- straight into the flat gradient buffer.  Runs beside the dgrad / InstanceNorm-backward chain.
+// their dy operands are final): one stream-K launch per kernel instance present (conv_wgrad.hip) + ONE reduce launch that sums the
+// partial tiles in a fixed order into the flat gradient buffer (weights and biases).  Runs beside the dgrad / InstanceNorm-backward chain.
 static int flush_wgrads(BwdCtx& c) {
     if (c.pend.empty()) return 0;
     hipStream_t ls = wgrad_edge(c);
     const int n = (int)c.pend.size();
     std::vector<WgradArgs> L((size_t)n);
     for (int i = 0; i < n; ++i) L[i] = c.pend[i].a;
-    const int nctr = avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
-    const int ctr0 = c.ctr_used;
-    c.ctr_used += nctr;
+    avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
     for (int i = 0; i < n; ++i) {
         WgradArgs& a = L[i];
         const long off = c.slab_used;
@@ -848,7 +845,7 @@ static int flush_wgrads(BwdCtx& c) {
     c.pend.clear();
     c.pend_units = 0;
     if (c.dry) return 0;
-    return avc_launch_wgrad_batch(L.data(), n, (int*)(c.ws + c.p->wg_ctr) + ctr0, ls, c.p->tun.wgrad_ablation);
+    return avc_launch_wgrad_batch(L.data(), n, ls, c.p->tun.wgrad_ablation);
 }
 
 // weight + bias gradient of layer L: x = forward input view, dy = output-gradient view (recorded; see flush_wgrads)
@@ -867,7 +864,7 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     c.pend_units += (long)a.tiles * a.total_chunks;
     c.pend.push_back(pw);
     // flush when the batch is worth a launch: enough work to give every CU a long K run, or enough layers
-    if ((int)c.pend.size() >= c.p->tun.wgrad_batch || c.pend_units >= c.p->tun.wgrad_batch_units) return flush_wgrads(c);
+    if (!c.hold && ((int)c.pend.size() >= c.p->tun.wgrad_batch || c.pend_units >= c.p->tun.wgrad_batch_units)) return flush_wgrads(c);
     return 0;
 }
 
@@ -1235,10 +1232,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                       long* slab_need) {
     BwdCtx c;
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
-    c.nev = 0; c.dy_used = 0; c.pend_units = 0; c.ctr_used = 0;
-    // arrival counters of the weight-gradient launches: zero before every call (a memset node; the kernels leave them zero, this covers
-    // a fresh workspace and an aborted call).  Every wgrad launch is ordered behind this point (wgrad_edge / the side-stream fork).
-    if (!dry && p->wg_ctr_n > 0) RUN((int)hipMemsetAsync(ws + p->wg_ctr, 0, (size_t)p->wg_ctr_n * sizeof(int), s));
+    c.nev = 0; c.dy_used = 0; c.pend_units = 0;
     const bool overlap = !dry && side_ready(p);
     c.wstream = overlap ? p->wstream[0] : s;
     const int B = p->B;
@@ -1346,6 +1340,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             }
         }
         // the weight gradients of the decoder (recorded; launched in batches on the wgrad stream, flush_wgrads)
+        c.hold = true;
         RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, Mr * To, To, 1, 1, B, To, To));
         for (int l = d.n - 1; l >= 0; --l) {
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
@@ -1369,17 +1364,15 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             w.B = 1; w.Cin = B; w.Cout = d.c.c_cond; w.Tin = La.Cout; w.Tout = La.Cout;
             w.KS = 1; w.padL = 0; w.stride = 1; w.bf16 = bh ? AVC_COMPUTE_BF16 : p->compute;   // (fp32-stored operands either way)
             w.rows_per_src = w.Cout;
-            const int nctr = avc_wgrad_plan_batch(&w, 1, 256);
+            avc_wgrad_plan_batch(&w, 1, 256);
             const long off = c.slab_used;
             c.slab_used += (w.slab_need + 63) / 64 * 64;
-            const int ctr0 = c.ctr_used;
-            c.ctr_used += nctr;
             if (!dry) {
                 w.slab = ws + p->slab + off;
                 w.dbslab = nullptr;
                 w.dw = ws + p->demb;   // demb: channel-major [c_cond][B]
                 w.db = nullptr;
-                RUN(avc_launch_wgrad_batch(&w, 1, (int*)(ws + p->wg_ctr) + ctr0, s, p->tun.wgrad_ablation));
+                RUN(avc_launch_wgrad_batch(&w, 1, s, p->tun.wgrad_ablation));
                 if (d_emb_up) RUN(avc_launch_add_transposed(ws + p->demb, d_emb_up, B, d.c.c_cond, s));
             }
         }
@@ -1389,10 +1382,9 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             RUN(avc_launch_latent_bwd(ws + p->muls, eps, ws + p->dz, d_muls_up, B, Czc, Tb, lk, ws + p->dmuls, s));
             if (bh) RUN(avc_launch_to_pairs(ws + p->dmuls, (long)2 * Czc * Tb, Tb, 1, B, 2 * Czc, Tb, ws + p->dmulsp, (long)Czc * Tb, Tb, s));
         }
-        RUN(flush_wgrads(c));  // decoder gradients are complete
-        // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
-        // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
-        if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
+        // (the decoder's weight gradients are launched from inside the speaker branch below, BEHIND the dense-stack backward kernel: that
+        // kernel opens the speaker branch's critical chain, needs a whole CU's LDS per workgroup and cannot share a CU with a persistent
+        // weight-gradient workgroup -- launched after 256 of those it waited for them: 413 instead of 66 us, traced in round 4)
     }
 
     // ---------------- content encoder (issued from inside the speaker branch below, right after that branch's first kernel: the host
@@ -1482,6 +1474,23 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
             }
             if (!dry) RUN(avc_launch_dense(da, 1, s));
+            {   // the decoder's pending weight gradients: their dy operands are final on the main stream; they go out now, ordered behind
+                // the dense-stack kernel as well
+                const hipStream_t ws0 = overlap ? p->wstream[0] : mainS;
+                if (overlap && sideS != mainS) {
+                    hipEventRecord(p->ev_dense, sideS);
+                    hipStreamWaitEvent(ws0, p->ev_dense, 0);
+                }
+                c.s = mainS;
+                c.wstream = ws0;
+                c.hold = false;
+                RUN(flush_wgrads(c));  // decoder gradients are complete
+                // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
+                // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
+                if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
+                c.s = sideS;
+                c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
+            }
             const LayerP* gl[AVC_DENSE_MAXL];
             const float* gx[AVC_DENSE_MAXL];
             const float* gdy[AVC_DENSE_MAXL];
@@ -1552,7 +1561,6 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         slab_need[0] = c.slab_used;
         slab_need[1] = c.dy_used;
         slab_need[2] = c.nev;
-        slab_need[3] = c.ctr_used;
     }
     return 0;
 }

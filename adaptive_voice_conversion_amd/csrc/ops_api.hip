@@ -181,7 +181,7 @@ int avc_conv1d_dgrad(const float* dy, long syb, long syc, int syt, int yps, int 
     return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
 }
 
-// workspace (floats) needed by avc_conv1d_wgrad: the partial-tile slots of the stream-K launch + its arrival counters
+// workspace (floats) needed by avc_conv1d_wgrad: the partial-tile slots of the stream-K launch
 static void op_wgrad_args(WgradArgs& a, int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride) {
     memset(&a, 0, sizeof(a));
     const avc_tuning& t = avc_op_tuning();
@@ -195,8 +195,8 @@ long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
     for (int stride = 1; stride <= 2; ++stride) {   // (the query does not know the stride: both geometries fit)
         WgradArgs a;
         op_wgrad_args(a, B, Cin, Cout, Tout * stride, Tout, KS, stride);
-        const int nctr = avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
-        const long n = a.slab_need + a.dbslab_need + 64 + nctr;
+        avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
+        const long n = a.slab_need + a.dbslab_need + 64;
         need = n > need ? n : need;
     }
     return need;
@@ -208,14 +208,11 @@ int avc_conv1d_wgrad(const float* x, long sxb, long sxc, int sxt, const float* d
     op_wgrad_args(a, B, Cin, Cout, Tin, Tout, KS, stride);
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
     a.dy.ptr = dy; a.dy.sb = syb; a.dy.sc = syc; a.dy.st = syt; a.dy.ps = yps;
-    const int nctr = avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
+    avc_wgrad_plan_batch(&a, 1, avc_op_tuning().wgrad_target_wgs);
     a.slab = ws;
     a.dbslab = db ? ws + a.slab_need : nullptr;
-    int* ctr = (int*)(ws + ((a.slab_need + a.dbslab_need + 63) / 64 * 64));
     a.dw = dW; a.db = db; a.rows_per_src = Cout;
-    int rc = (int)hipMemsetAsync(ctr, 0, (size_t)nctr * sizeof(int), (hipStream_t)stream);
-    if (rc) return rc;
-    return avc_launch_wgrad_batch(&a, 1, ctr, (hipStream_t)stream, avc_op_tuning().wgrad_ablation);
+    return avc_launch_wgrad_batch(&a, 1, (hipStream_t)stream, avc_op_tuning().wgrad_ablation);
 }
 
 // out = relu((y - mean_T)/sqrt(var_T + 1e-5) * gamma + beta) [+ resmap(res)]; saves mean/rstd

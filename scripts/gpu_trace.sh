@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-trace}; mkdir -p $OUT
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --presleep-ms ${2:-0} > /dev/null 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --no-config2 --presleep-ms ${2:-0} > /dev/null 2>&1)
 python $GRAFT_REPO_ROOT/scripts/trace_summary.py /tmp/rp/trace_kernel_trace.csv 40 > $OUT/trace_summary.txt
 python $GRAFT_REPO_ROOT/scripts/trace_timeline.py /tmp/rp/trace_kernel_trace.csv > $OUT/trace_timeline.txt
 head -8 $OUT/trace_timeline.txt
