@@ -45,6 +45,7 @@ class Tuning(ctypes.Structure):
 PLAN_X3 = 4
 PLAN_RAGGED = 8
 PLAN_BF16S = 16
+FWD_WEIGHTS_PACKED = 1   # avc_forward_ex: the caller packed the weight images behind its optimizer step (avc_plan_pack_weights)
 ERR_PAIR_SHAPE = -12   # avc_plan_create*: the shape is outside the bf16 pair kernels (odd channel count / frames not a multiple of 4)
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
@@ -99,6 +100,9 @@ def declare(lib):
     lib.avc_plan_latent_len.argtypes = [c_void_p]
     lib.avc_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
                                 c_void_p, c_void_p, c_void_p]
+    lib.avc_forward_ex.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
+                                   c_void_p, c_void_p, c_int, c_void_p]
+    lib.avc_plan_pack_weights.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.avc_loss.argtypes = [c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p, c_void_p]
     lib.avc_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]

@@ -45,6 +45,8 @@ int avc_launch_dsp_deemph(const float* x, long L, float a, float* out, hipStream
 int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop, int n_frames, float* out, hipStream_t s);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
+#define AVC_PACK_PIECE 2048   // image elements per block of the one-launch pack (8 per thread)
+int avc_launch_pack_table(const PackArgs* dev_tab, const void* dev_blk, int nblk, double bytes, const float* params, float* ws, hipStream_t stream);
 
 void avc_wgrad_geometry(WgradArgs& a);
 void avc_wgrad_plan_batch(WgradArgs* layers, int n, int target_wgs);

@@ -531,27 +531,65 @@ struct PackBatch {
     PackArgs a[AVC_PACK_BATCH];
 };
 
-static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride);
+static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride, long limit = (1L << 62));
 
 // several layers per launch: blockIdx.y selects the layer descriptor
 __global__ void __launch_bounds__(AVC_THREADS) pack_weight_batch_kernel(const PackBatch b) {
     pack_one(b.a[blockIdx.y], (long)blockIdx.x * AVC_THREADS + threadIdx.x, (long)gridDim.x * AVC_THREADS);
 }
 
+// ONE launch for every image of a plan: the descriptors live in a device table the plan owns (built once at plan creation); their
+// pointers are stored as BYTE OFFSETS from the caller's parameter buffer (sources) and workspace (destinations), rebased here.
+// Work is dealt in equal pieces: block b handles piece blk[b].y (AVC_PACK_PIECE consecutive image elements) of image blk[b].x --
+// the gather is latency-bound (one scattered 4-byte read per element), so it wants every CU full of waves whatever the image sizes are.
+__global__ void __launch_bounds__(AVC_THREADS) pack_weight_table_kernel(const PackArgs* tab, const int2* blk, const float* params, float* ws) {
+    const int2 bi = blk[blockIdx.x];
+    PackArgs p = tab[bi.x];
+    for (int k = 0; k < p.nsrc; ++k) p.src[k] = (const float*)((const char*)params + (size_t)p.src[k]);
+    p.dst = (float*)((char*)ws + (size_t)p.dst);
+    pack_one(p, (long)bi.y * AVC_PACK_PIECE + threadIdx.x, AVC_THREADS, (long)(bi.y + 1) * AVC_PACK_PIECE);
+}
+
 __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs p) {
     pack_one(p, (long)blockIdx.x * AVC_THREADS + threadIdx.x, (long)gridDim.x * AVC_THREADS);
 }
 
-static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride) {
+static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, long stride, long limit) {
     if (p.img == AVC_IMG_X3) {
-        avc_pack_x3_one(p, first, stride);
+        avc_pack_x3_one(p, first, stride, limit);
         return;
     }
     long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
+    total = total < limit ? total : limit;
     const int GR = p.CK >> 3;
+    // (the gather is one scattered read per element; with run-time integer divisions -- ~25 instructions each, five per element -- it
+    // was ALU-bound: exact float-reciprocal divisions instead, valid below 2^22 = every image of the model; larger ones take the slow path)
+    const bool fastok = total < (1L << 22);
+    const float inv_Mp = 1.0f / (float)p.Mp, inv_KS = 1.0f / (float)p.KS, inv_GR = 1.0f / (float)GR, inv_CK = 1.0f / (float)p.CK;
     for (long e = first; e < total; e += stride) {
         int m, r, j, chunk;
-        if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
+        if (fastok) {
+            if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
+                const int u = (int)(e & 3);
+                int rest = (int)(e >> 2);
+                int q = avc_fastdiv(rest, p.Mp, inv_Mp);
+                m = rest - q * p.Mp;
+                const int h = q & 1;
+                q >>= 1;
+                int q2 = avc_fastdiv(q, GR, inv_GR);
+                const int unit = q - q2 * GR;
+                chunk = avc_fastdiv(q2, p.KS, inv_KS);
+                j = q2 - chunk * p.KS;
+                r = 8 * unit + 2 * u + h;
+            } else {
+                int q = avc_fastdiv((int)e, p.Mp, inv_Mp);
+                m = (int)e - q * p.Mp;
+                int q2 = avc_fastdiv(q, p.CK, inv_CK);
+                r = q - q2 * p.CK;
+                chunk = avc_fastdiv(q2, p.KS, inv_KS);
+                j = q2 - chunk * p.KS;
+            }
+        } else if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
             const int u = (int)(e & 3);
             long rest = e >> 2;
             m = (int)(rest % p.Mp);
@@ -575,12 +613,12 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
         auto value = [&](int c) -> float {   // (m, reduction channel c, tap j)
             if (!p.dgrad) {
                 if (m < p.M && c < p.Cin) {
-                    int s = m / p.rows_per_src, mm = m - s * p.rows_per_src;
+                    int s = p.nsrc == 1 ? 0 : m / p.rows_per_src, mm = m - s * p.rows_per_src;
                     return p.src[s][((long)mm * p.Cin + c) * p.KS + j];
                 }
             } else {
                 if (m < p.M && c < p.Cout) {
-                    int s = c / p.rows_per_src, rr = c - s * p.rows_per_src;
+                    int s = p.nsrc == 1 ? 0 : c / p.rows_per_src, rr = c - s * p.rows_per_src;
                     return p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
                 }
             }
@@ -809,6 +847,12 @@ int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream) {
         ProfScope ps_(AVC_K_PACK, 0.0, (double)bytes, stream);
         hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(blocks, m), dim3(AVC_THREADS), 0, stream, b);
     }
+    return (int)hipGetLastError();
+}
+
+int avc_launch_pack_table(const PackArgs* dev_tab, const void* dev_blk, int nblk, double bytes, const float* params, float* ws, hipStream_t stream) {
+    ProfScope ps_(AVC_K_PACK, 0.0, bytes, stream);
+    hipLaunchKernelGGL(pack_weight_table_kernel, dim3(nblk), dim3(AVC_THREADS), 0, stream, dev_tab, (const int2*)dev_blk, params, ws);
     return (int)hipGetLastError();
 }
 

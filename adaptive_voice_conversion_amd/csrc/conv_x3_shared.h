@@ -37,9 +37,10 @@ static inline __host__ __device__ int x3_arows(int KS) { return KS * x3_kb(KS) *
 
 // weight image: W[Cout][Cin][KS] -> [chunk][tap][block][term][k-half][Mp][4 dwords], dword q = channels chunk*CK + 16 block + 8 h + 2q, +1
 //   fwd  : value(m, c, j) = W[m][c][j]          dgrad: value(m, c, j) = W[c][m][KS-1-j]   (transposed, tap-flipped)
-static __device__ __forceinline__ void avc_pack_x3_one(const PackArgs& p, long first, long stride) {
+static __device__ __forceinline__ void avc_pack_x3_one(const PackArgs& p, long first, long stride, long limit = (1L << 62)) {
     const int KB = x3_kb(p.KS);
-    const long total = (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
+    long total = (long)p.nchunk * x3_arows(p.KS) * p.Mp * 4;
+    total = total < limit ? total : limit;
     const float* w = p.src[0];
     const int Cred = p.dgrad ? p.Cout : p.Cin;
     unsigned* dst = (unsigned*)p.dst;

@@ -140,6 +140,13 @@ struct avc_plan {
     long enc_param_off = 0;   // first float of the content encoder's (the speaker encoder's are the head)
     // AVC_PLAN_BF16S: every [B, C, T] activation / activation gradient is a bf16 pair tensor (bf16_pairs.h) at the same workspace
     // offsets (half of each allocation is used); muls / dec / emb / cond and their gradients, statistics, slabs stay fp32
+    // every weight image of the plan as ONE launch (avc_plan_pack_weights / the head of avc_forward): descriptor table in device memory,
+    // pointers stored as byte offsets from the caller's parameter buffer / workspace.  Built at plan creation, owned by the plan.
+    mutable PackArgs* pack_tab_dev = nullptr;
+    mutable void* pack_blk_dev = nullptr;   // (image, piece) of every block of the launch
+    int pack_nblk = 0, pack_nblk_early = 0, pack_early_imgs = 0;   // blocks [0, pack_nblk_early) pack the images the step's first kernels read
+    double pack_tab_bytes = 0;
+    mutable bool pack_side_pending = false;   // the tail of the last pack ran on a helper stream: ev_pack[1] marks its end
     bool bh = false;
     long ddecp = -1, dmulsp = -1;   // pair copies of d(dec) and d(muls): the conv launches that consume them read pair operands
 
@@ -584,6 +591,8 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
 
 extern "C" void avc_plan_destroy(avc_plan* p) {
     if (!p) return;
+    if (p->pack_tab_dev) hipFree(p->pack_tab_dev);
+    if (p->pack_blk_dev) hipFree(p->pack_blk_dev);
     // every handle that exists, whatever state plan_init_streams ended in
     if (p->side) hipStreamDestroy(p->side);
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
@@ -618,7 +627,59 @@ extern "C" int avc_plan_set_compute_dtype(avc_plan* p, int dtype) {
 }
 extern "C" int avc_plan_compute_dtype(const avc_plan* p) { return p ? p->compute : -1; }
 
+static void pack_layer(const avc_plan* p, const LayerP& L, const float* params, float* ws, std::vector<PackArgs>& out);
+static void plan_init_pack_table(avc_plan* p) {
+    // descriptors against NULL bases: every pointer field then holds a byte offset
+    // The conv banks and in_convs open both encoder branches and run for ~1 ms: their images come first (a short launch on the caller's
+    // stream); everything else can be packed on a forward-idle helper stream UNDER those convolutions.
+    std::vector<char> early(p->layers.size(), 0);
+    if (!(p->flags & AVC_PLAN_RAGGED))
+        for (const EncNet* e : {&p->spk, &p->enc}) {
+            if (e->in_conv < 0) continue;
+            for (int g = 0; g < e->nb; ++g) early[e->bank[g]] = 1;
+            early[e->in_conv] = 1;
+        }
+    std::vector<PackArgs> all;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t i = 0; i < p->layers.size(); ++i)
+            if (p->layers[i].wpf >= 0 && (early[i] != 0) == (pass == 0)) pack_layer(p, p->layers[i], (const float*)nullptr, (float*)nullptr, all);
+        if (pass == 0) p->pack_early_imgs = (int)all.size();
+    }
+    if (all.empty()) return;
+    double bytes = 0;
+    std::vector<int> blk;   // (image, piece) pairs
+    for (size_t i = 0; i < all.size(); ++i) {
+        if ((int)i == p->pack_early_imgs) p->pack_nblk_early = (int)(blk.size() / 2);
+        const long t = avc_pack_total(all[i]);
+        bytes += 8.0 * t;
+        for (long q = 0; q * AVC_PACK_PIECE < t; ++q) {
+            blk.push_back((int)i);
+            blk.push_back((int)q);
+        }
+    }
+    if (p->pack_early_imgs >= (int)all.size()) p->pack_nblk_early = (int)(blk.size() / 2);
+    PackArgs* dev = nullptr;
+    void* dblk = nullptr;
+    if (hipMalloc((void**)&dev, all.size() * sizeof(PackArgs)) != hipSuccess || hipMalloc(&dblk, blk.size() * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();   // no device (host-only plan queries): forward packs with descriptor batches in kernel arguments instead
+        if (dev) hipFree(dev);
+        return;
+    }
+    if (hipMemcpy(dev, all.data(), all.size() * sizeof(PackArgs), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dblk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(dev);
+        hipFree(dblk);
+        return;
+    }
+    p->pack_tab_dev = dev;
+    p->pack_blk_dev = dblk;
+    p->pack_nblk = (int)(blk.size() / 2);
+    p->pack_tab_bytes = bytes;
+}
+
 static void plan_init_streams(avc_plan* p) {
+    plan_init_pack_table(p);
     p->side_state = -1;
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
@@ -978,35 +1039,46 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
     return 0;
 }
 
+static bool side_ready(const avc_plan* p);
+static int pack_all(const avc_plan* p, const float* params, float* ws, hipStream_t s) {
+    if (p->pack_tab_dev) {
+        const int ne = p->pack_nblk_early, nr = p->pack_nblk - ne;
+        const bool split = side_ready(p) && ne > 0 && nr > 0;   // (A/B on one box, round 4: 6.000 vs 6.009 ms/step without the split)
+        p->pack_side_pending = false;
+        if (!split) return avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, p->pack_nblk, p->pack_tab_bytes, params, ws, s);
+        const double be = p->pack_tab_bytes * ne / p->pack_nblk;
+        int rc = avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, ne, be, params, ws, s);
+        if (rc) return rc;
+        hipStream_t ps = p->wstream[0];
+        hipEventRecord(p->ev_pack[0], s);  // parameters are final (the optimizer ran on s)
+        hipStreamWaitEvent(ps, p->ev_pack[0], 0);
+        rc = avc_launch_pack_table(p->pack_tab_dev, (const int*)p->pack_blk_dev + 2 * ne, nr, p->pack_tab_bytes - be, params, ws, ps);
+        hipEventRecord(p->ev_pack[1], ps);
+        p->pack_side_pending = true;
+        return rc;
+    }
+    std::vector<PackArgs> all;
+    for (size_t i = 0; i < p->layers.size(); ++i)
+        if (p->layers[i].wpf >= 0) pack_layer(p, p->layers[i], params, ws, all);
+    return avc_launch_pack_batch(all.data(), (int)all.size(), s);
+}
+
+// Weights -> LDS-image order for every layer of the plan, ONE launch.  A training loop calls this right behind the optimizer step
+// (Solver.ae_step) and passes AVC_FWD_WEIGHTS_PACKED to the next avc_forward_ex: the step then opens with its first convolution.
+extern "C" int avc_plan_pack_weights(const avc_plan* p, const float* params, float* ws, void* stream) {
+    if (!p || !params || !ws) return fail(-1, "avc_plan_pack_weights: null argument");
+    RUN(pack_all(p, params, ws, (hipStream_t)stream));
+    return 0;
+}
+
 static int forward_impl(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
-                        const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s) {
+                        const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s, bool packed = false) {
     const int B = p->B;
     const bool bh = p->bh;
     const int NV = (int)p->tun.in_pairs_nv;
-    // 0. weights -> LDS-image order (they change every optimizer step)
-    // The conv banks and in_convs open both encoder branches and run for ~1 ms: only their images
-    // are packed up front; the rest is packed on a (forward-idle) wgrad stream under the bank convs.
-    bool pack_async = false;
-    {
-        std::vector<char> early(p->layers.size(), 0);
-        for (const EncNet* e : {&p->spk, &p->enc}) {
-            for (int g = 0; g < e->nb; ++g) early[e->bank[g]] = 1;
-            early[e->in_conv] = 1;
-        }
-        std::vector<PackArgs> first, rest;
-        for (size_t i = 0; i < p->layers.size(); ++i)
-            if (p->layers[i].wpf >= 0) pack_layer(p, p->layers[i], params, ws, early[i] ? first : rest);
-        RUN(avc_launch_pack_batch(first.data(), (int)first.size(), s));
-        pack_async = side_ready(p) && !rest.empty();
-        hipStream_t ps = s;
-        if (pack_async) {
-            ps = p->wstream[0];
-            hipEventRecord(p->ev_pack[0], s);  // parameters are final (the optimizer ran on s)
-            hipStreamWaitEvent(ps, p->ev_pack[0], 0);
-        }
-        if (!rest.empty()) RUN(avc_launch_pack_batch(rest.data(), (int)rest.size(), ps));
-        if (pack_async) hipEventRecord(p->ev_pack[1], ps);
-    }
+    // 0. weights -> LDS-image order (they change every optimizer step): one launch, unless the caller packed them behind its
+    // optimizer step already (AVC_FWD_WEIGHTS_PACKED)
+    if (!packed) RUN(pack_all(p, params, ws, s));
 
     const bool spk_only = (p->flags & AVC_PLAN_SPEAKER_ONLY) != 0;  // AE.get_speaker_embeddings (model.py:393-395)
     // first kernels of the content encoder (conv bank, in_conv, InstanceNorm) on the caller's stream
@@ -1039,7 +1111,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
-        if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
+        if (p->pack_side_pending) hipStreamWaitEvent(s, p->ev_pack[1], 0);   // the other layers' images (packed under the bank convs)
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
@@ -1085,7 +1157,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const int Cc = e.c.c_h;
         const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
         // (conv bank, in_conv and its InstanceNorm were issued by content_front(), above)
-        if (pack_async) hipStreamWaitEvent(s, p->ev_pack[1], 0);
+        if (p->pack_side_pending) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
@@ -1185,6 +1257,17 @@ extern "C" int avc_forward(const avc_plan* p, const float* params, const float* 
         x_cond = x; scb = sxb; scc = sxc; sct = sxt;
     }
     return forward_impl(p, params, x, sxb, sxc, sxt, x_cond, scb, scc, sct, eps, ws, (hipStream_t)stream);
+}
+
+extern "C" int avc_forward_ex(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                              const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, int flags, void* stream) {
+    if (!p || !params || !x || !ws) return fail(-1, "avc_forward_ex: null argument");
+    if (p->flags & AVC_PLAN_RAGGED) return fail(-8, "avc_forward_ex: ragged plans run through avc_forward_ragged");
+    if (flags & ~AVC_FWD_WEIGHTS_PACKED) return fail(-1, "avc_forward_ex: unknown flag");
+    if (!x_cond) {
+        x_cond = x; scb = sxb; scc = sxc; sct = sxt;
+    }
+    return forward_impl(p, params, x, sxb, sxc, sxt, x_cond, scb, scc, sct, eps, ws, (hipStream_t)stream, (flags & AVC_FWD_WEIGHTS_PACKED) != 0);
 }
 
 extern "C" int avc_loss(const avc_plan* p, const float* x, long sxb, long sxc, int sxt, float lambda_rec, float* ws,
@@ -1855,12 +1938,7 @@ extern "C" int avc_forward_ragged(const avc_plan* p, const float* params, const 
     // tables -> workspace (a few KB; stream-ordered in front of everything that reads them)
     RUN((int)hipMemcpyAsync(ws + p->rag_tab, p->rag_host.data(), p->rag_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     const int* tab = (const int*)(ws + p->rag_tab);
-    {   // weights -> LDS-image order
-        std::vector<PackArgs> all;
-        for (size_t i = 0; i < p->layers.size(); ++i)
-            if (p->layers[i].wpf >= 0) pack_layer(p, p->layers[i], params, ws, all);
-        RUN(avc_launch_pack_batch(all.data(), (int)all.size(), s));
-    }
+    RUN(pack_all(p, params, ws, s));   // weights -> LDS-image order (one launch)
     // A conv on packed activations: source rows of the sample's own length (x.sc = -1), output block of `cout` channels.
     auto conv = [&](float slope, const LayerP& L, const float* src, const avc_plan::RagLevel& sl, int cx, float* dst, const avc_plan::RagLevel& convl,
                     const avc_plan::RagLevel& outl, int cout, int act, int ops) {

@@ -251,11 +251,19 @@ class Plan:
         if rc != 0:
             raise RuntimeError(f"libavc: {self.lib.avc_last_error().decode()}")
 
-    def forward(self, params, x, x_cond, eps, ws):
+    def forward(self, params, x, x_cond, eps, ws, weights_packed=False):
+        """weights_packed: the weight images in ``ws`` are current (``pack_weights(params, ws)`` ran after the last change of ``params``):
+        the pass then opens with its first convolution instead of the pack launch."""
         xc = x if x_cond is None else x_cond
         with _on(ws):
-            self._chk(self.lib.avc_forward(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
-                                           xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(ws), _stream(ws)))
+            self._chk(self.lib.avc_forward_ex(self.h, _ptr(params), _ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(xc),
+                                              xc.stride(0), xc.stride(1), xc.stride(2), _ptr(eps), _ptr(ws),
+                                              _lib.FWD_WEIGHTS_PACKED if weights_packed else 0, _stream(ws)))
+
+    def pack_weights(self, params, ws):
+        """Every weight tensor -> the plan's LDS-image order, ONE launch (a training loop calls this right behind its optimizer step)."""
+        with _on(ws):
+            self._chk(self.lib.avc_plan_pack_weights(self.h, _ptr(params), _ptr(ws), _stream(ws)))
 
     def loss(self, x, lambda_rec, ws):
         with _on(ws):

@@ -231,6 +231,7 @@ class AE(nn.Module):
         self._gflat = None
         self._alias()
         # train: the regular batch + the short last batch of an epoch; inference / speaker: a few recent shapes
+        self._bump = 0
         self._plans = _PlanCache({"train": 2, "inference": 8, "speaker": 4})
         self._ragged = {}   # (lengths, device) -> (RaggedPlan, workspace), a few most recent
 
@@ -257,6 +258,15 @@ class AE(nn.Module):
 
     def flat_parameters(self):
         return self._flat
+
+    def weights_version(self):
+        """Changes whenever PyTorch saw an in-place write to the parameters (flat buffer or any parameter view): what
+        Solver.ae_step compares to decide whether the weight images it packed behind its last optimizer step are still current."""
+        return (self._flat._version, self._bump, sum(p._version for p in self.parameters()))
+
+    def weights_changed(self):
+        """Tell the engine that the parameters were modified behind PyTorch's back (in-place through `.data`, a foreign kernel)."""
+        self._bump += 1
 
     def flat_grads(self):
         if self._gflat is None or self._gflat.device != self._flat.device:

@@ -184,7 +184,13 @@ class Solver(object):
         if eps is None:
             eps = self._draw_eps(B, model._c_lat, plan.latent_len, x.device)  # model.py:383
         grads = model.flat_grads()
-        plan.forward(flat, x, None, eps, ws)
+        # the weight images in `ws` are current iff the last thing that touched the parameters was OUR optimizer step followed by
+        # pack_weights into this very workspace: torch's version counters (of the flat buffer and of every parameter view) see every
+        # other in-place change -- load_state_dict, a torch optimizer, user code.  (In-place edits through `.data` bypass the counters,
+        # as they bypass autograd's own checks: call AE.weights_changed() after those.)
+        pk = getattr(self, "_packed", None)
+        packed = pk is not None and pk[0] is plan and pk[1] is ws and pk[2] is flat and pk[3] == model.weights_version()
+        plan.forward(flat, x, None, eps, ws, weights_packed=packed)
         plan.loss(x, self.config["lambda"]["lambda_rec"], ws)
         plan.backward(flat, x, None, eps, grads, ws, lambda_kl=float(lambda_kl))
         prescale = 1.0
@@ -195,6 +201,8 @@ class Solver(object):
             self._allreduce_grads(d, plan, grads)
             prescale = 1.0 / d.get_world_size()
         gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)
+        plan.pack_weights(flat, ws)    # the next step opens with its first convolution (engine.Plan.forward, weights_packed)
+        self._packed = (plan, ws, flat, model.weights_version())
         losses = plan.view(ws, "losses", (2,))
         if not sync:
             return {"loss_rec": losses[0], "loss_kl": losses[1], "grad_norm": gnorm[0]}

@@ -181,6 +181,15 @@ int avc_plan_compute_dtype(const avc_plan* p);
  * Results are left in the workspace regions "muls", "emb", "dec". */
 int avc_forward(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
                 const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, void* stream);
+/* The forward pass opens by re-packing every weight tensor into the plan's LDS-image order (ONE launch; the parameters change with
+ * every optimizer step, solver.py:93).  A training loop moves that launch behind its optimizer step instead:
+ *     avc_clip_adam_step(...); avc_plan_pack_weights(plan, params, ws, stream);          // end of step n
+ *     avc_forward_ex(plan, params, ..., ws, AVC_FWD_WEIGHTS_PACKED, stream);             // step n + 1 opens with its first conv
+ * AVC_FWD_WEIGHTS_PACKED is a promise that `params` has not changed since the last avc_plan_pack_weights into THIS workspace. */
+#define AVC_FWD_WEIGHTS_PACKED 1
+int avc_plan_pack_weights(const avc_plan* p, const float* params, float* ws, void* stream);
+int avc_forward_ex(const avc_plan* p, const float* params, const float* x, long sxb, long sxc, int sxt,
+                   const float* x_cond, long scb, long scc, int sct, const float* eps, float* ws, int flags, void* stream);
 
 /* ---- ragged inference: B (source, target) pairs of DIFFERENT lengths in ONE launch set (the batched generalisation of
  * Inferencer.inference_one_utterance, inference.py:54-70; the reference converts one utterance per call).  Nothing is padded --

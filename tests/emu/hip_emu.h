@@ -38,6 +38,9 @@ static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyHostToDevice 1
 

@@ -327,3 +327,39 @@ def test_plan_evicted_under_a_pending_backward_is_closed_after_it():
     (out2[3].abs().mean()).backward()
     ae._plan(2, 48, 48, dev)                    # next cache access: the zombie is swept
     assert first.h is None and not ae._plans.zombies
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_weights_packed_behind_the_optimizer_step(kind, tmp_path):
+    """Solver.ae_step packs the weight images right behind its optimizer step (ONE launch) and opens the next step with
+    AVC_FWD_WEIGHTS_PACKED.  (1) the trajectory is bit-identical to steps that re-pack at the head of every forward; (2) any change
+    of the parameters the engine did not make itself (load_state_dict, in-place user code) invalidates the hint: the next step
+    re-packs and sees the new weights."""
+    lib, dev = backend(kind)
+    lib = lib if kind == "emu" else None
+    cfg = O.tiny_config()
+    sd = O.make_state_dict(cfg, 3)
+    x, eps = O.make_inputs(cfg, 2, 32, 3)
+    x, eps = x.to(dev), eps.to(dev)
+    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir=str(tmp_path / "log"))
+
+    def run(force_repack, poke):
+        s = Solver(cfg, args, lib=lib)
+        s.model.load_state_dict(sd)
+        out = []
+        for it in range(3):
+            if force_repack:
+                s._packed = None
+            if poke and it == 2:
+                with torch.no_grad():
+                    s.model.decoder.out_conv_layer.weight.mul_(0.5)     # in-place change behind the engine's back
+            out.append(s.ae_step(x, 1.0, eps=eps))
+        return out, {k: v.detach().cpu().clone() for k, v in s.model.state_dict().items()}
+
+    a, pa = run(False, False)
+    b, pb = run(True, False)
+    assert a == b
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    c, _ = run(False, True)
+    d, _ = run(True, True)
+    assert c[:2] == a[:2] and c[2] == d[2] and c[2]["loss_rec"] != a[2]["loss_rec"]
