@@ -33,10 +33,14 @@ def main():
     s = Solver(cfg, args)
     s.model.load_state_dict(sd)
     sl = slice(rank * per, (rank + 1) * per)
-    metas = [s.ae_step(x[sl].contiguous().to(dev), 1.0, eps=eps[sl].contiguous().to(dev)) for _ in range(steps)]
+    metas, grads1 = [], None
+    for it in range(steps):
+        metas.append(s.ae_step(x[sl].contiguous().to(dev), 1.0, eps=eps[sl].contiguous().to(dev)))
+        if it == 0:
+            grads1 = s.model.flat_grads().detach().cpu().clone()   # the all-reduced SUM of the ranks' gradients of step 1 (the 1 / W lives in the optimizer)
     e1 = s._draw_eps(2, 4, 4, dev).cpu()       # per-rank noise stream
     s.save_model()                              # rank 0 writes, everyone waits
-    torch.save({"params": s.model.flat_parameters().cpu(), "metas": metas, "eps_draw": e1,
+    torch.save({"params": s.model.flat_parameters().cpu(), "metas": metas, "eps_draw": e1, "grads_step1": grads1, "world": world,
                 "comm_stream": s._comm_stream is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 

@@ -37,8 +37,25 @@ def _single(B, steps):
     args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_log")
     s = Solver(cfg, args)
     s.model.load_state_dict(sd)
-    metas = [s.ae_step(x.to(dev), 1.0, eps=eps.to(dev)) for _ in range(steps)]
+    metas, grads1 = [], None
+    for it in range(steps):
+        metas.append(s.ae_step(x.to(dev), 1.0, eps=eps.to(dev)))
+        if it == 0:
+            grads1 = s.model.flat_grads().detach().cpu().clone()
+    _single.grads_step1 = grads1
+    _single.ranges = [s.model._plan(B, 128, 128, dev)[0].param_range(k) for k in (1, 3, 4)]   # _lib.GRADS_DECODER / GRADS_SPEAKER / GRADS_CONTENT
     return s.model.flat_parameters().cpu(), metas
+
+
+def _check_step1_gradients(r0):
+    """the looser two-step parameter bars below would let an ordering bug of the three-bucket all-reduce through.  Step 1
+    starts from identical parameters, so no activation can take another branch: the all-reduced gradient SUM / W must equal the
+    global-batch gradient up to fp32 summation order -- per bucket (decoder / speaker / content ranges), rel-L2 <= 2e-5."""
+    g_ranks = r0["grads_step1"].double() / r0["world"]
+    g_one = _single.grads_step1.double()
+    for (off, n) in _single.ranges:
+        d = (g_ranks[off:off + n] - g_one[off:off + n]).norm().item() / g_one[off:off + n].norm().item()
+        assert d <= 2e-5, ((off, n), d)
 
 
 @pytest.mark.gpu
@@ -48,6 +65,7 @@ def test_one_rank_nccl_group_runs_the_allreduce_branch(tmp_path):
     assert r0["comm_stream"], "the overlapped all-reduce branch did not run"
     params, metas = _single(4, 2)
     assert torch.equal(r0["params"], params)          # identity all-reduce, prescale 1: same bits
+    assert torch.equal(r0["grads_step1"], _single.grads_step1)
     assert r0["metas"][1]["grad_norm"] == metas[1]["grad_norm"]
     sd = torch.load(tmp_path / "ckpt.ckpt", map_location="cpu")   # atomic rank-0 checkpoint
     assert len(sd) == 166 and not list(tmp_path.glob("*.tmp.*"))
@@ -62,6 +80,7 @@ def test_two_rank_nccl_step_equals_global_batch_step(tmp_path):
     assert not torch.equal(r0["eps_draw"], r1["eps_draw"]), "ranks share one noise stream"
     params, metas = _single(8, 2)
     assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
+    _check_step1_gradients(r0)
     diff = (params - r0["params"]).abs()
     assert diff.max().item() < 4 * 5e-4 * 2                      # (see the gloo variant below: kink flips in step 2)
     assert (diff > 2e-6).float().mean().item() < 5e-2
@@ -81,6 +100,7 @@ def test_two_ranks_on_one_gpu_over_gloo_equal_the_global_batch_step(tmp_path):
     assert not torch.equal(r0["eps_draw"], r1["eps_draw"]), "ranks share one noise stream"
     params, metas = _single(8, 2)
     assert r0["metas"][0]["grad_norm"] == pytest.approx(metas[0]["grad_norm"], rel=1e-5)
+    _check_step1_gradients(r0)
     diff = (params - r0["params"]).abs()
     # Two steps from the same init: the shards are summed in another order than the global batch, so an activation that sits
     # on its kink can take the other branch in step 2 (tests/test_engine.py::branch_matched_oracle) -- that moves every element

@@ -423,3 +423,37 @@ def test_decoder_forward_as_two_half_batch_chains(kind, cfgname, B, T):
         res.append(grads.cpu().clone())
     torch.testing.assert_close(res[0], res[2], rtol=1e-5, atol=1e-6)
     assert ((res[1] - res[3]).norm() / res[1].norm()).item() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("part", ["decoder", "speaker"])
+def test_partial_gradient_events_order_a_consumer_stream(part):
+    """avc_plan_stream_wait_grads(AVC_GRADS_DECODER / AVC_GRADS_SPEAKER) lets a communication stream start on a bucket while
+    the rest of the backward pass still runs.  A copy of that bucket issued on such a stream right behind the wait must already hold the
+    FINAL gradients -- compared with the same range after a full device synchronisation (a too-early event would race with the
+    weight-gradient / reduce launches that write the range)."""
+    from adaptive_voice_conversion_amd import _lib
+    lib, dev = backend("gpu")
+    cfg = get_cfg("m80")
+    sd = O.make_state_dict(cfg, 7)
+    B, T = 32, 128
+    x, eps = O.make_inputs(cfg, B, T, 7)
+    plan = Plan(cfg, B, T, T, lib=None)
+    params = flat_params(plan, sd, dev)
+    ws = torch.zeros(plan.workspace_floats, device=dev)
+    xd, ed = x.to(dev), eps.to(dev)
+    kind = {"decoder": _lib.GRADS_DECODER, "speaker": _lib.GRADS_SPEAKER}[part]
+    off, n = plan.param_range(kind)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        grads = torch.full((plan.param_floats,), float("nan"), device=dev)
+        early = torch.full((n,), float("nan"), device=dev)
+        plan.forward(params, xd, None, ed, ws)
+        plan.loss(xd, cfg["lambda"]["lambda_rec"], ws)
+        plan.backward(params, xd, None, ed, grads, ws, lambda_kl=1.0)
+        assert plan.stream_wait_grads(kind, side)
+        with torch.cuda.stream(side):
+            early.copy_(grads[off:off + n], non_blocking=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(early).all()
+        assert torch.equal(early, grads[off:off + n])
