@@ -123,7 +123,8 @@ struct WgradArgs {
     int grid;         // workgroups of that launch
     int chunk_cost;   // cost units of one K-chunk of this layer (taps + a fixed part)
     int slots;        // slab slots per tile (>= the number of workgroups any tile of this layer is split over)
-    int tNB, tWCO;    // tile shape of the layer's kernel instance: (32 tWCO) co x (32 tNB 4 / tWCO) ci
+    int tNB, tWCO, tCW; // tile shape of the layer's kernel instance: tCW consumer waves, (32 tWCO) co x (32 tNB tCW / tWCO) ci
+    int cw8;          // (caller) 1: the k = 5 layers may take the eight-consumer-wave 128 x 64 tile (avc_tuning.wgrad_cw8)
     int rows_per_src; // (caller) stacked layers (heads, AdaIN affines): output rows per parameter tensor
     long cost_begin;  // cost units in front of this layer inside its launch
     long cost_total;  // ... of the whole launch

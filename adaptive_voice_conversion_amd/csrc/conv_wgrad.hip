@@ -29,7 +29,8 @@ static constexpr __host__ __device__ int wg_xrow_lin(int KS) {
     int r = (31 + KS + 3) / 4;       // 16-byte units covering XSEG = 31 + KS positions
     return 4 * (r | 1);              // KS = 1: 36, 2..5: 36, 6..8: 44
 }
-#define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue)
+#define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue); CW = 8 instances: 8 + 4 waves = 768 threads
+static constexpr __host__ __device__ int wg_threads(int CW) { return (CW + 4) * 64; }
 
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
@@ -114,9 +115,9 @@ struct WgSegIter {
 // BF == 2 (bf16 PAIR storage, bf16_pairs.h): x and dy are dword tensors [B][C/2][T].  The producers stage PAIR rows and the consumers
 // feed v_mfma_f32_32x32x16_bf16: a lane's 8 k-values are 8 consecutive columns of ITS channel, i.e. one half of 8 consecutive dwords of
 // its pair row, gathered with one v_perm_b32 per two columns.
-template <int KS, bool RT, int NB, int WCO, bool LIN, int BF>
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, int CW = 4>
 struct WgCfg {
-    static constexpr int WCI = 4 / WCO;            // waves along ci
+    static constexpr int WCI = CW / WCO;           // consumer waves along ci
     static constexpr int TCO = 32 * WCO;           // co rows per workgroup
     static constexpr int TCI = 32 * NB * WCI;      // ci rows per workgroup
     static constexpr int NACC = KS * NB;
@@ -132,13 +133,13 @@ struct WgCfg {
 
 // ---------------- producers: waves 4-7.  Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
 // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1 lands while chunk c multiplies.
-template <int KS, bool RT, int NB, int WCO, bool LIN, int BF>
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, int CW>
 static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
-    using C = WgCfg<KS, RT, NB, WCO, LIN, BF>;
+    using C = WgCfg<KS, RT, NB, WCO, LIN, BF, CW>;
     constexpr int TCO = C::TCO, TCI = C::TCI, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NPD = C::NPD, NPX = C::NPX, TPR = C::TPR, CPT = C::CPT;
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
-    const int ptid = tid & 255;   // thread index inside the role group
+    const int ptid = tid - CW * 64;   // thread index inside the producer group (0..255)
     unsigned dyo[NPD], xo[NPX];
     int xq[NPX];
     WgSegIter it(bt);
@@ -363,9 +364,9 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
 }
 
 // ---------------- consumers: waves 0-3 -- fragment reads, MFMAs, and at a segment's end the partial tile / the finished gradient
-template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3>
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
-    using C = WgCfg<KS, RT, NB, WCO, LIN, BF>;
+    using C = WgCfg<KS, RT, NB, WCO, LIN, BF, CW>;
     constexpr int WCI = C::WCI, TCO = C::TCO, TCI = C::TCI, NACC = C::NACC, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NBROW = C::NBROW;
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
@@ -385,7 +386,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
         const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;
         const float* dyT = smem;
         const float* xT = smem + 2 * DYSP;
-        const long tile_floats = (long)4 * KSr * NB * 1024;   // 4 consumer waves x (taps x blocks) accumulators x 16 registers x 64 lanes
+        const long tile_floats = (long)CW * KSr * NB * 1024;   // consumer waves x (taps x blocks) accumulators x 16 registers x 64 lanes
         const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
         const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
 #pragma unroll
@@ -696,30 +697,37 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
 // waves and the chain's small launches queue behind the persistent workgroups (traced in round 4: a 25-us dgrad launch took 440 us).
 // The second __launch_bounds__ argument (minimum waves per SIMD) caps the allocation: 128 registers for the k = 5 whole-chunk
 // instance (no spill), 168 for the instances with up to 128 accumulator registers.
-template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3>
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 struct WgWaves {
-    static constexpr int value = (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
+    static constexpr int value = CW == 8 ? 3   // 12 waves = 3 per SIMD: 168 registers
+                                 : (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
                                  : (((RT && BF == 0 && !X3) || (KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);
 };
-template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3 = false>
-__global__ void __launch_bounds__(WG_THREADS, (WgWaves<KS, RT, NB, WCO, LIN, BF, X3>::value)) conv_wgrad_kernel(const WgradBatch bt) {
+// CW = 8: eight consumer waves (two per SIMD) on a 128 co x 64 ci tile + the four producers.  Two MFMA waves per SIMD fill each
+// other's gaps (fragment-read latency behind every barrier), and the tile's DMA bytes per MFMA are 3/4 of the 64 x 64 tile's.
+template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3 = false, int CW = 4>
+__global__ void __launch_bounds__(wg_threads(CW), (WgWaves<KS, RT, NB, WCO, LIN, BF, X3, CW>::value)) conv_wgrad_kernel(const WgradBatch bt) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases must be provably wave-uniform
     // both stages start as zeros (the general staging path stores explicit zeros afterwards, the fast paths overwrite every position
     // they read; positions nobody reads may hold an earlier layer's finite data)
-    for (int e = tid; e < bt.lds_floats; e += WG_THREADS) smem[e] = 0.f;
-    if (wave8 >= 4) wg_producer<KS, RT, NB, WCO, LIN, BF>(bt, smem, tid, lane, wave8 & 3);
-    else wg_consumer<KS, RT, NB, WCO, LIN, BF, X3>(bt, smem, tid, lane, wave8);
+    for (int e = tid; e < bt.lds_floats; e += wg_threads(CW)) smem[e] = 0.f;
+    if (wave8 >= CW) wg_producer<KS, RT, NB, WCO, LIN, BF, CW>(bt, smem, tid, lane, wave8 - CW);
+    else wg_consumer<KS, RT, NB, WCO, LIN, BF, X3, CW>(bt, smem, tid, lane, wave8);
 }
 
 // --------------------------------------------------------------------------
 // tile shape per layer: returns (NB, WCO); tile = (32*WCO) co x (32*NB*(4/WCO)) ci
-static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
-    if (KS == 1 && Cin >= 256) {
+static void wgrad_shape(const WgradArgs& a, int* NB, int* WCO, int* CW) {
+    *CW = 4;
+    if (a.KS == 1 && a.Cin >= 256) {
         *NB = 4; *WCO = 4;      // 128 x 128 (the 1x1 over the 1104-channel concat buffer; a 128-channel 1x1 has too few such tiles: each
                                 // would be shared by ~100 workgroups and its reduce would be one long dependent chain)
-    } else if (Cin % 64 == 0) {
+    } else if (a.KS == 5 && a.Cin % 64 == 0 && a.Cout % 128 == 0 && a.cw8 && a.Tc == 32 && a.stride == 1 && a.bf16 != AVC_COMPUTE_BF16S &&
+               a.bf16 != AVC_COMPUTE_F32X3) {
+        *NB = 1; *WCO = 4; *CW = 8;   // 128 co x 64 ci, eight consumer waves (the model's k = 5 layers)
+    } else if (a.Cin % 64 == 0) {
         *NB = 1; *WCO = 2;      // 64 x 64
     } else {
         *NB = 1; *WCO = 4;      // 128 x 32: Cin = 80 wastes 17 % instead of 38 %
@@ -727,14 +735,14 @@ static void wgrad_shape(int Cin, int Cout, int KS, int* NB, int* WCO) {
 }
 
 // kernel instance a layer runs on; layers with equal keys share a launch.  KST: the tap count the instance is compiled for -- 1 and 5
-// (the model's own sizes on the 64 x 64 tile) have their own instances, every other case runs on the run-time-taps instance (KST = 8)
+// (the model's own sizes) have their own instances, every other case runs on the run-time-taps instance (KST = 8)
 struct WgradKey {
-    int KST, rt, NB, WCO, lin;
-    bool operator==(const WgradKey& o) const { return KST == o.KST && rt == o.rt && NB == o.NB && WCO == o.WCO && lin == o.lin; }
+    int KST, rt, NB, WCO, CW, lin;
+    bool operator==(const WgradKey& o) const { return KST == o.KST && rt == o.rt && NB == o.NB && WCO == o.WCO && CW == o.CW && lin == o.lin; }
 };
-static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO) {
+static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO, int CW) {
     const int half = a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1;   // pair rows
-    const int TCO = 32 * WCO / half, TCI = 32 * NB * (4 / WCO) / half;
+    const int TCO = 32 * WCO / half, TCI = 32 * NB * (CW / WCO) / half;
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
@@ -742,13 +750,17 @@ static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO) {
 }
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;
-    wgrad_shape(a.Cin, a.Cout, a.KS, &k.NB, &k.WCO);
-    if (a.KS == 1 && k.NB == 4 && wgrad_lds_bytes_for(a, 4, 4) > 158 * 1024) {  // LDS too small for the wide tile (many short samples)
+    wgrad_shape(a, &k.NB, &k.WCO, &k.CW);
+    if (a.KS == 1 && k.NB == 4 && wgrad_lds_bytes_for(a, 4, 4, 4) > 158 * 1024) {  // LDS too small for the wide tile (many short samples)
         k.NB = 1;
         k.WCO = 2;
     }
+    if (k.CW == 8 && wgrad_lds_bytes_for(a, k.NB, k.WCO, 8) > 158 * 1024) {
+        k.CW = 4;
+        k.WCO = 2;
+    }
     if (a.KS == 1) { k.KST = 1; k.rt = 0; }
-    else if (a.KS == 5 && k.WCO == 2) { k.KST = 5; k.rt = 0; }
+    else if (a.KS == 5 && (k.WCO == 2 || k.CW == 8)) { k.KST = 5; k.rt = 0; }
     else { k.KST = 8; k.rt = 1; }
     k.lin = (a.Tc == 32 && a.stride == 1) ? 1 : 0;
     return k;
@@ -770,7 +782,7 @@ void avc_wgrad_geometry(WgradArgs& a) {
         a.total_chunks = avc_cdiv(a.B, a.spc);
     }
     const WgradKey k = wgrad_key(a);
-    a.tiles = avc_cdiv(a.Cout, 32 * k.WCO) * avc_cdiv(a.Cin, 32 * k.NB * (4 / k.WCO));
+    a.tiles = avc_cdiv(a.Cout, 32 * k.WCO) * avc_cdiv(a.Cin, 32 * k.NB * (k.CW / k.WCO));
 }
 
 // Plans a batch: layers that share a kernel instance (and an operand dtype) form ONE launch (<= AVC_WGRAD_MAXL layers), a stream-K
@@ -830,12 +842,27 @@ void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
             a.cost_total = C;
             a.tNB = k.NB;
             a.tWCO = k.WCO;
-            const long tile_floats = (long)4 * a.KS * k.NB * 1024;
+            a.tCW = k.CW;
+            const long tile_floats = (long)k.CW * a.KS * k.NB * 1024;
             a.slab_need = a.slots > 1 ? (long)a.tiles * a.slots * tile_floats : 0;
             a.dbslab_need = a.slots > 1 ? (long)avc_cdiv(a.Cout, TCOv) * a.slots * TCOv : 0;
         }
         ++ngrp;
     }
+}
+
+template <int KS, bool RT, int NB, int WCO>
+static int launch_wgrad_t(const WgradBatch& bt, int grid_wgs, bool lin, int bf, bool x3, size_t lds, double flops, hipStream_t stream);
+
+// the eight-consumer-wave instances (fp32 / bf16-operand products of the k = 5 layers)
+static int launch_wgrad_cw8(const WgradBatch& bt, int grid_wgs, bool lin, int bf, size_t lds, double flops, hipStream_t stream) {
+    if (lds > 158 * 1024) return -3;
+    dim3 grid(grid_wgs), block(wg_threads(8));
+    ProfScope ps(AVC_K_CONV_WGRAD, flops, 0.0, stream);
+    if (!lin) return -1;   // (wgrad_shape: whole-chunk stride-1 layers only)
+    if (bf) hipLaunchKernelGGL((conv_wgrad_kernel<5, false, 1, 4, true, 1, false, 8>), grid, block, lds, stream, bt);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<5, false, 1, 4, true, 0, false, 8>), grid, block, lds, stream, bt);
+    return (int)hipGetLastError();
 }
 
 template <int KS, bool RT, int NB, int WCO>
@@ -871,7 +898,7 @@ struct WgReduceItem {
     float* db;
     long dw_src_stride, db_src_stride, cost_begin, cost_total;
     int tiles, slots, total_chunks, chunk_cost, grid;
-    int KS, NB, WCO, Cin, Cout, rows_per_src;
+    int KS, NB, WCO, CW, Cin, Cout, rows_per_src;
     int blk_begin, nblk_w;   // first block of this layer in the launch, its weight blocks (tiles x taps x ci blocks x 4 consumer waves)
 };
 struct WgReduceArgs {
@@ -889,7 +916,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduceArgs ra
     const WgReduceItem& a = ra.it[li_];
     const int blk = (int)blockIdx.x - a.blk_begin;
     const int tid = threadIdx.x;
-    const int WCI = 4 / a.WCO, TCO = 32 * a.WCO, TCI = 32 * a.NB * WCI;
+    const int WCI = a.CW / a.WCO, TCO = 32 * a.WCO, TCI = 32 * a.NB * WCI;
     const int ci_tiles = avc_cdiv(a.Cin, TCI);
     if (blk >= a.nblk_w) {   // bias rows of one co tile
         const int cot = blk - a.nblk_w;
@@ -906,14 +933,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduceArgs ra
     // tile's slots (contiguous z ranges, ascending), the quarters are combined through LDS as ((q0 + q1) + q2) + q3: a fixed order,
     // and a tile that 200 workgroups share (a lone 1x1 layer's only tile) is four times fewer dependent round trips
     const int nacc = a.KS * a.NB;
-    const int cw = blk & 3, ta = blk >> 2;           // consumer wave whose registers these are
+    const int ta = blk / a.CW, cw = blk - ta * a.CW;           // consumer wave whose registers these are
     const int tile = ta / nacc, ai = ta - tile * nacc;
     const int nsplit = wg_tile_nsplit(a, tile);
     if (nsplit == 1) return;   // the workgroup that walked the whole K range wrote the gradient itself
     const int zq = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave_m = cw / WCI, wave_n = cw % WCI;
     const int nb = ai / a.KS, j = ai - nb * a.KS;
-    const long tile_floats = (long)4 * nacc * 1024;
+    const long tile_floats = (long)a.CW * nacc * 1024;
     const float* p = a.slab + ((long)tile * a.slots) * tile_floats + (long)cw * (nacc * 1024) + (long)ai * 1024 + lane * 4;
     const int per = (nsplit + 3) >> 2;
     const int z_lo = zq * per, z_hi = (z_lo + per < nsplit) ? z_lo + per : nsplit;
@@ -976,9 +1003,9 @@ int avc_launch_wgrad_reduce(const WgradArgs* L, int n, hipStream_t stream) {
             t.dw_src_stride = a.dw_src_stride; t.db_src_stride = a.db_src_stride;
             t.cost_begin = a.cost_begin; t.cost_total = a.cost_total;
             t.tiles = a.tiles; t.slots = a.slots; t.total_chunks = a.total_chunks; t.chunk_cost = a.chunk_cost; t.grid = a.grid;
-            t.KS = a.KS; t.NB = a.tNB; t.WCO = a.tWCO; t.Cin = a.Cin; t.Cout = a.Cout; t.rows_per_src = a.rows_per_src;
+            t.KS = a.KS; t.NB = a.tNB; t.WCO = a.tWCO; t.CW = a.tCW; t.Cin = a.Cin; t.Cout = a.Cout; t.rows_per_src = a.rows_per_src;
             t.blk_begin = blocks;
-            t.nblk_w = a.tiles * a.KS * a.tNB * 4;
+            t.nblk_w = a.tiles * a.KS * a.tNB * a.tCW;
             blocks += t.nblk_w + (t.db ? avc_cdiv(a.Cout, 32 * a.tWCO) : 0);
             bytes += 4.0 * ((double)a.slab_need + (double)a.Cout * a.Cin * a.KS);
         }
@@ -1015,7 +1042,7 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ab
             if (bt.nlayers >= AVC_WGRAD_MAXL) return -1;
             if (a0.slots > 1 && (!a0.slab || (a0.db && !a0.dbslab))) return -1;
             bt.L[bt.nlayers++] = a0;
-            size_t l = wgrad_lds_bytes_for(a0, k.NB, k.WCO);
+            size_t l = wgrad_lds_bytes_for(a0, k.NB, k.WCO, k.CW);
             lds = l > lds ? l : lds;
             flops += 2.0 * a0.Cout * a0.Cin * a0.KS * (double)a0.B * a0.Tout;
         }
@@ -1032,6 +1059,8 @@ int avc_launch_wgrad_batch(const WgradArgs* L, int n, hipStream_t stream, int ab
             if (k.NB == 4) rc = launch_wgrad_t<1, false, 4, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
             else if (k.WCO == 4) rc = launch_wgrad_t<1, false, 1, 4>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
             else rc = launch_wgrad_t<1, false, 1, 2>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
+        } else if (k.KST == 5 && k.CW == 8) {
+            rc = launch_wgrad_cw8(bt, a0.grid, k.lin, bf, lds, flops, stream);
         } else if (k.KST == 5) {
             rc = launch_wgrad_t<5, false, 1, 2>(bt, a0.grid, k.lin, bf, x3, lds, flops, stream);
         } else {

@@ -920,6 +920,7 @@ static int wgrad_layer(BwdCtx& c, const LayerP& L, const float* x, long xsb, lon
     a.B = Bn; a.Cin = L.Cin; a.Cout = L.Cout; a.Tin = Tin; a.Tout = Tout;
     a.KS = L.KS; a.padL = L.KS / 2; a.stride = L.stride;
     a.bf16 = (L.bf16 == AVC_COMPUTE_F32 && c.p->tun.wgrad_x3) ? AVC_COMPUTE_F32X3 : L.bf16;
+    a.cw8 = c.p->tun.wgrad_cw8 ? 1 : 0;
     pw.L = &L;
     avc_wgrad_geometry(a);
     c.pend_units += (long)a.tiles * a.total_chunks;

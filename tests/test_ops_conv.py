@@ -239,6 +239,8 @@ WG = [
     (16, 8, 32, 8, 5, 1),
     (7, 16, 32, 16, 5, 1),       # ... B not a multiple of samples-per-chunk: generic path
     (4, 16, 32, 64, 5, 1),       # whole 32-column chunks of longer samples
+    (2, 64, 128, 64, 5, 1),      # 128 co x 64 ci tile, eight consumer waves (round 4)
+    (1, 128, 256, 96, 5, 1),     # ... several such tiles
     pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
     pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
     pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
@@ -453,11 +455,11 @@ def test_conv_x3_fwd_and_dgrad_are_fp32_accurate(kind, B, Cin, Cout, T, stride):
     torch.testing.assert_close(dx.cpu(), dx32, rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", [(4, 16, 32, 64, 5, 1), (6, 80, 32, 64, 7, 1), (8, 16, 32, 32, 5, 2), (3, 130, 40, 96, 1, 1)])
-def test_conv_wgrad_last_arriver_reduce_is_order_independent(B, Cin, Cout, T, KS, stride, monkeypatch):
-    """The stream-K launch hands partial tiles from workgroup to workgroup; the LAST workgroup to arrive at a tile sums the tile's slots
-    in the fixed order z = 0, 1, ... -- so the gradient must be bit-identical whichever workgroup that is.  The simulator runs the
-    workgroups in ascending, reversed and interleaved order (hardware promises none)."""
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride", [(4, 16, 32, 64, 5, 1), (6, 80, 32, 64, 7, 1), (8, 16, 32, 32, 5, 2), (3, 130, 40, 96, 1, 1), (4, 64, 128, 64, 5, 1)])
+def test_conv_wgrad_reduce_is_order_independent(B, Cin, Cout, T, KS, stride, monkeypatch):
+    """The stream-K launch leaves partial tiles in slots; the reduce launch sums every tile's slots in a FIXED order -- so the gradient
+    must be bit-identical whatever order the workgroups of either launch ran in.  The simulator runs them in ascending, reversed and
+    interleaved order (hardware promises none)."""
     lib, dev = backend("emu")
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, Cin, T, generator=g)
