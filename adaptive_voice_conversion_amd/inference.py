@@ -121,6 +121,8 @@ class Inferencer(object):
         would be batches of one).  ``ragged=False``: the round-2 path -- pairs with equal (T, T') share one uniform plan,
         different shapes go out on up to ``max_streams`` HIP streams.  Lengths are never padded: reflect padding and the
         InstanceNorm statistics depend on the true length, so padding would change the result.
+        Under ``compute_dtype: bf16`` the ragged path rounds the matrix-product operands to bf16 on fp32 storage ("bf16r"; the bf16
+        pair-STORAGE engine of ``AE.inference`` takes uniform shapes only) -- ``self.model.last_ragged_compute`` says which mode ran.
         Returns the converted mels ([T'',M] CPU tensors) in input order."""
         if ragged:
             with torch.no_grad():

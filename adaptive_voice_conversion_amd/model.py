@@ -233,7 +233,9 @@ class AE(nn.Module):
         # train: the regular batch + the short last batch of an epoch; inference / speaker: a few recent shapes
         self._bump = 0
         self._plans = _PlanCache({"train": 2, "inference": 8, "speaker": 4})
-        self._ragged = {}   # (lengths, device) -> (RaggedPlan, workspace), a few most recent
+        self._ragged = {}   # (lengths, device) -> (RaggedPlan, None), a few most recent
+        self._ragged_ws = None   # the one workspace they share
+        self.last_ragged_compute = None
 
     # ---- flat storage ------------------------------------------------------
     def _alias(self):
@@ -254,6 +256,7 @@ class AE(nn.Module):
         for plan, _ in getattr(self, "_ragged", {}).values():
             plan.close()
         self._ragged = {}
+        self._ragged_ws = None
         return self
 
     def flat_parameters(self):
@@ -354,17 +357,25 @@ class AE(nn.Module):
         key = (T, Tc, str(dev))
         hit = self._ragged.get(key)
         if hit is None:
+            # compute_dtype "bf16" -> "bf16r" here: the pair-STORAGE engine takes uniform shapes only; ragged plans round the operands of
+            # the matrix products to bf16 on fp32 storage (engine.RaggedPlan).  The mode that ran is reported in `last_ragged_compute`.
             plan = RaggedPlan(self.config, T, Tc, lib=self._lib, compute_dtype="bf16r" if str(self.compute_dtype).lower().startswith(("bf16", "bfloat16")) else "fp32", device=dev,
                               tuning=self._tuning)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")
-            hit = self._ragged[key] = (plan, torch.zeros(plan.workspace_floats, dtype=torch.float32, device=dev))
+            hit = self._ragged[key] = (plan, None)
             while len(self._ragged) > 4:
                 old = self._ragged.pop(next(iter(self._ragged)))
                 old[0].close()
         else:
             self._ragged[key] = self._ragged.pop(key)   # most recently used last
-        plan, ws = hit
+        plan = hit[0]
+        # ONE pooled workspace for all ragged plans (real traffic almost never repeats a tuple of lengths: a fresh multi-hundred-MB
+        # torch.zeros per call was most of the cold-path cost): every region a forward pass reads it has written before, in that pass
+        ws = self._ragged_ws
+        if ws is None or ws.device != dev or ws.numel() < plan.workspace_floats:
+            ws = self._ragged_ws = torch.zeros(int(plan.workspace_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+        self.last_ragged_compute = plan.compute_dtype
         x = torch.cat([self._prep(t).to(dev) for t in xs]).contiguous()
         xc = torch.cat([self._prep(t).to(dev) for t in x_conds]).contiguous()
         plan.forward(self._flat, x, xc, ws)
