@@ -696,12 +696,13 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
 // At 2 waves per SIMD x ~200 registers (what the compiler takes when nothing stops it) a CU has no room left for a second kernel's
 // waves and the chain's small launches queue behind the persistent workgroups (traced in round 4: a 25-us dgrad launch took 440 us).
 // The second __launch_bounds__ argument (minimum waves per SIMD) caps the allocation: 128 registers for the k = 5 whole-chunk
-// instance (no spill), 168 for the instances with up to 128 accumulator registers.
+// instance (no spill), 168 where that costs no spill in the loop; the bank instance (128 accumulator registers) keeps 256.
 template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 struct WgWaves {
     static constexpr int value = CW == 8 ? 3   // 12 waves = 3 per SIMD: 168 registers
                                  : (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
-                                 : (((RT && BF == 0 && !X3) || (KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);
+                                 : (((KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);   // (run-time-taps bank instance: 256 registers -- at 168 it spills
+                                                                                             // in the loop: 2.49 vs 2.42 ms class, A/B on one box)
 };
 // CW = 8: eight consumer waves (two per SIMD) on a 128 co x 64 ci tile + the four producers.  Two MFMA waves per SIMD fill each
 // other's gaps (fragment-read latency behind every barrier), and the tile's DMA bytes per MFMA are 3/4 of the 64 x 64 tile's.

@@ -893,8 +893,8 @@ def main():
                 gbs = bts / us / 1e3
                 tot_b = sum(p["bytes_per_launch"] * p["launches_per_step"] for p in ib)
                 tot_ms = sum(p["ms_per_step"] for p in ib)
-                tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
-                tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
+                tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1, 1>", B * C * 32)
+                tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1, 1>", B * C * 32)
                 have = bool(tf and tb and B == 256 and T == 128 and a.dtype != "bf16")
                 out["roofline_instnorm"] = {
                     "kernel": f"instnorm_fwd + instnorm_bwd (IN/AdaIN/ReLU) at the dominant shape [{B},{C},{T}]",
