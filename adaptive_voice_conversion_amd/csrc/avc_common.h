@@ -178,7 +178,6 @@ struct INFwdArgs {
     float slope;
     int planar;         // pair kernels (rowops_pairs.hip): y rows are natural bf16 rows (the output of a pixel-shuffling conv)
     int nv_hint;        // pair kernels: 16-byte vectors per lane (avc_tuning.in_pairs_nv)
-    int rpl_hint;       // rows per lane group (avc_tuning.in_rows_per_group; 0 = automatic)
 };
 
 // ragged InstanceNorm forward (ragged_rows.hip): packed [C][T_b] blocks, see ConvRag
@@ -214,7 +213,6 @@ struct INBwdArgs {
     float slope;
     int planar;       // pair kernels: y and dy rows are natural bf16 rows
     int nv_hint;
-    int rpl_hint;
 };
 
 struct AdamArgs {

@@ -139,7 +139,7 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
     constexpr int TCO = C::TCO, TCI = C::TCI, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NPD = C::NPD, NPX = C::NPX, TPR = C::TPR, CPT = C::CPT;
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
-    const int ptid = tid - CW * 64;   // thread index inside the producer group (0..255)
+    const int ptid = tid & 255;   // thread index inside the producer group (CW * 64 is a multiple of 256; the mask tells the compiler the range)
     unsigned dyo[NPD], xo[NPX];
     int xq[NPX];
     WgSegIter it(bt);
@@ -699,13 +699,17 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
 // instance (no spill), 168 where that costs no spill in the loop; the bank instance (128 accumulator registers) keeps 256.
 template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 struct WgWaves {
-    static constexpr int value = CW == 8 ? 3   // 12 waves = 3 per SIMD: 168 registers
+    static constexpr int value = CW == 8 ? 3   // 12 waves = 3 per SIMD: 168 registers (at 128: class 2.31 vs 2.21 ms, spills only in the cold store path)
                                  : (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
-                                 : (((KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);   // (run-time-taps bank instance: 256 registers -- at 168 it spills
-                                                                                             // in the loop: 2.49 vs 2.42 ms class, A/B on one box)
+                                 : (((KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);   // (run-time-taps bank instance: 256 registers -- at 168 it
+                                                                                             // spills in the loop; class and step equal within noise)
 };
-// CW = 8: eight consumer waves (two per SIMD) on a 128 co x 64 ci tile + the four producers.  Two MFMA waves per SIMD fill each
-// other's gaps (fragment-read latency behind every barrier), and the tile's DMA bytes per MFMA are 3/4 of the 64 x 64 tile's.
+// CW = 8 (opt-in, avc_tuning.wgrad_cw8): eight consumer waves (two per SIMD) on a 128 co x 64 ci tile + the four producers.  Two MFMA
+// waves per SIMD fill each other's gaps (fragment-read latency behind every barrier), and the tile's DMA bytes per MFMA are 3/4 of the
+// 64 x 64 tile's: the class drops 2.26 -> 2.21 ms per step, but the STEP rises 5.98 -> 6.03 ms (same box, round 4) -- a 768-thread
+// workgroup at 168 registers owns its CU, and the chain's small launches wait for one to leave.  Hence off by default.
+// NOTE the role-local indices below are MASKS (tid & 255, wave & 3), not differences: with `tid - CW * 64` the compiler loses the
+// value range and every instance's producer address arithmetic got 5-25 % slower (measured per instance, round 4).
 template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3 = false, int CW = 4>
 __global__ void __launch_bounds__(wg_threads(CW), (WgWaves<KS, RT, NB, WCO, LIN, BF, X3, CW>::value)) conv_wgrad_kernel(const WgradBatch bt) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -714,7 +718,7 @@ __global__ void __launch_bounds__(wg_threads(CW), (WgWaves<KS, RT, NB, WCO, LIN,
     // both stages start as zeros (the general staging path stores explicit zeros afterwards, the fast paths overwrite every position
     // they read; positions nobody reads may hold an earlier layer's finite data)
     for (int e = tid; e < bt.lds_floats; e += wg_threads(CW)) smem[e] = 0.f;
-    if (wave8 >= CW) wg_producer<KS, RT, NB, WCO, LIN, BF, CW>(bt, smem, tid, lane, wave8 - CW);
+    if (wave8 >= CW) wg_producer<KS, RT, NB, WCO, LIN, BF, CW>(bt, smem, tid, lane, wave8 & 3);
     else wg_consumer<KS, RT, NB, WCO, LIN, BF, X3, CW>(bt, smem, tid, lane, wave8);
 }
 

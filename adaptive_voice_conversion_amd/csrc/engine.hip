@@ -983,7 +983,7 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
     a.y = y; a.out = out; a.mean = stats + (long)b0 * C; a.rstd = stats + (long)Bfull * C + (long)b0 * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = planar; a.nv_hint = nv & 255; a.rpl_hint = nv >> 8;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = planar; a.nv_hint = nv;
     if (pairs) {
         a.R = Bn * (C / 2);
         return avc_launch_in_fwd_pairs(a, s);
@@ -997,7 +997,7 @@ static int in_bwd(float slope, const float* g, const float* y, const float* stat
     a.g = g; a.y = y; a.mean = stats; a.rstd = stats + (long)Bn * C;
     a.cond = cond; a.cond_sb = cond_sb; a.cond_off = cond_off;
     a.dy = dy; a.dcond = dcond; a.dcond_sb = cond_sb; a.dcond_off = cond_off;
-    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0; a.nv_hint = nv & 255; a.rpl_hint = nv >> 8;
+    a.R = Bn * C; a.C = C; a.T = T; a.relu = 1; a.slope = slope; a.planar = 0; a.nv_hint = nv;
     if (pairs) {
         a.R = Bn * (C / 2);
         return avc_launch_in_bwd_pairs(a, s);
@@ -1076,7 +1076,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
                         const float* xc, long scb, long scc, int sct, const float* eps, float* ws, hipStream_t s, bool packed = false) {
     const int B = p->B;
     const bool bh = p->bh;
-    const int NV = (int)p->tun.in_pairs_nv | ((int)p->tun.in_rows_per_group << 8);   // (vectors per lane | rows per lane group << 8)
+    const int NV = (int)p->tun.in_pairs_nv;
     // 0. weights -> LDS-image order (they change every optimizer step): one launch, unless the caller packed them behind its
     // optimizer step already (AVC_FWD_WEIGHTS_PACKED)
     if (!packed) RUN(pack_all(p, params, ws, s));
@@ -1321,7 +1321,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     c.wstream = overlap ? p->wstream[0] : s;
     const int B = p->B;
     const bool bh = p->bh;
-    const int NV = (int)p->tun.in_pairs_nv | ((int)p->tun.in_rows_per_group << 8);   // (vectors per lane | rows per lane group << 8)
+    const int NV = (int)p->tun.in_pairs_nv;
     float* gA = ws + p->gA;
     float* gB = ws + p->gB;
     float* gC = ws + p->gC;
@@ -1368,7 +1368,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 a.mean = ws + stoff + (long)b0 * Cc; a.rstd = ws + stoff + (long)B * Cc + (long)b0 * Cc;
                 a.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.cond_sb = csb; a.cond_off = coff;
                 a.dy = dy + off; a.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.dcond_sb = csb; a.dcond_off = coff;
-                a.R = Bn * Cc; a.C = Cc; a.T = T; a.relu = 1; a.slope = SL; a.planar = planar; a.nv_hint = (int)p->tun.in_pairs_nv; a.rpl_hint = (int)p->tun.in_rows_per_group;
+                a.R = Bn * Cc; a.C = Cc; a.T = T; a.relu = 1; a.slope = SL; a.planar = planar; a.nv_hint = (int)p->tun.in_pairs_nv;
                 if (bh) {
                     a.R = Bn * (Cc / 2);
                     return avc_launch_in_bwd_pairs(a, s);

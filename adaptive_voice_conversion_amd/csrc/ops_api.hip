@@ -30,8 +30,7 @@ static avc_tuning make_default_tuning() {
     t.kg_wgs = 256;
     t.bh_ck5 = 8;    // r3 (profiles/r03_bf16s_tune.log): 2.75-2.78 ms/step with 8, 2.83 with 16
     t.in_pairs_nv = 1;
-    t.in_rows_per_group = 0;
-    t.wgrad_cw8 = 1;
+    t.wgrad_cw8 = 0;
     return t;
 }
 const avc_tuning& avc_default_tuning() {
@@ -58,7 +57,7 @@ int avc_set_tuning(const char* name, int value) {
     AVC_TUNE_FIELD(single_stream) AVC_TUNE_FIELD(dec_split_min) AVC_TUNE_FIELD(conv_x3) AVC_TUNE_FIELD(wgrad_x3) AVC_TUNE_FIELD(dgrad_par)
     AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
     AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(side_prio) AVC_TUNE_FIELD(wgrad_batch_units)
-    AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(in_rows_per_group) AVC_TUNE_FIELD(wgrad_cw8)
+    AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(wgrad_cw8)
 #undef AVC_TUNE_FIELD
     if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }
     return -1;
@@ -227,7 +226,7 @@ int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, lon
     a.res = res; a.res_mode = res ? res_mode : 0; a.Tres = Tres;
     a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
-    a.planar = 0; a.nv_hint = 0; a.rpl_hint = (int)avc_op_tuning().in_rows_per_group;
+    a.planar = 0; a.nv_hint = 0;
     return avc_launch_in_fwd(a, (hipStream_t)stream);
 }
 
@@ -240,7 +239,7 @@ int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const fl
     a.dy = dy; a.dcond = dcond; a.dcond_sb = dcond_sb; a.dcond_off = dcond_off;
     a.R = B * C; a.C = C; a.T = T; a.relu = relu ? 1 : 0;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
-    a.planar = 0; a.nv_hint = 0; a.rpl_hint = (int)avc_op_tuning().in_rows_per_group;
+    a.planar = 0; a.nv_hint = 0;
     return avc_launch_in_bwd(a, (hipStream_t)stream);
 }
 
@@ -256,7 +255,6 @@ int avc_instnorm_fwd_pairs(const void* y, int B, int C, int T, const float* cond
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     a.planar = planar ? 1 : 0;
     a.nv_hint = (int)avc_op_tuning().in_pairs_nv;
-    a.rpl_hint = (int)avc_op_tuning().in_rows_per_group;
     return avc_launch_in_fwd_pairs(a, (hipStream_t)stream);
 }
 int avc_instnorm_bwd_pairs(const void* g, const void* y, const float* mean, const float* rstd, int B, int C, int T, const float* cond, long cond_sb,
@@ -269,7 +267,6 @@ int avc_instnorm_bwd_pairs(const void* g, const void* y, const float* mean, cons
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     a.planar = planar ? 1 : 0;
     a.nv_hint = (int)avc_op_tuning().in_pairs_nv;
-    a.rpl_hint = (int)avc_op_tuning().in_rows_per_group;
     return avc_launch_in_bwd_pairs(a, (hipStream_t)stream);
 }
 // fp32 [B, C, T] (explicit element strides) -> bf16 pairs [B][C/2][T]

@@ -56,91 +56,74 @@ static __device__ __forceinline__ float4 res4(const float* rrow, int mode, int t
     return r;
 }
 
-// RPL rows per lane group (opt-in experiment, avc_tuning.in_rows_per_group; default 1): every load of RPL consecutive rows goes out
-// before the first reduction -- 16 * RPL bytes in flight per lane, 1 / RPL as many wavefronts.  Per-row arithmetic and its order
-// are unchanged (bit-identical results, tested).  Measured slower than RPL = 1: see in_rpl().
-template <int LPR, int NV, int RPL>
+template <int LPR, int NV>
 __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_kernel(const INFwdArgs a) {
     constexpr int RPB = AVC_THREADS / LPR;
     const int tid = threadIdx.x;
-    const int row0 = (blockIdx.x * RPB + tid / LPR) * RPL;
+    const int row = blockIdx.x * RPB + tid / LPR;
     const int l = tid % LPR;
+    const bool rvalid = row < a.R;
+    const int rr = rvalid ? row : 0;
     const int n4 = a.T >> 2;
-    float4 v[RPL][NV], rv[RPL][NV];
-    float gamma[RPL], beta[RPL];
-    bool rvalid[RPL];
-    int rr[RPL];
+    const float* yrow = a.y + (long)rr * a.T;
+    float4 v[NV], rv[NV];
+    float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) {
-        rvalid[q] = row0 + q < a.R;
-        rr[q] = rvalid[q] ? row0 + q : 0;
-        const float* yrow = a.y + (long)rr[q] * a.T;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            v[q][k] = (i4 < n4) ? *(const float4*)(yrow + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        v[k] = (i4 < n4) ? *(const float4*)(yrow + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // every other load of the rows -- the AdaIN scale / shift and the residual -- goes out NOW, behind the rows themselves: written
-    // where they are used (after the two reductions) they are a second and a third dependent memory round trip of a 5-8 us kernel
-#pragma unroll
-    for (int q = 0; q < RPL; ++q) {
-        gamma[q] = 1.f;
-        beta[q] = 0.f;
-        const int b = rr[q] / a.C, c = rr[q] - b * a.C;
-        if (a.cond) {
-            const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
-            beta[q] = cr[c];          // first half = shift   (model.py:81)
-            gamma[q] = cr[a.C + c];   // second half = scale
-        }
-        const float* rrow = a.res ? a.res + (long)rr[q] * a.Tres : nullptr;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            rv[q][k] = (rrow && i4 < n4) ? res4(rrow, a.res_mode, 4 * i4, a.Tres) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    // every other load of the row -- the AdaIN scale / shift and the residual -- goes out NOW, behind the row itself: written where they
+    // are used (after the two reductions) they are a second and a third dependent memory round trip of a 5-8 us kernel
+    float gamma = 1.f, beta = 0.f;
+    const int b = rr / a.C, c = rr - b * a.C;
+    if (a.cond) {
+        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
+        beta = cr[c];          // first half = shift   (model.py:81)
+        gamma = cr[a.C + c];   // second half = scale
     }
+    const float* rrow = a.res ? a.res + (long)rr * a.Tres : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        rv[k] = (rrow && i4 < n4) ? res4(rrow, a.res_mode, 4 * i4, a.Tres) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     const float invT = 1.0f / (float)a.T;
+    const float mean = group_sum<LPR>(s) * invT;
+    float ss = 0.f;
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) s += (v[q][k].x + v[q][k].y) + (v[q][k].z + v[q][k].w);
-        const float mean = group_sum<LPR>(s) * invT;
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            if (i4 < n4) {
-                float dx = v[q][k].x - mean, dy = v[q][k].y - mean, dz = v[q][k].z - mean, dw = v[q][k].w - mean;
-                ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        if (i4 < n4) {
+            float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
-        const float var = group_sum<LPR>(ss) * invT;  // biased variance
-        const float rstd = 1.0f / sqrtf(var + AVC_IN_EPS);
-        if (!rvalid[q]) continue;
-        const int row = row0 + q;
-        if (l == 0) {
-            a.mean[row] = mean;
-            a.rstd[row] = rstd;
-        }
-        float* orow = a.out + (long)row * a.T;
+    }
+    const float var = group_sum<LPR>(ss) * invT;  // biased variance
+    const float rstd = 1.0f / sqrtf(var + AVC_IN_EPS);
+    if (rvalid && l == 0) {
+        a.mean[row] = mean;
+        a.rstd[row] = rstd;
+    }
+    if (!rvalid) return;
+    float* orow = a.out + (long)row * a.T;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            if (i4 < n4) {
-                float o[4] = {v[q][k].x, v[q][k].y, v[q][k].z, v[q][k].w};
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        if (i4 < n4) {
+            float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float w = in_preact(in_xhat(o[e], mean, rstd), gamma[q], beta[q]);
-                    o[e] = a.relu ? avc_act(w, a.slope) : w;
-                }
-                if (a.res) {
-                    const float4 r = rv[q][k];
-                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                }
-                *(float4*)(orow + 4 * i4) = make_float4(o[0], o[1], o[2], o[3]);
+            for (int e = 0; e < 4; ++e) {
+                float w = in_preact(in_xhat(o[e], mean, rstd), gamma, beta);
+                o[e] = a.relu ? avc_act(w, a.slope) : w;
             }
+            if (rrow) {
+                const float4 r = rv[k];
+                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+            }
+            *(float4*)(orow + 4 * i4) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -197,92 +180,72 @@ __global__ void __launch_bounds__(AVC_THREADS) instnorm_fwd_generic_kernel(const
 // backward:  g = dL/d(out);  out = relu(xh*gamma+beta) [+ res]
 //   gm = g * 1[xh*gamma+beta > 0];  dbeta = sum gm;  dgamma = sum gm*xh
 //   dy = rstd * (gm*gamma - mean_T(gm*gamma) - xh * mean_T(gm*gamma*xh))
-template <int LPR, int NV, int RPL>
+template <int LPR, int NV>
 __global__ void __launch_bounds__(AVC_THREADS) instnorm_bwd_kernel(const INBwdArgs a) {
     constexpr int RPB = AVC_THREADS / LPR;
     const int tid = threadIdx.x;
-    const int row0 = (blockIdx.x * RPB + tid / LPR) * RPL;
+    const int row = blockIdx.x * RPB + tid / LPR;
     const int l = tid % LPR;
+    const bool rvalid = row < a.R;
+    const int rr = rvalid ? row : 0;
     const int n4 = a.T >> 2;
-    float4 yv[RPL][NV], gv[RPL][NV];
-    float mean[RPL], rstd[RPL], gamma[RPL], beta[RPL];
-    bool rvalid[RPL];
-    int rr[RPL];
-    // all loads of all RPL rows first (see instnorm_fwd_kernel)
+    const float* yrow = a.y + (long)rr * a.T;
+    const float* grow = a.g + (long)rr * a.T;
+    const float mean = a.mean[rr], rstd = a.rstd[rr];
+    float gamma = 1.f, beta = 0.f;
+    const int b = rr / a.C, c = rr - b * a.C;
+    if (a.cond) {
+        const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
+        beta = cr[c];
+        gamma = cr[a.C + c];
+    }
+    float4 xh[NV], gm[NV];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) {
-        rvalid[q] = row0 + q < a.R;
-        rr[q] = rvalid[q] ? row0 + q : 0;
-        const float* yrow = a.y + (long)rr[q] * a.T;
-        const float* grow = a.g + (long)rr[q] * a.T;
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        if (i4 < n4) {
+            float4 yv = *(const float4*)(yrow + 4 * i4);
+            float4 gv = *(const float4*)(grow + 4 * i4);
+            float xx[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            const bool on = i4 < n4;
-            yv[q][k] = on ? *(const float4*)(yrow + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            gv[q][k] = on ? *(const float4*)(grow + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        mean[q] = a.mean[rr[q]];
-        rstd[q] = a.rstd[rr[q]];
-        gamma[q] = 1.f;
-        beta[q] = 0.f;
-        if (a.cond) {
-            const int b = rr[q] / a.C, c = rr[q] - b * a.C;
-            const float* cr = a.cond + (long)b * a.cond_sb + a.cond_off;
-            beta[q] = cr[c];
-            gamma[q] = cr[a.C + c];
+            for (int e = 0; e < 4; ++e) {
+                float h = in_xhat(xx[e], mean, rstd);
+                float w = in_preact(h, gamma, beta);
+                float gme = avc_act_grad(gg[e], !a.relu || w > 0.f, a.slope);
+                xx[e] = h;
+                gg[e] = gme;
+                s1 += gme;
+                s2 += gme * h;
+            }
+            xh[k] = make_float4(xx[0], xx[1], xx[2], xx[3]);
+            gm[k] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+        } else {
+            xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gm[k] = xh[k];
         }
     }
+    s1 = group_sum<LPR>(s1);  // dbeta
+    s2 = group_sum<LPR>(s2);  // dgamma
+    if (!rvalid) return;
+    if (a.dcond && l == 0) {
+        float* dc = a.dcond + (long)b * a.dcond_sb + a.dcond_off;
+        dc[c] = s1;
+        dc[a.C + c] = s2;
+    }
     const float invT = 1.0f / (float)a.T;
+    const float m1 = gamma * s1 * invT, m2 = gamma * s2 * invT;
+    float* drow = a.dy + (long)row * a.T;
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) {
-        float4 xh[NV], gm[NV];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            if (i4 < n4) {
-                float xx[4] = {yv[q][k].x, yv[q][k].y, yv[q][k].z, yv[q][k].w}, gg[4] = {gv[q][k].x, gv[q][k].y, gv[q][k].z, gv[q][k].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float h = in_xhat(xx[e], mean[q], rstd[q]);
-                    float w = in_preact(h, gamma[q], beta[q]);
-                    float gme = avc_act_grad(gg[e], !a.relu || w > 0.f, a.slope);
-                    xx[e] = h;
-                    gg[e] = gme;
-                    s1 += gme;
-                    s2 += gme * h;
-                }
-                xh[k] = make_float4(xx[0], xx[1], xx[2], xx[3]);
-                gm[k] = make_float4(gg[0], gg[1], gg[2], gg[3]);
-            } else {
-                xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                gm[k] = xh[k];
-            }
-        }
-        s1 = group_sum<LPR>(s1);  // dbeta
-        s2 = group_sum<LPR>(s2);  // dgamma
-        if (!rvalid[q]) continue;
-        const int row = row0 + q;
-        if (a.dcond && l == 0) {
-            const int b = row / a.C, c = row - b * a.C;
-            float* dc = a.dcond + (long)b * a.dcond_sb + a.dcond_off;
-            dc[c] = s1;
-            dc[a.C + c] = s2;
-        }
-        const float m1 = gamma[q] * s1 * invT, m2 = gamma[q] * s2 * invT;
-        float* drow = a.dy + (long)row * a.T;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            int i4 = k * LPR + l;
-            if (i4 < n4) {
-                float4 o;
-                o.x = rstd[q] * (gm[k].x * gamma[q] - m1 - xh[k].x * m2);
-                o.y = rstd[q] * (gm[k].y * gamma[q] - m1 - xh[k].y * m2);
-                o.z = rstd[q] * (gm[k].z * gamma[q] - m1 - xh[k].z * m2);
-                o.w = rstd[q] * (gm[k].w * gamma[q] - m1 - xh[k].w * m2);
-                *(float4*)(drow + 4 * i4) = o;
-            }
+    for (int k = 0; k < NV; ++k) {
+        int i4 = k * LPR + l;
+        if (i4 < n4) {
+            float4 o;
+            o.x = rstd * (gm[k].x * gamma - m1 - xh[k].x * m2);
+            o.y = rstd * (gm[k].y * gamma - m1 - xh[k].y * m2);
+            o.z = rstd * (gm[k].z * gamma - m1 - xh[k].z * m2);
+            o.w = rstd * (gm[k].w * gamma - m1 - xh[k].w * m2);
+            *(float4*)(drow + 4 * i4) = o;
         }
     }
 }
@@ -623,34 +586,15 @@ __global__ void __launch_bounds__(AVC_THREADS) clip_adam_kernel(const AdamArgs a
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
-// rows per lane group (RPL): `hint` (avc_tuning.in_rows_per_group: 2 | 4), else ONE.  Measured on MI355X (round 4,
-// profiles/r04_instnorm_rows_per_group.log): two / four rows per lane group are SLOWER at every shape of the step ([256,128,128]
-// forward 8.7 -> 10.7 -> 11.3 us, backward 12.6 -> 13.1 -> 13.6) and neutral at 1024-frame rows: these launches are a launch ramp
-// plus ~7 us of streaming; fewer, fatter wavefronts lengthen the ramp more than deeper per-lane queues shorten the stream.
-static int in_rpl(int hint, int R, int rpb, int NV) {
-    (void)R; (void)rpb;
-    if (NV > 1) return 1;
-    return (hint == 2 || hint == 4) ? hint : 1;
-}
 template <int LPR, int NV>
 static void launch_in_fwd(const INFwdArgs& a, hipStream_t s) {
-    const int rpb = AVC_THREADS / LPR;
-    const int rpl = in_rpl(a.rpl_hint, a.R, rpb, NV);
-    if constexpr (NV == 1) {
-        if (rpl == 4) { hipLaunchKernelGGL((instnorm_fwd_kernel<LPR, 1, 4>), dim3(avc_cdiv(a.R, rpb * 4)), dim3(AVC_THREADS), 0, s, a); return; }
-        if (rpl == 2) { hipLaunchKernelGGL((instnorm_fwd_kernel<LPR, 1, 2>), dim3(avc_cdiv(a.R, rpb * 2)), dim3(AVC_THREADS), 0, s, a); return; }
-    }
-    hipLaunchKernelGGL((instnorm_fwd_kernel<LPR, NV, 1>), dim3(avc_cdiv(a.R, rpb)), dim3(AVC_THREADS), 0, s, a);
+    int rpb = AVC_THREADS / LPR;
+    hipLaunchKernelGGL((instnorm_fwd_kernel<LPR, NV>), dim3(avc_cdiv(a.R, rpb)), dim3(AVC_THREADS), 0, s, a);
 }
 template <int LPR, int NV>
 static void launch_in_bwd(const INBwdArgs& a, hipStream_t s) {
-    const int rpb = AVC_THREADS / LPR;
-    const int rpl = in_rpl(a.rpl_hint, a.R, rpb, NV);
-    if constexpr (NV == 1) {
-        if (rpl == 4) { hipLaunchKernelGGL((instnorm_bwd_kernel<LPR, 1, 4>), dim3(avc_cdiv(a.R, rpb * 4)), dim3(AVC_THREADS), 0, s, a); return; }
-        if (rpl == 2) { hipLaunchKernelGGL((instnorm_bwd_kernel<LPR, 1, 2>), dim3(avc_cdiv(a.R, rpb * 2)), dim3(AVC_THREADS), 0, s, a); return; }
-    }
-    hipLaunchKernelGGL((instnorm_bwd_kernel<LPR, NV, 1>), dim3(avc_cdiv(a.R, rpb)), dim3(AVC_THREADS), 0, s, a);
+    int rpb = AVC_THREADS / LPR;
+    hipLaunchKernelGGL((instnorm_bwd_kernel<LPR, NV>), dim3(avc_cdiv(a.R, rpb)), dim3(AVC_THREADS), 0, s, a);
 }
 
 int avc_launch_in_fwd(const INFwdArgs& a, hipStream_t s) {

@@ -149,10 +149,10 @@ typedef struct avc_tuning {
     long conv_min_lds;      /* occupancy experiment: every conv_gemm launch asks for at least this many BYTES of LDS (0 = what the tiles need) */
     long in_pairs_nv;       /* bf16 pair InstanceNorm rows: 16-byte vectors per lane, 1 (default: one lane group spans the row) | 2 | 4 */
     long bh_ck5;            /* AVC_PLAN_BF16S plans: chunk depth (DWORD channels = bf16 channel pairs) of the k >= 4 convs: 8 (default) | 16 | 32 */
-    long in_rows_per_group; /* fp32 InstanceNorm rows a lane group handles with all their loads issued up front: 0 / 1 = one (default; two and four
-                             * measured slower on MI355X, profiles/r04_instnorm_rows_per_group.log) | 2 | 4 */
-    long wgrad_cw8;         /* 1 (default): the weight gradients of the k = 5 layers (Cin % 64 == 0, Cout % 128 == 0) run on 128 x 64 tiles with EIGHT
-                             * consumer waves (two MFMA waves per SIMD) + four producers; 0: 64 x 64 tiles, four consumers */
+    long wgrad_cw8;         /* 1: the weight gradients of the k = 5 layers (Cin % 64 == 0, Cout % 128 == 0) run on 128 x 64 tiles with EIGHT consumer
+                             * waves (two MFMA waves per SIMD) + four producers.  0 (default): 64 x 64 tiles, four consumers.  Measured on MI355X,
+                             * same box: the wgrad class is 2.21 vs 2.26 ms per step with it, the STEP 6.03 vs 5.98 ms (768 threads x 168 registers
+                             * leave the chain's kernels no room on a CU the persistent workgroup sits on) */
 } avc_tuning;
 void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"

@@ -239,8 +239,8 @@ WG = [
     (16, 8, 32, 8, 5, 1),
     (7, 16, 32, 16, 5, 1),       # ... B not a multiple of samples-per-chunk: generic path
     (4, 16, 32, 64, 5, 1),       # whole 32-column chunks of longer samples
-    (2, 64, 128, 64, 5, 1),      # 128 co x 64 ci tile, eight consumer waves (round 4)
-    (1, 128, 256, 96, 5, 1),     # ... several such tiles
+    (2, 64, 128, 64, 5, 1),
+    (1, 128, 256, 96, 5, 1),
     pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
     pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
     pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),
@@ -273,6 +273,22 @@ def test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride):
     scale = dw_ref.abs().max().item()
     torch.testing.assert_close(dW.cpu(), dw_ref, rtol=1e-4, atol=1e-5 * max(1.0, scale))
     torch.testing.assert_close(db.cpu(), db_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS", [(2, 64, 128, 64, 5), (1, 128, 256, 96, 5), (3, 64, 128, 40, 5),
+                                             pytest.param(16, 128, 128, 128, 5, marks=GPU), pytest.param(4, 128, 256, 1024, 5, marks=GPU)])
+def test_conv_wgrad_eight_consumer_waves(kind, B, Cin, Cout, T, KS):
+    """avc_set_tuning("wgrad_cw8", 1) (opt-in): the k = 5 layers with Cin % 64 == 0 and Cout % 128 == 0 run on 128 co x 64 ci tiles with
+    eight consumer waves + four producers (768 threads).  Same bar as the default 64 x 64 instance."""
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    assert lib.avc_set_tuning(b"wgrad_cw8", 1) == 0
+    try:
+        test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, 1)
+    finally:
+        lib.avc_set_tuning(b"wgrad_cw8", 0)
 
 
 @pytest.mark.parametrize("kind", KINDS)

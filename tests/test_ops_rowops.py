@@ -83,44 +83,6 @@ def test_instnorm_fwd_bwd(kind, B, C, T, affine, res_mode):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("B,C,T,affine,res_mode", [(3, 7, 16, True, 0), (2, 9, 64, True, 5), (5, 5, 128, False, 1), (3, 6, 32, True, 2),
-                                                   pytest.param(64, 128, 128, True, 1, marks=GPU), pytest.param(256, 128, 16, True, 0, marks=GPU)])
-def test_instnorm_rows_per_lane_group_is_bit_identical(kind, B, C, T, affine, res_mode):
-    """avc_tuning.in_rows_per_group: a lane group handles 1, 2 or 4 consecutive rows with every load issued up front (more bytes in flight
-    per lane at short rows).  The per-row arithmetic and its order do not change: forward, statistics, dy and d(cond) must be
-    bit-identical -- also when the row count is no multiple of the group size (the padded rows of the last group are not stored)."""
-    if kind == "emu" and B * C * T > 20000:
-        pytest.skip("gpu-sized")
-    lib, dev = backend(kind)
-    g = torch.Generator().manual_seed(T + B)
-    y = (torch.randn(B, C, T, generator=g) * 2 + 0.5).to(dev)
-    cond = torch.randn(B, 2 * C, generator=g).to(dev)
-    res = {0: None, 1: torch.randn(B, C, T, generator=g), 2: torch.randn(B, C, 2 * T, generator=g), 5: torch.randn(B, C, T // 2, generator=g)}[res_mode]
-    rd = res.to(dev) if res is not None else None
-    gout = torch.randn(B, C, T, generator=g).to(dev)
-    got = []
-    try:
-        for rpl in (1, 2, 4):
-            assert lib.avc_set_tuning(b"in_rows_per_group", rpl) == 0
-            out = torch.full((B, C, T), float("nan"), device=dev)
-            mean = torch.full((B * C,), float("nan"), device=dev)
-            rstd = torch.full((B * C,), float("nan"), device=dev)
-            assert lib.avc_instnorm_fwd(P(y), B, C, T, P(cond if affine else None), cond.stride(0), 0, 1, P(rd), res_mode,
-                                        res.shape[2] if res is not None else 0, P(out), P(mean), P(rstd), None) == 0
-            dy = torch.full((B, C, T), float("nan"), device=dev)
-            dcond = torch.zeros(B, 2 * C, device=dev)
-            assert lib.avc_instnorm_bwd(P(gout), P(y), P(mean), P(rstd), B, C, T, P(cond if affine else None), cond.stride(0), 0, 1, P(dy),
-                                        P(dcond if affine else None), dcond.stride(0), 0, None) == 0
-            got.append([t.cpu() for t in (out, mean, rstd, dy, dcond)])
-    finally:
-        lib.avc_set_tuning(b"in_rows_per_group", 0)
-    assert not any(torch.isnan(t).any() for t in got[0])
-    for other in got[1:]:
-        for a_, b_ in zip(got[0], other):
-            assert torch.equal(a_, b_)
-
-
-@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("amsgrad,wd,prescale,n", [(True, 1e-4, 1.0, 5000), (False, 0.0, 0.5, 5000),
                                                     pytest.param(True, 1e-4, 1.0, 4892880, marks=GPU)])
 def test_clip_adam_matches_torch(kind, amsgrad, wd, prescale, n):
