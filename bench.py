@@ -325,8 +325,33 @@ def pmc_class_traffic(cls):
     return (tot / launches, src) if launches else (None, None)
 
 
+def _cpu_busy(interval=0.3):
+    """Busy fraction of every logical CPU over `interval` seconds (/proc/stat deltas); {} where that file is not readable."""
+    def snap():
+        out = {}
+        try:
+            for line in open("/proc/stat"):
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = (sum(v), v[3] + v[4])   # (total, idle + iowait)
+        except (OSError, ValueError, IndexError):
+            return {}
+        return out
+    a = snap()
+    time.sleep(interval)
+    b = snap()
+    busy = {}
+    for c in a:
+        if c in b and b[c][0] > a[c][0]:
+            busy[c] = 1.0 - (b[c][1] - a[c][1]) / (b[c][0] - a[c][0])
+    return busy
+
+
 def _pick_cpus(n):
-    """n logical CPUs for a pinned CPU-baseline point: distinct physical cores of ONE NUMA node (node 0 first), in order."""
+    """n logical CPUs for a pinned CPU-baseline point: distinct physical cores of ONE NUMA node -- the node whose cores are idlest right
+    now (the GPU boxes are shared hosts: other tenants' jobs sit on some nodes and not on others, and that, not the pinning, was the
+    box-to-box spread of rounds 3-4: 429 vs 612 segments/s), and inside it the idlest cores first."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -347,23 +372,32 @@ def _pick_cpus(n):
                 nodes.append([c for c in parse(open(f"/sys/devices/system/node/{d}/cpulist").read()) if c in allowed])
     except OSError:
         pass
+    nodes = [x for x in nodes if x]
     if not nodes:
         nodes = [allowed]
-    pick = []
-    for cpus in nodes:          # fill one node; spill to the next only if it is too small
-        seen = set()
+    busy = _cpu_busy()
+
+    def cores_of(cpus):   # physical cores of a node: (busy of the core = max over its hardware threads, first logical CPU)
+        seen, out = {}, []
         for c in cpus:
             try:
-                sib = min(parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+                sibs = parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read())
             except OSError:
-                sib = c
-            if sib in seen:
+                sibs = [c]
+            key = min(sibs)
+            if key in seen:
                 continue
-            seen.add(sib)
-            pick.append(c)
-            if len(pick) == n:
-                return pick
-    return (pick + [c for c in allowed if c not in pick])[:n]
+            seen[key] = True
+            out.append((max(busy.get(x, 0.0) for x in sibs), c))
+        return out
+    per_node = [cores_of(cpus) for cpus in nodes]
+    # a node qualifies if it has n physical cores; the idlest n cores of each candidate decide
+    cand = [sorted(cs)[:n] for cs in per_node if len(cs) >= n]
+    if cand:
+        best = min(cand, key=lambda cs: sum(b for b, _ in cs))
+        return sorted(c for _, c in best)
+    pick = [c for cs in per_node for _, c in sorted(cs)]   # no node is large enough: idlest cores across nodes
+    return sorted((pick + [c for c in allowed if c not in pick])[:n])
 
 
 def cpu_baseline_worker(n_mels, T, point):
@@ -397,13 +431,17 @@ def cpu_baseline_worker(n_mels, T, point):
         torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=o["grad_norm"])
         opt.step()
 
-    step()  # warm-up
+    step()  # warm-up: allocator, oneDNN primitive caches, optimizer state
+    step()  # ... and one step on the warm state (the first timed step of round 4's runs was the lone outlier of every point)
     ts = []
     for _ in range(n_timed):
         t0 = time.perf_counter()
         step()
         ts.append(time.perf_counter() - t0)
+        srt = sorted(ts)
+        q25, q75 = srt[(len(srt) - 1) // 4], srt[(3 * (len(srt) - 1) + 3) // 4]
         print(json.dumps({"B": Bc, "threads": threads, "steps": len(ts), "median_step_s": statistics.median(ts), "min_step_s": min(ts), "max_step_s": max(ts),
+                          "q25_step_s": q25, "q75_step_s": q75,
                           "seg_per_s": Bc / statistics.median(ts), "host_cores": cores, "pinned_cpus": len(cpus) if cpus else 0}), flush=True)
 
 
@@ -413,7 +451,7 @@ def cpu_baseline(n_mels, T, budget_s=45.0):
     ``torch.optim.Adam(amsgrad, weight_decay)`` + ``clip_grad_norm_`` around it (solver.py:75-77, 81-97).  Every (batch, threads) point is
     its own child process PINNED to `threads` physical cores of one NUMA node (sched_setaffinity + OMP_PROC_BIND=close): unpinned, the same
     point moved by 2x between runs on a 256-core host (round 3).  The two points that won every sweep (B = 128 and 256 at 16 threads) run
-    first with 1 warm-up + 7 timed steps (median, min-max reported); the other (batch, threads) points follow with 3 steps each while the
+    first with 2 warm-ups + 7 timed steps (median, min-max reported); the other (batch, threads) points follow with 3 steps each while the
     HARD wall-clock budget lasts.  Best median segments/s among the points with >= 5 timed steps is the value."""
     import select
     import subprocess
@@ -469,11 +507,12 @@ def cpu_baseline(n_mels, T, budget_s=45.0):
     print(f"[bench] cpu_baseline: {len(pts)} points in {time.perf_counter() - t0:.1f}s, best {best}", file=sys.stderr, flush=True)
     return dict(value=best["seg_per_s"], unit="mel-segments/sec", cores=best["threads"], kind="port", host_cores=best["host_cores"],
                 spread={"min_seg_per_s": best["B"] / best["max_step_s"], "max_seg_per_s": best["B"] / best["min_step_s"],
-                        "rel": (best["max_step_s"] - best["min_step_s"]) / best["median_step_s"]},
+                        "rel": (best["max_step_s"] - best["min_step_s"]) / best["median_step_s"],
+                        "iqr_rel": (best["q75_step_s"] - best["q25_step_s"]) / best["median_step_s"]},
                 pinning=f"each point: own process, sched_setaffinity to {best['threads']} physical cores of one NUMA node, OMP_PROC_BIND=close",
                 sample=(f"oracle forward issuing the reference's ATen ops (F.pad reflect, conv1d, F.instance_norm, avg_pool1d(ceil), interpolate) + autograd backward + in-place torch.optim.Adam(amsgrad, L2) + clip_grad_norm_, {n_mels}x{T} segments, "
                         f"torch CPU fp32; (batch, threads) points under a {budget_s:.0f} s wall-clock budget: "
-                        f"{len(pts)} points finished (1 warm-up + median of the timed steps each); best = B {best['B']}, "
+                        f"{len(pts)} points finished (2 warm-ups + median of the timed steps each); best = B {best['B']}, "
                         f"{best['threads']} threads, median of {best['steps']} steps"),
                 points=[{"B": d["B"], "threads": d["threads"], "steps": d["steps"], "seg_per_s": round(d["seg_per_s"], 2),
                          "min_seg_per_s": round(d["B"] / d["max_step_s"], 2), "max_seg_per_s": round(d["B"] / d["min_step_s"], 2)}
@@ -869,7 +908,9 @@ def main():
         }
         if world == 1 and not a.no_profile:
             prof = profile_classes(solver, x, eps, steps=3)
-            dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"])
+            # the weight gradient's reduce launches belong to its class when classes are ranked (they carry no FLOPs of their own)
+            red_ms = prof.get("slab_reduce", {}).get("ms_per_step", 0.0)
+            dom = max((k for k in prof if prof[k]["tflops"]), key=lambda k: prof[k]["ms_per_step"] + (red_ms if k == "conv_wgrad" else 0.0))
             d = prof[dom]
             # f32x3: six 8-pass bf16 MFMAs per 16 reduction steps -> the matrix pipe's ceiling for these products is the bf16 peak / 6
             peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16r": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
@@ -881,6 +922,10 @@ def main():
                                                   "build (replayed, not a counter read of this run)") if tsrc else _PMC_NOTE[0],
                                "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
                                "ms_per_step": d["ms_per_step"],
+                               "with_reduce_launches": ({"ms_per_step": d["ms_per_step"] + red_ms,
+                                                         "tflops": d["tflops"] * d["ms_per_step"] / (d["ms_per_step"] + red_ms)} if dom == "conv_wgrad" else None),
+                               "mfma_classes": {k: {"tflops": prof[k]["tflops"], "frac": prof[k]["tflops"] / peak, "ms_per_step": prof[k]["ms_per_step"]}
+                                                for k in prof if prof[k]["tflops"]},
                                "whole_step": {"algorithmic_tflop_per_step": TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3,
                                               "tflops": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps)) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None,
                                               "frac": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps) / peak) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None}}
@@ -893,8 +938,8 @@ def main():
                 gbs = bts / us / 1e3
                 tot_b = sum(p["bytes_per_launch"] * p["launches_per_step"] for p in ib)
                 tot_ms = sum(p["ms_per_step"] for p in ib)
-                tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1, 1>", B * C * 32)
-                tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1, 1>", B * C * 32)
+                tf, s1 = pmc_traffic("instnorm_fwd_kernel<32, 1>", B * C * 32)
+                tb, s2 = pmc_traffic("instnorm_bwd_kernel<32, 1>", B * C * 32)
                 have = bool(tf and tb and B == 256 and T == 128 and a.dtype != "bf16")
                 out["roofline_instnorm"] = {
                     "kernel": f"instnorm_fwd + instnorm_bwd (IN/AdaIN/ReLU) at the dominant shape [{B},{C},{T}]",
