@@ -16,3 +16,7 @@ run "kg_wgs=512" "--tune kg_wgs=512"
 run "kg_wgs=128" "--tune kg_wgs=128"
 run "wgrad_batch=6" "--tune wgrad_batch=6"
 done 2>&1 | tee $OUT/sweep.log
+python bench.py --mode infer --batch 1 --frames 400 --steps 50 --warmup 10 > $OUT/infer_b1_t400.json 2>/dev/null; python -c "import json; d=json.loads(open('$OUT/infer_b1_t400.json').read().strip().splitlines()[-1]); print('infer B=1 T=400', round(d['ms_per_step'],4), 'ms')"
+python bench.py --mode infer --batch 1 --frames 400 --dtype bf16 --steps 50 --warmup 10 > $OUT/infer_b1_t400_bf16.json 2>/dev/null; python -c "import json; d=json.loads(open('$OUT/infer_b1_t400_bf16.json').read().strip().splitlines()[-1]); print('infer B=1 T=400 bf16', round(d['ms_per_step'],4), 'ms')"
+python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; python -c "
+import json; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline_instnorm']['traffic'], d['cpu_baseline']['value'], d['cpu_baseline']['spread'])"
