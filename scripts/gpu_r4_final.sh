@@ -1,4 +1,4 @@
-# round 4 final measurement set (one call): full GPU test suite, PMC fetch/write summary of THIS build, rocprofv3 kernel stats
+# round 4 final measurement set (one call; produced profiles/r04_bench.json (first version), r04_pmc_fetch_write_summary.json, r04_rocprof_kernel_stats*.csv, r04_train_*.json, r04_infer_*.json): full GPU test suite, PMC fetch/write summary of THIS build, rocprofv3 kernel stats
 # (multi- and single-stream), the default bench line and the other BASELINE configs
 OUT=gpurun_out/${1:-r4final}; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 1100 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log

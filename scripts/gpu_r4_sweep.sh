@@ -1,3 +1,4 @@
+# command that produced profiles/r04_tune_sweep.log, r04_infer_b1_t400.json and the last r04_bench.json
 # round 4: tuning sweep on the final build, every setting beside the default on ONE box (boxes differ by ~4 %), two rounds
 OUT=gpurun_out/${1:-r4sweep}; mkdir -p $OUT
 run() { python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-config2 --no-profile $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s step %.4f ms' % ('$1', d['ms_per_step']))"; }
