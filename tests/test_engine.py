@@ -92,14 +92,30 @@ CASES = [
     pytest.param("gpu", "tiny", 3, 24, True, marks=GPU),
     pytest.param("gpu", "m80", 4, 128, True, marks=GPU),
     pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
+    ("emu", "tiny8", 2, 32, False),                        # 8 blocks per encoder: the deepest plan
+    ("emu", "tiny8b", 2, 32, False),                       # ... with wgrad_batch = 64: every branch's weight gradients in ONE flush (up to 16 layers in a stream-K launch)
+    pytest.param("gpu", "tiny8", 3, 64, False, marks=GPU),
+    pytest.param("gpu", "tiny8b", 3, 64, False, marks=GPU),
     pytest.param("gpu", "m80", 3, 24, False, marks=GPU),   # T_l = 3 at the bottleneck
     pytest.param("gpu", "m80", 3, 40, False, marks=GPU),   # T_l = 5: odd rows, generic InstanceNorm path
     pytest.param("gpu", "m512", 2, 128, False, marks=GPU),
 ]
 
 
+def deep_tiny_config():
+    """The deepest network a plan takes (8 blocks per encoder = AVC_MAX_BLOCKS, 6 in the decoder: its 12 AdaIN affines are one stacked
+    operand): 16 k = 5 weight gradients per encoder branch and 12 held in the decoder -- with `wgrad_batch = 64` ("tiny8b") a branch's flush
+    is as many layers as a stream-K launch has descriptors for (AVC_WGRAD_MAXL = 16)."""
+    cfg = O.tiny_config(n_blocks=8)
+    for k in ("SpeakerEncoder", "ContentEncoder"):
+        cfg[k]["subsample"] = [1, 1, 1, 2, 1, 1, 1, 2]
+    cfg["Decoder"]["n_conv_blocks"] = 6
+    cfg["Decoder"]["upsample"] = [2, 1, 1, 2, 1, 1]
+    return cfg
+
+
 def get_cfg(name):
-    return {"tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny8": deep_tiny_config, "tiny8b": deep_tiny_config, "tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -112,7 +128,7 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     if transposed:
         xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
     x3 = cfgname.endswith("x3")            # opt-in split-bf16 products: conv kernel (2 = every layer of an eligible shape, whatever its size) + weight gradients
-    plan = Plan(cfg, B, T, lib=lib, tuning={"conv_x3": 2, "wgrad_x3": 1} if x3 else None)
+    plan = Plan(cfg, B, T, lib=lib, tuning={"conv_x3": 2, "wgrad_x3": 1} if x3 else ({"wgrad_batch": 64} if cfgname == "tiny8b" else None))
     assert plan.num_params == len(sd)
     if x3:   # the opt-in kernel brings its own weight images: the plan really switched
         assert plan.workspace_floats > Plan(cfg, B, T, lib=lib).workspace_floats
