@@ -14,6 +14,7 @@ struct Rec {
     int cls;
     double flops, bytes;
     hipEvent_t e0, e1;
+    hipStream_t s;
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -30,6 +31,7 @@ ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : activ
     hipEventCreate(&r.e0);
     hipEventCreate(&r.e1);
     hipEventRecord(r.e0, s);
+    r.s = s;
     g_recs.push_back(r);
 }
 ProfScope::~ProfScope() {
@@ -64,6 +66,32 @@ int avc_prof_end(double* ms, long* launches, double* flops, double* bytes) {
     }
     g_recs.clear();
     return 0;
+}
+// Diagnostic twin of avc_prof_end for a MULTI-stream step: every bracketed launch as (class, stream handle, start, end) in ms from the
+// first bracket's start -- a per-stream timeline taken with HIP events instead of a tracer (rocprofv3's kernel trace stretches the step
+// by ~10 %; the events cost ~2 us per launch).  Returns the number of records (at most `max` are written); ends the recording.
+int avc_prof_timeline(int* cls, long* stream, double* t0_ms, double* t1_ms, int max) {
+    g_on = false;
+    int n = 0;
+    for (auto& r : g_recs) hipEventSynchronize(r.e1);
+    for (auto& r : g_recs) {
+        if (n < max) {
+            float a = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, g_recs[0].e0, r.e0);
+            hipEventElapsedTime(&b, g_recs[0].e0, r.e1);
+            cls[n] = r.cls;
+            stream[n] = (long)(size_t)r.s;
+            t0_ms[n] = a;
+            t1_ms[n] = b;
+        }
+        ++n;
+    }
+    for (auto& r : g_recs) {
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    g_recs.clear();
+    return n;
 }
 const char* avc_prof_class_name(int i) {
     static const char* names[AVC_K_NCLASS] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "slab_reduce", "instnorm_fwd",

@@ -2,9 +2,10 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'pack_weight_batch' in r['Kernel_Name']]
-starts = idx[::8]
-step = rows[starts[-2]:starts[-1]]
+# one step = everything behind the optimizer kernel of the step before it, up to and including its own (the weight images of a step are
+# packed right behind the previous optimizer step since round 4)
+idx = [i for i, r in enumerate(rows) if 'clip_adam_kernel' in r['Kernel_Name']]
+step = rows[idx[-2] + 1:idx[-1] + 1]
 t0 = int(step[0]['Start_Timestamp'])
 streams = sorted(set(r['Stream_Id'] for r in step))
 ev = []
