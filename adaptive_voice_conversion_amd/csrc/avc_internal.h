@@ -87,6 +87,11 @@ int avc_backward_impl(const avc_plan*, const float*, const float*, long, long, i
 enum { AVC_K_CONV_FWD = 0, AVC_K_CONV_DGRAD, AVC_K_CONV_WGRAD, AVC_K_REDUCE, AVC_K_IN_FWD, AVC_K_IN_BWD, AVC_K_PACK,
        AVC_K_ADAM, AVC_K_MISC, AVC_K_NCLASS };
 bool avc_prof_on();
+// named points of a backward pass (prof.hip: avc_prof_marks_begin / _end): 0 backward starts, 1 dense-stack backward issued (side stream),
+// 2 the speaker branch's first chain kernel issued (side), 3 content branch chain done (main), 4 speaker branch chain done (side),
+// 5 decoder weight gradients done (wgrad stream 0), 6 everything joined (main)
+#define AVC_PROF_NMARK 8
+void avc_prof_mark(int id, hipStream_t s);
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
     ~ProfScope();

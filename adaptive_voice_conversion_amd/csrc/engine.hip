@@ -858,6 +858,8 @@ struct BwdCtx {
     };
     std::vector<PendW> pend;
     bool hold = false;     // keep recording (no automatic flush): the decoder's layers go out together, behind the dense-stack kernel
+    hipStream_t s_extra = nullptr;   // a second producer stream the next flush must also be ordered behind (the decoder's other half-batch chain)
+    int target_wgs = 0;              // workgroups per launch of the next flush (0 = avc_tuning.wgrad_batch_wgs)
     long pend_units = 0;   // (co, ci) tiles x K-chunks of the pending layers
     // every gradient tensor a (possibly still running) wgrad kernel reads gets its own buffer
     float* fresh(long n) {
@@ -870,25 +872,31 @@ struct BwdCtx {
 // One ordering edge "everything queued on c.s so far -> the branch's wgrad stream"; returns the stream
 // to launch on.  Edges are counted in the dry run too: that count sizes the plan's event pool, so the
 // index is always valid at run time.
-static hipStream_t wgrad_edge(BwdCtx& c) {
+static hipStream_t wgrad_edge(BwdCtx& c, bool two_producers = false) {
     const int i = c.nev++;
+    const int i2 = two_producers ? c.nev++ : -1;   // (counted in the dry run whether or not the second stream exists at run time)
     if (c.dry || c.wstream == c.s) return c.s;
     hipEvent_t e = c.p->wev[i];
     hipEventRecord(e, c.s);
     hipStreamWaitEvent(c.wstream, e, 0);
+    if (two_producers && c.s_extra && c.s_extra != c.s) {
+        hipEvent_t e2 = c.p->wev[i2];
+        hipEventRecord(e2, c.s_extra);
+        hipStreamWaitEvent(c.wstream, e2, 0);
+    }
     return c.wstream;
 }
 
 // Launch the pending weight gradients of this branch on the branch's wgrad stream (ordered behind everything queued on c.s so far:
 // their dy operands are final): one stream-K launch per kernel instance present (conv_wgrad.hip) + ONE reduce launch that sums the
 // partial tiles in a fixed order into the flat gradient buffer (weights and biases).  Runs beside the dgrad / InstanceNorm-backward chain.
-static int flush_wgrads(BwdCtx& c) {
+static int flush_wgrads(BwdCtx& c, bool two_producers = false) {
     if (c.pend.empty()) return 0;
-    hipStream_t ls = wgrad_edge(c);
+    hipStream_t ls = wgrad_edge(c, two_producers);
     const int n = (int)c.pend.size();
     std::vector<WgradArgs> L((size_t)n);
     for (int i = 0; i < n; ++i) L[i] = c.pend[i].a;
-    avc_wgrad_plan_batch(L.data(), n, c.p->tun.wgrad_batch_wgs);
+    avc_wgrad_plan_batch(L.data(), n, c.target_wgs > 0 ? c.target_wgs : c.p->tun.wgrad_batch_wgs);
     for (int i = 0; i < n; ++i) {
         WgradArgs& a = L[i];
         const long off = c.slab_used;
@@ -1316,6 +1324,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                       long* slab_need) {
     BwdCtx c;
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
+    if (!dry) avc_prof_mark(0, s);
     c.nev = 0; c.dy_used = 0; c.pend_units = 0;
     const bool overlap = !dry && side_ready(p);
     c.wstream = overlap ? p->wstream[0] : s;
@@ -1408,31 +1417,50 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             float* t = st.gA; st.gA = st.gC; st.gC = t;
             return 0;
         };
-        if (!dry) {
+        // The weight gradient of a layer is RECORDED right behind the phase that produces its dy.  By default all of them are held and go
+        // out behind the dense-stack backward kernel (below).  avc_tuning.dec_wgrad_flush = N > 0: every N recorded layers go out at once,
+        // on the wgrad stream, as launches of only dec_wgrad_wgs persistent workgroups -- the decoder's backward chain is latency-bound
+        // and leaves most CUs idle; a launch that occupies only part of the chip is filler for exactly that phase.
+        c.hold = true;
+        const int early = p->tun.dec_wgrad_flush;
+        auto rec_phase = [&](int ph) -> int {   // (the order of the records is the order of round 3: out_conv, blocks n-1 .. 0 (second, first conv), in_conv)
+            if (ph == 0) return wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, Mr * To, To, 1, 1, B, To, To);
+            if (ph == 2 * d.n + 1) return wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dy0, (long)C * Tb, Tb, 1, 1, B, Tb, Tb);
+            const int l = d.n - 1 - (ph - 1) / 2;
+            const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
+            if ((ph - 1) % 2 == 0) {
+                if (bh) return wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, Ti, 1, 1, B, Ti, Ti);
+                return wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, T2, up, up, B, Ti, Ti);
+            }
+            return wgrad_layer(c, p->layers[d.c1[l]], ws + d.out[l], (long)C * Ti, Ti, 1, dy1[l], (long)C * Ti, Ti, 1, 1, B, Ti, Ti);
+        };
+        {
             const int nph = 2 * d.n + 2;
             ChainSt st0 = {ws + p->gA, ws + p->gB, ws + p->gC}, st1 = st0;
-            if (B >= p->tun.dec_split_min && side_ready(p)) {
-                const int Bh = B / 2;
-                const hipStream_t s2 = fork_side(p, s);
-                for (int ph = 0; ph < nph; ++ph) {   // issued in turn (see the forward pass)
-                    RUN(chain_phase(st0, 0, Bh, s, ph));
-                    RUN(chain_phase(st1, Bh, B - Bh, s2, ph));
+            const bool split = !dry && B >= p->tun.dec_split_min && side_ready(p);
+            const int Bh = B / 2;
+            const hipStream_t s2 = split ? fork_side(p, s) : s;
+            for (int ph = 0; ph < nph; ++ph) {   // the two half-batch chains are issued in turn (see the forward pass)
+                if (!dry) {
+                    if (split) {
+                        RUN(chain_phase(st0, 0, Bh, s, ph));
+                        RUN(chain_phase(st1, Bh, B - Bh, s2, ph));
+                    } else {
+                        RUN(chain_phase(st0, 0, B, s, ph));
+                    }
                 }
-                join_side(p, s, s2);
-            } else {
-                for (int ph = 0; ph < nph; ++ph) RUN(chain_phase(st0, 0, B, s, ph));
+                // phase ph consumed (ph = 0: d(dec)) or produced (its InstanceNorm backward) the dy of this layer -- on BOTH chains' streams
+                RUN(rec_phase(ph));
+                if (early > 0 && (int)c.pend.size() >= early && ph + 1 < nph) {
+                    c.s_extra = s2;
+                    c.target_wgs = (int)p->tun.dec_wgrad_wgs;
+                    RUN(flush_wgrads(c, true));
+                    c.s_extra = nullptr;
+                    c.target_wgs = 0;
+                }
             }
+            if (split) join_side(p, s, s2);
         }
-        // the weight gradients of the decoder (recorded; launched in batches on the wgrad stream, flush_wgrads)
-        c.hold = true;
-        RUN(wgrad_layer(c, Lo, ws + d.out[d.n], (long)C * To, To, 1, ddec, Mr * To, To, 1, 1, B, To, To));
-        for (int l = d.n - 1; l >= 0; --l) {
-            const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
-            if (bh) RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, Ti, 1, 1, B, Ti, Ti));
-            else RUN(wgrad_layer(c, p->layers[d.c2[l]], ws + d.a1[l], (long)C * Ti, Ti, 1, dy2[l], (long)C * T2, T2, up, up, B, Ti, Ti));
-            RUN(wgrad_layer(c, p->layers[d.c1[l]], ws + d.out[l], (long)C * Ti, Ti, 1, dy1[l], (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
-        }
-        RUN(wgrad_layer(c, Li, ws + d.z, (long)Cz * Tb, Tb, 1, dy0, (long)C * Tb, Tb, 1, 1, B, Tb, Tb));
         // affine Linears: dW/db from (emb, dcond), d(emb) = W^T dcond (+ upstream)
         const LayerP& La = p->layers[d.affine];
         RUN(wgrad_layer(c, La, ws + p->emb, 0, 1, d.c.c_cond, ws + d.dcond, 0, 1, (int)csb, 1, 1, B, B));
@@ -1509,6 +1537,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         dyA = c.fresh((long)B * C * e.T[0]);
         if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh, NV));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
+        if (!dry) avc_prof_mark(3, s);
         RUN(flush_wgrads(c));
         return 0;
     };
@@ -1558,6 +1587,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 da.Wmax = D.Kp * D.Mp > da.Wmax ? D.Kp * D.Mp : da.Wmax;
             }
             if (!dry) RUN(avc_launch_dense(da, 1, s));
+            if (!dry) avc_prof_mark(1, s);
             {   // the decoder's pending weight gradients: their dy operands are final on the main stream; they go out now, ordered behind
                 // the dense-stack kernel as well
                 const hipStream_t ws0 = overlap ? p->wstream[0] : mainS;
@@ -1572,6 +1602,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 // ... which lets a data-parallel caller start their all-reduce under the encoders' backward
                 // (avc_plan_stream_wait_grads): the decoder's parameters are the tail of the flat buffer
                 if (!dry && p->side_state == 1) hipEventRecord(p->ev_dec_grads, c.wstream);
+                if (!dry) avc_prof_mark(5, c.wstream);
                 c.s = sideS;
                 c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
             }
@@ -1600,6 +1631,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         if (!dry) {
             if (bh) RUN(avc_launch_timepool_bwd_pairs(dhA, ws + e.a2[e.n - 1], B, Cc, Tn, gA, dyA, SL, s));
             else RUN(avc_launch_timepool_bwd(dhA, ws + e.a2[e.n - 1], B, Cc, Tn, gA, dyA, SL, s));
+            avc_prof_mark(2, s);
         }
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
@@ -1626,6 +1658,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             rot();
         }
         RUN(enc_back_front(c, e, xc, scb, scc, sct, dyA));
+        if (!dry) avc_prof_mark(4, s);
         RUN(flush_wgrads(c));
         // the speaker encoder's gradients (head of the flat buffer) are final once its wgrad stream drains: a data-parallel caller
         // reduces them under the content encoder's longer branch (avc_plan_stream_wait_grads(AVC_GRADS_SPEAKER))
@@ -1641,6 +1674,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         }
     }
     if (!dry && p->side_state == 1) hipEventRecord(p->ev_all_grads, s);
+    if (!dry) avc_prof_mark(6, s);
     if (slab_need) {
         slab_need[0] = c.slab_used;
         slab_need[1] = c.dy_used;

@@ -31,6 +31,8 @@ static avc_tuning make_default_tuning() {
     t.bh_ck5 = 8;    // r3 (profiles/r03_bf16s_tune.log): 2.75-2.78 ms/step with 8, 2.83 with 16
     t.in_pairs_nv = 1;
     t.wgrad_cw8 = 0;
+    t.dec_wgrad_flush = 0;
+    t.dec_wgrad_wgs = 128;
     return t;
 }
 const avc_tuning& avc_default_tuning() {
@@ -57,7 +59,7 @@ int avc_set_tuning(const char* name, int value) {
     AVC_TUNE_FIELD(single_stream) AVC_TUNE_FIELD(dec_split_min) AVC_TUNE_FIELD(conv_x3) AVC_TUNE_FIELD(wgrad_x3) AVC_TUNE_FIELD(dgrad_par)
     AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
     AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(side_prio) AVC_TUNE_FIELD(wgrad_batch_units)
-    AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(wgrad_cw8)
+    AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(wgrad_cw8) AVC_TUNE_FIELD(dec_wgrad_flush) AVC_TUNE_FIELD(dec_wgrad_wgs)
 #undef AVC_TUNE_FIELD
     if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }
     return -1;

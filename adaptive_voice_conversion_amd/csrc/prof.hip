@@ -22,6 +22,20 @@ std::vector<Rec> g_recs;
 
 bool avc_prof_on() { return g_on; }
 
+// A handful of named points of a step, each ONE timing event on the stream it is reached on: unlike the per-launch brackets (and unlike
+// a tracer) five events do not change the schedule they observe.
+namespace {
+bool g_marks = false;
+hipEvent_t g_mark[AVC_PROF_NMARK];
+bool g_mark_set[AVC_PROF_NMARK];
+}  // namespace
+void avc_prof_mark(int id, hipStream_t s) {
+    if (!g_marks || id < 0 || id >= AVC_PROF_NMARK) return;
+    if (!g_mark_set[id]) hipEventCreate(&g_mark[id]);
+    g_mark_set[id] = true;
+    hipEventRecord(g_mark[id], s);
+}
+
 ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : active_(g_on), s_(s) {
     if (!active_) return;
     Rec r;
@@ -39,6 +53,28 @@ ProfScope::~ProfScope() {
 }
 
 extern "C" {
+int avc_prof_marks_begin(void) {
+    for (int i = 0; i < AVC_PROF_NMARK; ++i) g_mark_set[i] = false;
+    g_marks = true;
+    return 0;
+}
+// ms[i] = time of mark i relative to mark 0 (NaN where the mark was not reached); ends the recording
+int avc_prof_marks_end(double* ms) {
+    g_marks = false;
+    for (int i = 0; i < AVC_PROF_NMARK; ++i) {
+        ms[i] = __builtin_nan("");
+        if (!g_mark_set[i]) continue;
+        hipEventSynchronize(g_mark[i]);
+        if (g_mark_set[0]) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, g_mark[0], g_mark[i]);
+            ms[i] = t;
+        }
+    }
+    for (int i = 0; i < AVC_PROF_NMARK; ++i)
+        if (g_mark_set[i]) hipEventDestroy(g_mark[i]);
+    return AVC_PROF_NMARK;
+}
 int avc_prof_begin(void) {
     g_recs.clear();
     g_on = true;

@@ -153,6 +153,10 @@ typedef struct avc_tuning {
                              * waves (two MFMA waves per SIMD) + four producers.  0 (default): 64 x 64 tiles, four consumers.  Measured on MI355X,
                              * same box: the wgrad class is 2.21 vs 2.26 ms per step with it, the STEP 6.03 vs 5.98 ms (768 threads x 168 registers
                              * leave the chain's kernels no room on a CU the persistent workgroup sits on) */
+    long dec_wgrad_flush;   /* decoder backward: every N recorded weight gradients go out at once, under the decoder's own (latency-bound) backward chain,
+                             * as launches of only dec_wgrad_wgs persistent workgroups; 0 = all of them are held until the dense-stack backward
+                             * kernel of the speaker branch has been launched (round 4's first schedule) */
+    long dec_wgrad_wgs;     /* workgroups (= CUs occupied) of those early launches */
 } avc_tuning;
 void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"

@@ -60,3 +60,24 @@ print(f"# {n} bracketed launches on {len(streams)} streams; span {max(e[i] for i
 rows = sorted(range(min(n, N)), key=lambda i: b[i])
 for i in rows:
     print(f"{b[i] * 1e3:9.1f} +{(e[i] - b[i]) * 1e3:8.1f}  s{streams.index(st[i])}  {lib.avc_prof_class_name(cls[i]).decode()}")
+
+# ---- a handful of named points of the backward pass, one event each (the schedule is NOT perturbed), median of 9 steps
+import statistics
+lib.avc_prof_marks_end.restype = ctypes.c_int
+names = ["backward starts (main)", "dense-stack backward issued (side)", "speaker chain's first kernel issued (side)", "content chain done (main)",
+         "speaker chain done (side)", "decoder weight gradients done (wgrad stream)", "all joined (main)", "-"]
+acc = [[] for _ in names]
+for _ in range(9):
+    torch.cuda.synchronize()
+    lib.avc_prof_marks_begin()
+    solver.ae_step(x, 1.0, eps=eps, sync=False)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_double * 8)()
+    lib.avc_prof_marks_end(ms)
+    for i in range(8):
+        if ms[i] == ms[i]:
+            acc[i].append(ms[i])
+print("# marks of the backward pass, ms from its start (median of 9 un-bracketed steps):")
+for i, nm in enumerate(names):
+    if acc[i]:
+        print(f"#   {statistics.median(acc[i]):7.3f}  {nm}")

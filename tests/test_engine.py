@@ -94,6 +94,8 @@ CASES = [
     pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
     ("emu", "tiny8", 2, 32, False),                        # 8 blocks per encoder: the deepest plan
     ("emu", "tiny8b", 2, 32, False),                       # ... with wgrad_batch = 64: every branch's weight gradients in ONE flush (up to 16 layers in a stream-K launch)
+    ("emu", "tiny_early", 3, 32, False),                   # decoder weight gradients flushed under the decoder's own backward chain (dec_wgrad_flush)
+    pytest.param("gpu", "m80_early", 4, 128, False, marks=GPU),
     pytest.param("gpu", "tiny8", 3, 64, False, marks=GPU),
     pytest.param("gpu", "tiny8b", 3, 64, False, marks=GPU),
     pytest.param("gpu", "m80", 3, 24, False, marks=GPU),   # T_l = 3 at the bottleneck
@@ -115,7 +117,7 @@ def deep_tiny_config():
 
 
 def get_cfg(name):
-    return {"tiny8": deep_tiny_config, "tiny8b": deep_tiny_config, "tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny8": deep_tiny_config, "tiny8b": deep_tiny_config, "tiny_early": O.tiny_config, "m80_early": lambda: O.stock_config(80), "tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
@@ -128,7 +130,7 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     if transposed:
         xd = xd.transpose(1, 2).contiguous().transpose(1, 2)  # collate view, strides (T*M, 1, M)
     x3 = cfgname.endswith("x3")            # opt-in split-bf16 products: conv kernel (2 = every layer of an eligible shape, whatever its size) + weight gradients
-    plan = Plan(cfg, B, T, lib=lib, tuning={"conv_x3": 2, "wgrad_x3": 1} if x3 else ({"wgrad_batch": 64} if cfgname == "tiny8b" else None))
+    plan = Plan(cfg, B, T, lib=lib, tuning={"conv_x3": 2, "wgrad_x3": 1} if x3 else ({"wgrad_batch": 64} if cfgname == "tiny8b" else ({"dec_wgrad_flush": 2, "dec_wgrad_wgs": 24} if cfgname.endswith("_early") else None)))
     assert plan.num_params == len(sd)
     if x3:   # the opt-in kernel brings its own weight images: the plan really switched
         assert plan.workspace_floats > Plan(cfg, B, T, lib=lib).workspace_floats
@@ -156,9 +158,11 @@ def test_forward_loss_backward_vs_oracle(kind, cfgname, B, T, transposed):
     # fp32 (the oracle's own fp32 vs fp64 gradients differ by 2.1e-4 on decoder.in_conv_layer.weight
     # there, 6e-6 at T=48; measured), so that case gets 5e-3; everything else the stated 1e-4.
     illc = T <= 24 and not cfgname.startswith("tiny")
-    worst, med, total = check_grads(plan, grads, grads_m, tol=5e-3 if illc else 1e-4, cfg=cfg, zero_abs=2e-5 if illc else 1e-6)
+    # (the 23 analytically-zero bias gradients are sums of rounding errors: 1e-6 for the stock depth; the 8-block net measures 1.01e-6)
+    zabs = 2e-5 if illc else (3e-6 if cfgname.startswith("tiny8") else 1e-6)
+    worst, med, total = check_grads(plan, grads, grads_m, tol=5e-3 if illc else 1e-4, cfg=cfg, zero_abs=zabs)
     assert med < 2e-5
-    uw, um, ut = check_grads(plan, grads, grads_ref, tol=None, cfg=cfg, zero_abs=2e-5 if illc else 1e-6)
+    uw, um, ut = check_grads(plan, grads, grads_ref, tol=None, cfg=cfg, zero_abs=zabs)
     print(f"[{kind}/{cfgname} B={B} T={T}] grad rel-L2 (same ReLU branch): worst tensor {worst:.2e}, median {med:.2e}, "
           f"whole gradient {total:.2e} | vs the oracle's own branch: worst {uw:.2e}, median {um:.2e}, whole {ut:.2e}")
     assert ut < 3e-2  # even with kink flips the whole gradient stays close
