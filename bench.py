@@ -903,7 +903,7 @@ def main():
                        "world_size": world, "dist_backend": (a.dist_backend if world > 1 else None), "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
                        "tuning": a.tune or None,
                        "allreduce": ("decoder range on a communication stream under the encoders' backward, encoders' range after it; "
-                                     "RCCL via torch.distributed nccl") if world > 1 else None,
+                                     + ("RCCL via torch.distributed nccl" if a.dist_backend == "nccl" else f"torch.distributed {a.dist_backend} (staged through the host: executes the path, not a scaling number)")) if world > 1 else None,
                        "final_losses": meta},
         }
         if world == 1 and not a.no_profile:
