@@ -1,0 +1,57 @@
+"""Property tests: the conv kernels (forward, input gradient, weight gradient) and the InstanceNorm rows at RANDOM small shapes --
+channel counts that are no multiple of anything, odd lengths, every tap count 1..8, stride 1 / 2 -- against the same torch
+restatements as the table-driven tests (model.py:21-32 and its autograd).  Derandomised: the same shapes every run."""
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+from tests import test_ops_conv as C
+from tests.emu_util import backend
+
+GPU = pytest.mark.gpu
+
+shape = st.tuples(st.integers(1, 5),                       # B
+                  st.integers(1, 72),                      # Cin
+                  st.integers(1, 140),                     # Cout
+                  st.integers(5, 80),                      # T
+                  st.integers(1, 8),                       # KS
+                  st.sampled_from([1, 1, 2]))              # stride
+
+
+def _ok(B, Cin, Cout, T, KS, stride):
+    return T > KS // 2 + 1 and B * Cin * Cout * T * KS < 6e6   # (reflect padding needs pad < T; keep the simulator's time per example small)
+
+
+def _run(kind, which, s):
+    B, Cin, Cout, T, KS, stride = s
+    if not _ok(*s):
+        return
+    if which == "fwd":
+        C.test_conv_fwd_matches_pad_conv(kind, B, Cin, Cout, T, KS, stride, 0)
+    elif which == "dgrad":
+        C.test_conv_dgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride, 0)
+    else:
+        C.test_conv_wgrad_matches_autograd(kind, B, Cin, Cout, T, KS, stride)
+
+
+@pytest.mark.parametrize("which", ["fwd", "dgrad", "wgrad"])
+def test_conv_random_shapes_on_the_simulator(which):
+    backend("emu")
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(shape)
+    def run(s):
+        _run("emu", which, s)
+    run()
+
+
+@GPU
+@pytest.mark.parametrize("which", ["fwd", "dgrad", "wgrad"])
+def test_conv_random_shapes_on_the_gpu(which):
+    backend("gpu")
+
+    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(shape)
+    def run(s):
+        _run("gpu", which, s)
+    run()
