@@ -55,3 +55,39 @@ def test_conv_random_shapes_on_the_gpu(which):
     def run(s):
         _run("gpu", which, s)
     run()
+
+
+# ---- InstanceNorm / AdaIN / activation / residual rows (model.py:296,341,77-83,316-320,362-369)
+from tests import test_ops_rowops as R   # noqa: E402
+
+in_shape = st.tuples(st.integers(1, 6), st.integers(1, 20), st.integers(2, 300), st.booleans(), st.sampled_from([0, 1, 2, 5]))
+
+
+def _run_in(kind, s):
+    B, Cc, T, affine, res_mode = s
+    if res_mode == 5 and T % 2:     # an upsampled residual has an even length
+        T += 1
+    if B * Cc * T > 20000:
+        return
+    R.test_instnorm_fwd_bwd(kind, B, Cc, T, affine, res_mode)
+
+
+def test_instnorm_random_shapes_on_the_simulator():
+    backend("emu")
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(in_shape)
+    def run(s):
+        _run_in("emu", s)
+    run()
+
+
+@GPU
+def test_instnorm_random_shapes_on_the_gpu():
+    backend("gpu")
+
+    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(in_shape)
+    def run(s):
+        _run_in("gpu", s)
+    run()
