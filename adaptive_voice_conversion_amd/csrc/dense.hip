@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(AVC_THREADS) dense_stack_bwd_kernel(const Dens
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = (wave + 4 * i) * 16 + 4 * kq + r;
-                mk[i][r] = below.act[(long)(m < L.Cin ? m : L.Cin - 1) * a.B + (ok ? b : a.B - 1)];   // (clamped, no branch; unused at l == 0)
+                // (clamped, no lane-dependent branch.  l == 0 hands down d(pooled) unmasked -- and with n_dense_blocks = 0 the only layer is the
+                // output layer, which HAS no ReLU output to read: the test on l is wave-uniform)
+                mk[i][r] = (l > 0) ? below.act[(long)(m < L.Cin ? m : L.Cin - 1) * a.B + (ok ? b : a.B - 1)] : 0.f;
             }
         if (nbuf == 2 && l > 0)
             dense_load_w(a.layer[l - 1].wp, smem + ((idx + 1) & 1) * WB, a.layer[l - 1].Kp * a.layer[l - 1].Mp, wave, lane);

@@ -94,6 +94,8 @@ CASES = [
     pytest.param("gpu", "m80", 2, 256, False, marks=GPU),
     ("emu", "tiny8", 2, 32, False),                        # 8 blocks per encoder: the deepest plan
     ("emu", "tiny8b", 2, 32, False),                       # ... with wgrad_batch = 64: every branch's weight gradients in ONE flush (up to 16 layers in a stream-K launch)
+    ("emu", "tiny_nd0", 2, 32, False),                     # n_dense_blocks = 0: the dense stack is the output layer alone (crashed the backward until round 4)
+    pytest.param("gpu", "tiny_nd0", 20, 32, False, marks=GPU),
     ("emu", "tiny_early", 3, 32, False),                   # decoder weight gradients flushed under the decoder's own backward chain (dec_wgrad_flush)
     pytest.param("gpu", "m80_early", 4, 128, False, marks=GPU),
     pytest.param("gpu", "tiny8", 3, 64, False, marks=GPU),
@@ -117,7 +119,7 @@ def deep_tiny_config():
 
 
 def get_cfg(name):
-    return {"tiny8": deep_tiny_config, "tiny8b": deep_tiny_config, "tiny_early": O.tiny_config, "m80_early": lambda: O.stock_config(80), "tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
+    return {"tiny_nd0": lambda: O.tiny_config(n_dense=0), "tiny8": deep_tiny_config, "tiny8b": deep_tiny_config, "tiny_early": O.tiny_config, "m80_early": lambda: O.stock_config(80), "tiny": O.tiny_config, "tiny_lrelu": lambda: O.tiny_config(act="lrelu"), "tiny128": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m80": lambda: O.stock_config(80), "m80x3": lambda: O.stock_config(80), "tiny128x3": lambda: O.tiny_config(n_mels=16, c_h=128, c_bank=32, bank_size=4, n_blocks=2, n_dense=1), "m512": lambda: O.stock_config(512)}[name]()
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T,transposed", CASES)
