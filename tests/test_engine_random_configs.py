@@ -107,3 +107,64 @@ def test_random_configs_on_the_gpu():
     def run(case, seed):
         _check("gpu", case, seed)
     run()
+
+
+# ---- one-shot conversion (model.py:387-391) of random members of the family: the uniform plan with unequal source / target lengths and the
+# ragged plan (any number of pairs of different lengths in one launch set) against the oracle's AE.inference of each pair alone
+@st.composite
+def infer_cases(draw):
+    cfg, _, T = draw(nets())
+    n = draw(st.integers(1, 4))
+    lo = T                                   # (the shortest length `nets` found legal for this config)
+    Ts = [draw(st.integers(lo, lo + 40)) for _ in range(n)]
+    Tc = [draw(st.integers(lo, lo + 40)) for _ in range(n)]
+    return cfg, Ts, Tc
+
+
+def _check_infer(kind, case, seed):
+    from adaptive_voice_conversion_amd.engine import RaggedPlan
+    cfg, Ts, Tc = case
+    print("INFER CASE", Ts, Tc, seed, {k: {kk: vv for kk, vv in cfg[k].items() if kk in ("c_in", "c_h", "bank_size", "kernel_size", "n_conv_blocks", "subsample", "upsample", "n_dense_blocks")} for k in ("SpeakerEncoder", "ContentEncoder", "Decoder")}, flush=True)
+    lib, dev = backend(kind)
+    M = cfg["ContentEncoder"]["c_in"]
+    sd = O.make_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(t, M, generator=g) for t in Ts]
+    cs = [torch.randn(t, M, generator=g) for t in Tc]
+    refs = [O.ae_inference(x.t()[None], c.t()[None], sd, cfg)[0] for x, c in zip(xs, cs)]
+    # uniform plan, first pair: unequal source / target lengths
+    plan = Plan(cfg, 1, Ts[0], Tc[0], lib=lib, mode="inference")
+    params = flat_params(plan, sd, dev)
+    ws = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    plan.forward(params, xs[0].t()[None].contiguous().to(dev), cs[0].t()[None].contiguous().to(dev), None, ws)
+    dec = plan.view(ws, "dec", (1, cfg["Decoder"]["c_out"], plan.out_len)).cpu()[0]
+    assert tuple(dec.shape) == tuple(refs[0].shape)
+    torch.testing.assert_close(dec, refs[0], rtol=1e-4, atol=2e-5)
+    plan.close()
+    # ragged plan: all pairs in one launch set
+    rp = RaggedPlan(cfg, Ts, Tc, lib=lib)
+    params = flat_params(rp, sd, dev)
+    ws = torch.full((rp.workspace_floats,), float("nan"), device=dev)
+    rp.forward(params, torch.cat(xs).to(dev), torch.cat(cs).to(dev), ws)
+    outs = rp.outputs(ws)
+    for b, ref in enumerate(refs):
+        assert tuple(outs[b].shape) == tuple(ref.shape), (b, Ts[b], outs[b].shape, ref.shape)
+        torch.testing.assert_close(outs[b].cpu(), ref, rtol=1e-4, atol=2e-5, msg=lambda m: f"pair {b} (T={Ts[b]}, T_cond={Tc[b]}): {m}")
+    rp.close()
+
+
+def test_random_inference_on_the_simulator():
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(infer_cases(), st.integers(0, 1000))
+    def run(case, seed):
+        _check_infer("emu", case, seed)
+    run()
+
+
+@GPU
+def test_random_inference_on_the_gpu():
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(infer_cases(), st.integers(0, 1000))
+    def run(case, seed):
+        _check_infer("gpu", case, seed)
+    run()
