@@ -102,7 +102,7 @@ def test_random_configs_on_the_simulator():
 
 @GPU
 def test_random_configs_on_the_gpu():
-    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=24, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(nets(), st.integers(0, 1000))
     def run(case, seed):
         _check("gpu", case, seed)
@@ -163,7 +163,7 @@ def test_random_inference_on_the_simulator():
 
 @GPU
 def test_random_inference_on_the_gpu():
-    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=24, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(infer_cases(), st.integers(0, 1000))
     def run(case, seed):
         _check_infer("gpu", case, seed)
@@ -243,7 +243,7 @@ def test_random_configs_in_the_optional_compute_modes_on_the_simulator(mode):
 @GPU
 @pytest.mark.parametrize("mode", ["bf16", "fp32x3"])
 def test_random_configs_in_the_optional_compute_modes_on_the_gpu(mode):
-    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(nets(), st.integers(0, 1000))
     def run(case, seed):
         _check_mode("gpu", case, seed, mode)
