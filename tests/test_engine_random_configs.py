@@ -295,3 +295,34 @@ def test_random_configs_through_the_solver_on_the_gpu():
     def run(case, seed):
         _check_solver("gpu", case, seed)
     run()
+
+
+# ---- AE.inference_ragged keeps ONE pooled workspace for all ragged plans (round 4): alternating length sets A, B, A, C on the same model --
+# a cached plan that runs again after another plan used (and possibly re-allocated) the pool must still be right
+def _check_pool(kind, case, seed):
+    from adaptive_voice_conversion_amd.model import AE
+    cfg, Ts, Tc = case
+    print("POOL CASE", Ts, Tc, seed, flush=True)
+    lib, dev = backend(kind)
+    ae = AE(cfg, lib=lib) if kind == "emu" else AE(cfg).to(dev)
+    sd = O.make_state_dict(cfg, seed)
+    ae.load_state_dict(sd)
+    M_ = cfg["ContentEncoder"]["c_in"]
+    g = torch.Generator().manual_seed(seed)
+    lo = min(Ts + Tc)
+    sets = [(Ts, Tc), ([lo + 3, lo + 50, lo], [lo, lo + 7, lo + 90]), (Ts, Tc), ([lo + 200], [lo + 1])]
+    for (a, b) in sets:
+        xs = [torch.randn(t, M_, generator=g) for t in a]
+        cs = [torch.randn(t, M_, generator=g) for t in b]
+        outs = ae.inference_ragged([x.to(dev) for x in xs], [c.to(dev) for c in cs])
+        for i, (x, c) in enumerate(zip(xs, cs)):
+            ref = O.ae_inference(x.t()[None], c.t()[None], sd, cfg)[0]
+            torch.testing.assert_close(outs[i].cpu(), ref, rtol=1e-4, atol=2e-5, msg=lambda m: f"set {a} / {b}, pair {i}: {m}")
+
+
+def test_ragged_workspace_pool_on_the_simulator():
+    @settings(max_examples=5, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(infer_cases(), st.integers(0, 1000))
+    def run(case, seed):
+        _check_pool("emu", case, seed)
+    run()
