@@ -326,3 +326,56 @@ def test_ragged_workspace_pool_on_the_simulator():
     def run(case, seed):
         _check_pool("emu", case, seed)
     run()
+
+
+# ---- the autograd seam under random interleavings: forwards of several shapes are pending at once, their backwards run in any order,
+# inference / no_grad calls come in between, the plan cache is small (evictions while plans are busy).  Every result against the oracle.
+def test_interleaved_forwards_and_backwards_on_the_simulator():
+    from adaptive_voice_conversion_amd.model import AE
+    lib, dev = backend("emu")
+    cfg = O.tiny_config()
+    sd = O.make_state_dict(cfg, 3)
+    shapes = [(2, 16), (1, 24), (2, 32), (3, 16)]
+    ref_cache = {}
+
+    def reference(shape, seed):
+        key = (shape, seed)
+        if key not in ref_cache:
+            x, eps = O.make_inputs(cfg, shape[0], shape[1], seed)
+            outs, grads = O.loss_and_grads(x, eps, sd, cfg, 1.0)
+            ref_cache[key] = (x, eps, outs, grads)
+        return ref_cache[key]
+
+    @settings(max_examples=6, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.lists(st.tuples(st.sampled_from(["fwd", "bwd", "infer", "nograd"]), st.integers(0, 3), st.integers(0, 2)), min_size=6, max_size=12))
+    def run(ops):
+        ae = AE(cfg, lib=lib)
+        ae.load_state_dict(sd)
+        ae.set_plan_cache_size(train=2, inference=1)
+        pending = []
+        for op, si, seed in ops + [("bwd", 0, 0)] * 12:
+            shape = shapes[si]
+            if op == "fwd" and len(pending) < 3:
+                x, eps, outs, grads = reference(shape, seed)
+                mu, ls, emb, dec = ae(x, eps=eps)
+                torch.testing.assert_close(dec.detach(), outs["dec"], rtol=1e-4, atol=2e-5)
+                pending.append((x, mu, ls, dec, grads))
+            elif op == "bwd" and pending:
+                x, mu, ls, dec, grads = pending.pop(si % len(pending))
+                ae.zero_grad()
+                loss = 10 * torch.nn.L1Loss()(dec, x) + 0.5 * torch.mean(torch.exp(ls) + mu ** 2 - 1 - ls)
+                loss.backward()
+                for k, p in ae.named_parameters():
+                    d = grads[k].norm().item()
+                    assert (p.grad - grads[k]).norm().item() <= 2e-4 * d + 2e-6, (k, shape)
+            elif op == "infer":
+                x, eps, _, _ = reference(shape, seed)
+                out = ae.inference(x, x)
+                torch.testing.assert_close(out, O.ae_inference(x, x, sd, cfg), rtol=1e-4, atol=2e-5)
+            elif op == "nograd":
+                x, eps, outs, _ = reference(shape, seed)
+                with torch.no_grad():
+                    dec = ae(x, eps=eps)[3]
+                torch.testing.assert_close(dec, outs["dec"], rtol=1e-4, atol=2e-5)
+        assert not pending
+    run()
