@@ -93,7 +93,7 @@ def _check(kind, case, seed):
 
 
 def test_random_configs_on_the_simulator():
-    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(nets(), st.integers(0, 1000))
     def run(case, seed):
         _check("emu", case, seed)
@@ -154,7 +154,7 @@ def _check_infer(kind, case, seed):
 
 
 def test_random_inference_on_the_simulator():
-    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=6, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(infer_cases(), st.integers(0, 1000))
     def run(case, seed):
         _check_infer("emu", case, seed)
@@ -233,7 +233,7 @@ def _check_mode(kind, case, seed, mode):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp32x3"])
 def test_random_configs_in_the_optional_compute_modes_on_the_simulator(mode):
-    @settings(max_examples=8, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=5, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(nets(), st.integers(0, 1000))
     def run(case, seed):
         _check_mode("emu", case, seed, mode)
@@ -281,7 +281,7 @@ def _check_solver(kind, case, seed):
 
 
 def test_random_configs_through_the_solver_on_the_simulator():
-    @settings(max_examples=5, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=3, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(nets(), st.integers(0, 1000))
     def run(case, seed):
         _check_solver("emu", case, seed)
@@ -321,7 +321,7 @@ def _check_pool(kind, case, seed):
 
 
 def test_ragged_workspace_pool_on_the_simulator():
-    @settings(max_examples=5, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=3, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(infer_cases(), st.integers(0, 1000))
     def run(case, seed):
         _check_pool("emu", case, seed)
@@ -346,7 +346,7 @@ def test_interleaved_forwards_and_backwards_on_the_simulator():
             ref_cache[key] = (x, eps, outs, grads)
         return ref_cache[key]
 
-    @settings(max_examples=6, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=4, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(st.lists(st.tuples(st.sampled_from(["fwd", "bwd", "infer", "nograd"]), st.integers(0, 3), st.integers(0, 2)), min_size=6, max_size=12))
     def run(ops):
         ae = AE(cfg, lib=lib)
