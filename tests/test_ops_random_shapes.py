@@ -91,3 +91,34 @@ def test_instnorm_random_shapes_on_the_gpu():
     def run(s):
         _run_in("gpu", s)
     run()
+
+
+# ---- the bf16 pair-storage instances of the same kernels (compute_dtype "bf16": channel pairs in one dword): even channel counts,
+# lengths that are multiples of 4 (the engine's shape rule for that mode)
+from tests import test_bf16_pairs as BP   # noqa: E402
+
+pair_shape = st.tuples(st.integers(1, 4), st.integers(1, 36).map(lambda v: 2 * v), st.integers(1, 70).map(lambda v: 2 * v),
+                       st.integers(2, 20).map(lambda v: 4 * v), st.integers(1, 8), st.sampled_from([1, 1, 2]))
+
+
+def _run_pairs(kind, which, s):
+    B, Cin, Cout, T, KS, stride = s
+    if not _ok(*s) or (stride == 2 and (T // 2) % 4):   # (the strided output is a pair tensor too: its length obeys the same rule)
+        return
+    if which == "fwd":
+        BP.test_pairs_conv_fwd(kind, B, Cin, Cout, T, KS, stride, 0, False)
+    elif which == "dgrad":
+        BP.test_pairs_conv_dgrad(kind, B, Cin, Cout, T, KS, stride, 0)
+    else:
+        BP.test_pairs_conv_wgrad(kind, B, Cin, Cout, T, KS, stride)
+
+
+@pytest.mark.parametrize("which", ["fwd", "dgrad", "wgrad"])
+def test_pair_conv_random_shapes_on_the_simulator(which):
+    backend("emu")
+
+    @settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(pair_shape)
+    def run(s):
+        _run_pairs("emu", which, s)
+    run()
