@@ -101,6 +101,10 @@ struct ConvArgs {
                // from bf16 operands (the heads, the decoder's last conv)
     int par;  // stride-2 dgrad: columns of one parity per wave, each wave multiplies only the taps that meet non-zero
               // positions of the zero-upsampled dy (set by the launcher)
+    // ---- tile walk (set by the launcher; conv_gemm.hip): workgroup x of gridDim.x walkers computes the column tiles x, x + gridDim.x, ...
+    int walk_n;    // tiles of the longest walk (1: one tile per workgroup)
+    int walk_rem;  // walkers [0, walk_rem) take walk_n tiles, the others walk_n - 1
+    int walk_db;   // samples between two tiles of a walker (the first frame of the tile never changes along a walk)
     ConvGroup g[AVC_MAX_GROUPS];
 };
 

@@ -203,7 +203,22 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // from the ConvRag tables; everything else is the uniform kernel with one sample per tile.
 // WN = 2 (64 x 128 and 128 x 128 tiles; uniform stride-1 launches): two 32-column fragments per wave share every weight fragment --
 // the weight image is 80 % of a chunk's LDS-DMA bytes and it is re-read by every column tile (section 3.1 of DESIGN.md).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false>
+// TILE WALK (round 5; WALK instances: uniform launches with KG == 1): a workgroup is PERSISTENT over `a.walk_n` column tiles of its row slab -- tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... .  The walk keeps the first frame t0 of the tile and steps only the sample (a.walk_db samples per
+// step), so everything the prologue derives per lane -- source offsets with their reflect / zero-upsampling index math, structural zeros
+// of the X stages, column descriptors, mirror windows -- is computed ONCE; a step is a scalar bump of the source base and of the
+// epilogue's sample index.  The chunk pipeline runs THROUGH the tile boundary: the LDS-DMA of the next tile's first chunk is issued
+// in front of the last chunk's products of this tile, the wave waits for ITS pieces before the epilogue (they had the whole chunk to
+// land), and the barrier in front of the next tile's first products is a bare s_barrier behind the epilogue -- no s_waitcnt vmcnt(0)
+// stands between the stores of tile i and the loop of tile i + 1.  Each tile is computed by exactly the instruction sequence of the
+// one-tile kernel: results are bit-identical (tests/test_conv_walk.py).
+// MEASURED (profiles/r05_conv_walk_ablation.log, one MI355X, same-box A/B against the round-4 library): no gain.  With 1024 tiles on 1024
+// resident slots (the model's T = 128 layers at B = 256) there is nothing to pipeline -- two walkers per CU x two tiles lose 6-14 % against
+// four one-tile workgroups per CU -- and where a launch holds many tiles per slot (B = 1024: 4096 tiles; the 8192-tile bank) the hardware's
+// own dispatch of the next workgroup already overlaps prologue and epilogue with the neighbours' products: walk 201 us vs 202 us, and the
+// shared kernel body paid 3-5 % for carrying the walk's state through its epilogue (registers 100 -> 120, ~80 spilled scalars).  Hence a
+// compile-time flag: WALK = false IS the round-4 kernel; the WALK instances exist for the tests and `avc_tuning.conv_walk` (default 0).
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false, bool WALK = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -276,16 +291,17 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             int seg = p / q.SEG, qq = p - seg * q.SEG;
             int b = q.b0 + seg;
             int pp = q.seg_p0 + qq;
+            const int bs = WALK ? seg : b;   // (a walk steps the base pointer: offsets relative to the tile's first sample)
             if (b < Bv) {
                 if (a.mode == 0) {
                     int v = pp - padL;
                     int r = avc_reflect(v, Tsrc);
-                    if (r >= 0 && r < Tsrc) sp = (int)(b * xsb + (long)r * a.x.st + lu);
+                    if (r >= 0 && r < Tsrc) sp = (int)(bs * xsb + (long)r * a.x.st + lu);
                 } else {
                     int v = pp - (KS - 1);
                     if (v >= 0) {
                         int vs = v / a.stride;
-                        if (vs * a.stride == v && vs < Tsrc) sp = (int)(b * xsb + (long)vs * a.x.st + lu);
+                        if (vs * a.stride == v && vs < Tsrc) sp = (int)(bs * xsb + (long)vs * a.x.st + lu);
                     }
                 }
             }
@@ -323,7 +339,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             t = n - bl * Tout;
             v = (bl < q.SPT) && (q.b0 + bl < Bv);
         }
-        colb[wn] = q.b0 + bl;
+        colb[wn] = WALK ? bl : q.b0 + bl;   // (walk: sample inside the tile; the tile's first sample is added in the epilogue)
         colt[wn] = t;
         colv[wn] = v;
         int base = q.ROWDATA, bL = q.ROWDATA, bR = q.ROWDATA;
@@ -342,14 +358,6 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         cbl4[wn] = 4 * bL;
         cbr4[wn] = 4 * bR;
     }
-
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-        for (int wn = 0; wn < WN; ++wn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
     const int npieces = (KS * CK * BM) >> 8;  // 1 KiB (256 floats) per wave-instruction of the LDS DMA
     const int nj = (ROW + 15) >> 4;
@@ -381,7 +389,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     };
     // source tile: this wave's position groups of its planes (see xo above)
     const int njw = (nj - jpar + 1) >> 1;   // position groups j = 2 jj + jpar < nj
-    auto load_x = [&](int chunk, int buf) {
+    auto load_x = [&](const float* xtile, int chunk, int buf) {
         float* Xd = Xs + buf * XS + 64 * jpar;
         const int c_chunk = chunk * CK;
         for (int pl = wave & 1; pl < 2 * GR; pl += 2) {
@@ -394,7 +402,7 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
                 c = c < a.Cred ? c : a.Cred - 1;
                 fix = ((a.x.ps == 1) ? (long)c * xsc : (long)(c >> 1) * xsc + (c & 1)) - (pbase + lu);
             }
-            const float* src = xptr + pbase + fix;
+            const float* src = xtile + pbase + fix;
             float* dst = Xd + pl * ROW * 4;
 #pragma unroll
             for (int jj = 0; jj < AVC_CONV_NJ4 / 2; ++jj)
@@ -415,30 +423,50 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     };
 
     constexpr int DIST = NS - 1;   // prefetch distance in chunks
+    // ---- tile walk state
+    static_assert(!WALK || (KG == 1 && !RAG && NS == 2), "tile walk: uniform launches, one wave group, two stages");
+    const int walk_n = WALK ? a.walk_n - ((int)blockIdx.x < a.walk_rem ? 0 : 1) : 1;   // (the first walk_rem walkers take one tile more)
+    const long walk_dx = WALK ? (long)a.walk_db * xsb : 0;
+    const float* xtile = WALK ? xptr + (long)q.b0 * xsb : xptr;
+    int b0_cur = WALK ? q.b0 : 0;
     if (kg < nchunk) {
         load_a(kg, 0);
-        load_x(kg, 0);
+        load_x(xtile, kg, 0);
     }
     if (DIST == 2 && kg + KG < nchunk && !(a.dbg & 1)) {
         load_a(kg + KG, 1);
-        load_x(kg + KG, 1);
+        load_x(xtile, kg + KG, 1);
     }
     __syncthreads();
 
     const int a_lane4 = (wave_m * (32 * WM) + li) * 4;
     const int nit = (nchunk + KG - 1) / KG;
     int st = 0;   // stage of the chunk being multiplied (it % NS)
+    for (int wk = 0; wk < walk_n; ++wk) {
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+    const bool walk_more = WALK && wk + 1 < walk_n;
     for (int it = 0; it < nit; ++it) {
         const int chunk = it * KG + kg;
         // chunk c + DIST is issued now and lands while chunks c .. c + DIST - 1 are multiplied; chunk c + 1 must have landed by the
         // barrier at the end of this iteration (DIST == 1: that is everything outstanding)
         const bool more = (chunk + DIST * KG < nchunk) && !((a.dbg & 1) && (DIST == 2 || it >= 1));
+        const bool last_of_tile = walk_more && it == nit - 1;   // (tile walk: DIST == 1) the next tile's first chunk rides under this tile's last
         int issued = 0;
         if (more) {
             const int stn = (st + DIST) % NS;   // last read during chunk c - 1, free since that chunk's barrier
             load_a(chunk + DIST * KG, stn);
-            load_x(chunk + DIST * KG, stn);
+            load_x(xtile, chunk + DIST * KG, stn);
             if (DIST == 2) issued = dma_count(chunk + DIST * KG);
+        } else if (last_of_tile && !(a.dbg & 1)) {
+            const int stn = (st + 1) % NS;
+            load_a(0, stn);
+            load_x(xtile + walk_dx, 0, stn);
         }
         const float* Ab = As + st * AS;
         const float* Xb = Xs + st * XS;
@@ -473,7 +501,9 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
             }
         } else
             conv_chunk_mma<WM, WN, 0, KSC, GRC, BF>(acc, Ab, Xb, KS, CK, ROW, h, a_lane4, cb4, cbl4, cbr4);
-        if (!(a.dbg & 4)) {
+        if (last_of_tile) {
+            conv_wait_dma(0);   // this wave's pieces of the next tile's first chunk; the workgroup's barrier follows the epilogue
+        } else if (!(a.dbg & 4)) {
             conv_wait_dma(issued);   // everything but the DMA instructions issued in THIS iteration has landed
             conv_bare_barrier();
         }
@@ -505,16 +535,59 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     }
 
     // ---- epilogue
-    if (a.dbg & 8) return;
+    if (!(a.dbg & 8)) {
+        if constexpr (WALK) {
+            // The epilogue's parameters (strides, bases, pointers: ~40 scalar registers) and its row / column arithmetic are invariant along a
+            // walk.  Left visible, the compiler keeps all of it live through the chunk loop -- hoisted address arithmetic (246-398 VGPRs: half
+            // the waves per SIMD) and ~100 spilled scalars.  So every tile RE-READS its parameters from the kernel-argument segment through an
+            // opaque pointer (scalar loads under the last products) and takes opaque copies of the lane's row / column.
+            ConvEpi epi_t;
+            ConvGroup g_t;
+#ifdef AVC_EMU
+            const ConvArgs* ka = &a;
+#else
+            const __attribute__((address_space(4))) ConvArgs* ka = (const __attribute__((address_space(4))) ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+#endif
+            epi_t.ob = ka->ob; epi_t.oc = ka->oc; epi_t.rb = ka->rb; epi_t.rc = ka->rc; epi_t.obase = 0; epi_t.rbase = 0;
+            epi_t.ot = ka->ot; epi_t.ops = ka->ops; epi_t.rt = ka->rt; epi_t.Tres = ka->Tres; epi_t.Tout = ka->Tout; epi_t.M = ka->M;
+            epi_t.act = ka->act; epi_t.res_mode = ka->res_mode; epi_t.res_to_primary = ka->res_to_primary; epi_t.slope = ka->slope;
+            epi_t.pairs = ka->pairs;
+            const int z = blockIdx.z;
+            g_t.wp = nullptr; g_t.bias = ka->g[z].bias; g_t.out = ka->g[z].out; g_t.out2 = ka->g[z].out2; g_t.res = ka->g[z].res;
+            g_t.mask = ka->g[z].mask; g_t.KS = 0; g_t.padL = 0; g_t.padR = 0; g_t.nchunk = 0; g_t.CK = 0; g_t.out_c0 = 0;
 #pragma unroll
-    for (int wn = 0; wn < WN; ++wn) {
-        if (!colv[wn]) continue;
+            for (int wn = 0; wn < WN; ++wn) {
+                if (!colv[wn]) continue;
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) {
-            if (BF == 2 && epi.pairs) conv_store_frag_pairs(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
-            else conv_store_frag(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+                for (int wm = 0; wm < WM; ++wm) {
+                    int tcol = colt[wn], bcol = b0_cur + colb[wn], mb = m_tile0 + wave_m * (32 * WM) + wm * 32;
+#ifndef AVC_EMU
+                    asm volatile("" : "+v"(tcol), "+v"(bcol));
+                    asm volatile("" : "+s"(mb));
+#endif
+                    if (BF == 2 && epi_t.pairs) conv_store_frag_pairs(epi_t, g_t, acc[wm][wn], mb, h, bcol, tcol);
+                    else conv_store_frag(epi_t, g_t, acc[wm][wn], mb, h, bcol, tcol);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) {
+                if (!colv[wn]) continue;
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) {
+                    if (BF == 2 && epi.pairs) conv_store_frag_pairs(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+                    else conv_store_frag(epi, g, acc[wm][wn], m_tile0 + wave_m * (32 * WM) + wm * 32, h, colb[wn], colt[wn]);
+                }
+            }
         }
     }
+    if (walk_more) {
+        conv_bare_barrier();   // every wave's pieces of the next tile's first chunk have landed (each waited for its own in front of its epilogue)
+        xtile += walk_dx;
+        b0_cur += a.walk_db;
+    }
+    }   // tile walk
 }
 
 // --------------------------------------------------------------------------
@@ -719,6 +792,21 @@ static void conv_launch_variant(const ConvArgs& a, bool mir, int fast, dim3 grid
     else hipLaunchKernelGGL((conv_gemm_kernel<WM, 1, false, 0, 0, KG, BF>), grid, block, lds, stream, a);
 }
 
+// tile walk (opt-in, avc_tuning.conv_walk; exact fp32 only): the k = 5 straight-line chunk both ways, the grouped bank launch, the 1x1
+// convs on 64- and 128-row tiles.  false: no WALK instance for this launch
+static bool conv_launch_walk(const ConvArgs& a, int tile, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (tile == 11 && fast == 1 && mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, 1, 0, false, false, true>), grid, block, lds, stream, a);
+    else if (tile == 11 && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, 1, 0, false, false, true>), grid, block, lds, stream, a);
+    else if (tile == 11 && fast == -1 && !mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, -1, 0, 1, 0, false, false, true>), grid, block, lds, stream, a);
+    else if (tile == 11 && fast == 14 && !mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, 1, 0, false, false, true>), grid, block, lds, stream, a);
+    else if (tile == 21 && fast == 14 && !mir) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, false, 1, 4, 1, 0, false, false, true>), grid, block, lds, stream, a);
+    else return false;
+    return true;
+}
+static bool conv_walk_instance(int tile, bool mir, int fast) {
+    return (tile == 11 && (fast == 1 || ((fast == -1 || fast == 14) && !mir))) || (tile == 21 && fast == 14 && !mir);
+}
+
 // 64 x 128 tiles (WN = 2): the k = 5 straight-line chunk, forward and mirrored input gradient
 template <int BF>
 static void conv_launch_wide(const ConvArgs& a, bool mir, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
@@ -791,13 +879,42 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     if (a.pairs && (bf != 2 || a.ops != 1 || a.ot != 1 || (a.M & 1) || (a.res_mode != AVC_RES_NONE && a.rt != 1))) return -2;
     a.par = tun.dgrad_par && a.mode == 1 && a.stride == 2 && tile == 11 && a.ngroups == 1 && (fast == 1 || fast == 2) && !a.dbg &&
             a.g[0].padL == 2 && (a.Tout >= 64 || (a.Tout % 2 == 0 && 64 % a.Tout == 0));
+    // ---- tile walk: persistent workgroups over the column tiles of a row slab (conv_gemm_kernel).  Only where every tile of a walk has
+    // the geometry of the first one: rows of >= 64 frames (a walker keeps its first frame), or whole groups of short samples
+    a.walk_n = 1;
+    a.walk_rem = (int)grid.x;
+    a.walk_db = 0;
+    bool walk = false;
+    if (tun.conv_walk != 0 && !rag && !a.par && bf == 0 && kgroups == 1 && AVC_CONV_STAGES == 2 && conv_walk_instance(tile, mir, fast)) {
+        const int ntn = (int)grid.x;
+        const int tps = a.Tout >= BN ? avc_cdiv(a.Tout, BN) : 1;
+        const int SPT = a.Tout >= BN ? 1 : conv_geom(a.mode, a.stride, a.Tout, a.g[0].KS, BN, 0).SPT;
+        const bool geom_ok = a.Tout >= BN || (a.ngroups == 1 && a.B % SPT == 0);
+        long per_cu = (long)(160 * 1024) / (long)lds;                 // resident workgroups per CU: LDS ...
+        const long reg_cu = BM == 128 ? 3 : 4;                          // ... and registers (126-129 / 100-115 VGPRs per lane)
+        per_cu = per_cu < reg_cu ? per_cu : reg_cu;
+        per_cu = per_cu < tun.conv_walk ? per_cu : tun.conv_walk;
+        long W = 256 * per_cu / ((long)grid.y * grid.z);
+        const bool forced = tun.conv_walk < 0;   // (test aid: exactly -conv_walk walkers per row slab, whatever the chip holds)
+        if (forced) W = -tun.conv_walk < tps ? tps : -tun.conv_walk;
+        W = W / tps * tps;
+        if (geom_ok && W >= tps && W < ntn && (forced || (long)ntn >= (tun.conv_walk_min > 1 ? tun.conv_walk_min : 2) * W)) {
+            a.walk_n = avc_cdiv(ntn, (int)W);
+            a.walk_rem = ntn - (a.walk_n - 1) * (int)W;
+            a.walk_db = a.Tout >= BN ? (int)W / tps : (int)W * SPT;
+            grid.x = (unsigned)W;
+            walk = true;
+        }
+    }
 #define AVC_BF3(CALL_)                       \
     do {                                     \
         if (bf == 2) { CALL_(2); }           \
         else if (bf == 1) { CALL_(1); }      \
         else { CALL_(0); }                   \
     } while (0)
-    if (rag) {
+    if (walk) {
+        if (!conv_launch_walk(a, tile, mir, fast, grid, block, lds, stream)) return -2;
+    } else if (rag) {
         if (bf == 2) return -2;   // (ragged plans run fp32 storage)
         const int f = (fast == 1 || fast == -1 || fast == 14) ? fast : 0;
 #define AVC_C_RAG2(BF_) conv_launch_rag<2, BF_>(a, f, grid, block, lds, stream)

@@ -824,7 +824,9 @@ void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
         const int TCOv = 32 * k.WCO;
         // no tile is shared by more than 64 workgroups (its reduce is a dependent chain of slot reads): a launch of very few tiles gets
         // fewer workgroups instead
-        for (int pass = 0; pass < 4; ++pass) {
+        // (slots are ALWAYS those of the final grid: the loop ends on a pass that did not shrink it -- a stale count would size the slabs
+        // for another split than the one the kernel and the reduce derive from `grid`)
+        for (;;) {
             int worst = 1;
             for (int j : mem) {
                 WgradArgs& a = L[j];
@@ -838,8 +840,8 @@ void avc_wgrad_plan_batch(WgradArgs* L, int n, int target_wgs) {
                 worst = slots > worst ? slots : worst;
             }
             if (worst <= 64 || grid <= 1) break;
-            grid = grid * 62 / worst;
-            if (grid < 1) grid = 1;
+            const long shrunk = grid * 62 / worst;
+            grid = shrunk < grid ? (shrunk < 1 ? 1 : shrunk) : grid - 1;   // strictly smaller every pass: terminates
         }
         for (int j : mem) {
             WgradArgs& a = L[j];

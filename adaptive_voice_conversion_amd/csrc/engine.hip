@@ -1051,20 +1051,11 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
 static bool side_ready(const avc_plan* p);
 static int pack_all(const avc_plan* p, const float* params, float* ws, hipStream_t s) {
     if (p->pack_tab_dev) {
-        const int ne = p->pack_nblk_early, nr = p->pack_nblk - ne;
-        const bool split = side_ready(p) && ne > 0 && nr > 0;   // (A/B on one box, round 4: 6.000 vs 6.009 ms/step without the split)
+        // ONE launch on the caller's stream.  (Round 4 ran the tail of the table on a helper stream under the next step's bank convs:
+        // measured neutral -- 6.000 vs 6.009 ms/step -- and its read of `params` was ordered only against a later forward of the SAME
+        // plan, a formal read / write race with an optimizer step or a parameter write that follows on another plan; removed.)
         p->pack_side_pending = false;
-        if (!split) return avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, p->pack_nblk, p->pack_tab_bytes, params, ws, s);
-        const double be = p->pack_tab_bytes * ne / p->pack_nblk;
-        int rc = avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, ne, be, params, ws, s);
-        if (rc) return rc;
-        hipStream_t ps = p->wstream[0];
-        hipEventRecord(p->ev_pack[0], s);  // parameters are final (the optimizer ran on s)
-        hipStreamWaitEvent(ps, p->ev_pack[0], 0);
-        rc = avc_launch_pack_table(p->pack_tab_dev, (const int*)p->pack_blk_dev + 2 * ne, nr, p->pack_tab_bytes - be, params, ws, ps);
-        hipEventRecord(p->ev_pack[1], ps);
-        p->pack_side_pending = true;
-        return rc;
+        return avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, p->pack_nblk, p->pack_tab_bytes, params, ws, s);
     }
     std::vector<PackArgs> all;
     for (size_t i = 0; i < p->layers.size(); ++i)

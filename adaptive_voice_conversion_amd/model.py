@@ -229,9 +229,9 @@ class AE(nn.Module):
             for (o, n, _), p in zip(self._layout, self.parameters()):
                 self._flat[o:o + n] = p.detach().reshape(-1)
         self._gflat = None
+        self._bump = 0
         self._alias()
         # train: the regular batch + the short last batch of an epoch; inference / speaker: a few recent shapes
-        self._bump = 0
         self._plans = _PlanCache({"train": 2, "inference": 8, "speaker": 4})
         self._ragged = {}   # (lengths, device) -> (RaggedPlan, None), a few most recent
         self._ragged_ws = None   # the one workspace they share
@@ -239,6 +239,7 @@ class AE(nn.Module):
 
     # ---- flat storage ------------------------------------------------------
     def _alias(self):
+        self._bump = getattr(self, "_bump", 0) + 1   # the parameters may point at new storage: any "weights already packed" promise is void
         for (o, n, shape), p in zip(self._layout, self.parameters()):
             p.data = self._flat[o:o + n].view(shape)
             if self._gflat is not None:
@@ -279,6 +280,7 @@ class AE(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)  # copies into the aliased views
+        self.weights_changed()   # (the version counters see the copies too; this does not depend on it)
         return out
 
     # ---- plans ---------------------------------------------------------------

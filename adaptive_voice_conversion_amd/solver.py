@@ -116,6 +116,7 @@ class Solver(object):
         d = _dist()
         if d is not None and d.get_world_size() > 1:  # identical replicas: rank 0's init wins
             d.broadcast(self.model.flat_parameters(), src=0)
+            self.model.weights_changed()   # (a collective writes the flat buffer without touching the views' version counters)
         # reparameterisation noise (model.py:383): every rank draws from its OWN generator stream
         self._eps_gen = None
         self._comm_stream = None
@@ -188,8 +189,17 @@ class Solver(object):
         # pack_weights into this very workspace: torch's version counters (of the flat buffer and of every parameter view) see every
         # other in-place change -- load_state_dict, a torch optimizer, user code.  (In-place edits through `.data` bypass the counters,
         # as they bypass autograd's own checks: call AE.weights_changed() after those.)
+        # Fail-safe side: the promise is made ONLY here, behind our own optimizer step + pack_weights, and AE voids it on _alias /
+        # _apply / load_state_dict / weights_changed(); `repack_every_step: true` in the config gives it up altogether, and
+        # `verify_packed_weights: true` (debug: one host sync per step) compares a checksum of the parameters with the one taken when
+        # the images were packed and raises on a silent edit.
         pk = getattr(self, "_packed", None)
-        packed = pk is not None and pk[0] is plan and pk[1] is ws and pk[2] is flat and pk[3] == model.weights_version()
+        packed = (pk is not None and pk[0] is plan and pk[1] is ws and pk[2] is flat and pk[3] == model.weights_version()
+                  and not self.config.get("repack_every_step", False))
+        if packed and self.config.get("verify_packed_weights", False):
+            if float(flat.double().sum()) != pk[4]:
+                raise RuntimeError("the parameters changed behind the version counters since the weight images were packed "
+                                   "(in-place edit through .data, a foreign kernel, a collective): call AE.weights_changed() after such writes")
         plan.forward(flat, x, None, eps, ws, weights_packed=packed)
         plan.loss(x, self.config["lambda"]["lambda_rec"], ws)
         plan.backward(flat, x, None, eps, grads, ws, lambda_kl=float(lambda_kl))
@@ -202,7 +212,8 @@ class Solver(object):
             prescale = 1.0 / d.get_world_size()
         gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)
         plan.pack_weights(flat, ws)    # the next step opens with its first convolution (engine.Plan.forward, weights_packed)
-        self._packed = (plan, ws, flat, model.weights_version())
+        self._packed = (plan, ws, flat, model.weights_version(),
+                        float(flat.double().sum()) if self.config.get("verify_packed_weights", False) else None)
         losses = plan.view(ws, "losses", (2,))
         if not sync:
             return {"loss_rec": losses[0], "loss_kl": losses[1], "grad_norm": gnorm[0]}

@@ -59,7 +59,7 @@ def profile_classes(solver, x, eps, steps):
     plan.set_single_stream(True)   # one stream: event brackets then measure each kernel class in isolation
     lib.avc_prof_begin()
     for _ in range(steps):
-        solver.ae_step(x, 1.0, eps=eps, sync=False)
+        solver.ae_step(x, 1.0, sync=False)   # (eps drawn inside the step, model.py:383)
     torch.cuda.synchronize()
     lib.avc_prof_end(ms, launches, flops, nbytes)
     plan.set_single_stream(was_single)
@@ -250,7 +250,7 @@ def instnorm_all_shapes(plan, reps=8, pairs=False):
     return out
 
 
-PMC_SUMMARIES = ("r04_pmc_fetch_write_summary.json", "r03_pmc_fetch_write_summary.json")
+PMC_SUMMARIES = ("r05_pmc_fetch_write_summary.json", "r04_pmc_fetch_write_summary.json")
 
 
 def build_fingerprint():
@@ -323,6 +323,39 @@ def pmc_class_traffic(cls):
                 tot += n * (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
                 launches += n
     return (tot / launches, src) if launches else (None, None)
+
+
+SQ_SUMMARIES = ("r05_sq_step.json",)
+_SQ_NOTE = [None]
+
+
+def sq_mfma_busy():
+    """MFMA utilisation per kernel class from the committed SQ-counter passes over THIS command in its single-stream mode
+    (scripts/gpu_r5a.sh + scripts/sq_step_summary.py: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE, summed over every
+    dispatch of the class): mfma_busy = matrix-pipe busy cycles / (4 SIMDs x 256 CUs) / cycles the kernels were on the chip.  Only a
+    summary taken on THIS build (source fingerprint) is replayed -- like `traffic`, it is a profile of the same build, not a counter
+    read of this run.  Returns ({class: {...}}, source) or (None, None)."""
+    fp = build_fingerprint()
+    for fn in SQ_SUMMARIES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except Exception:
+            continue
+        meta = d.get("_meta", {})
+        if meta.get("build_fingerprint") != fp:
+            _SQ_NOTE[0] = (f"profiles/{fn} was taken on build {meta.get('build_fingerprint')} (git {meta.get('git_head')}), this library is build {fp}: "
+                           "refused (mfma_busy = null) -- re-run scripts/gpu_r5a.sh on this build")
+            continue
+        out = {}
+        for k, v in d.get("classes", {}).items():
+            dd = v.get("derived", {})
+            if "mfma_busy" in dd:
+                out[k] = {"mfma_busy": dd["mfma_busy"], "launches_profiled": v.get("launches"),
+                          "wave_cycles_waiting_on_waitcnt_or_barrier": dd.get("frac_wave_cycles_waitcnt_or_barrier")}
+        return out, f"profiles/{fn} (build {fp}, git {meta.get('git_head')})"
+    if _SQ_NOTE[0] is None:
+        _SQ_NOTE[0] = "no SQ summary under profiles/ for this build"
+    return None, None
 
 
 def _cpu_busy(interval=0.3):
@@ -643,11 +676,11 @@ def config2_bf16_record(a, dev, g, x):
     plan, _ = solver.model._plan(B, T, T, dev)
     eps = torch.randn(B, cfg["ContentEncoder"]["c_out"], plan.latent_len, generator=g).to(dev)
     for _ in range(a.warmup):
-        solver.ae_step(x, 1.0, eps=eps, sync=False)
+        solver.ae_step(x, 1.0, sync=False)   # (eps drawn inside the step, model.py:383)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        solver.ae_step(x, 1.0, eps=eps, sync=False)
+        solver.ae_step(x, 1.0, sync=False)   # (eps drawn inside the step, model.py:383)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     meta = solver.ae_step(x, 1.0, eps=eps, sync=True)
@@ -873,9 +906,9 @@ def main():
         idx = [["corpus", int(t)] for t in torch.randint(0, rows - T, (n_idx,), generator=gc).tolist()]
         feed = DeviceSegmentFeed(data, idx, T, B, dev, shuffle=True, seed=0, rank=rank, world_size=world)
 
-    def one_step():
+    def one_step():   # the reparameterisation noise (model.py:383 `normal_`) is drawn INSIDE the step, as the reference does
         xb = next(feed) if feed is not None else x
-        solver.ae_step(xb, 1.0, eps=eps, sync=False)
+        solver.ae_step(xb, 1.0, sync=False)
 
     for _ in range(a.warmup):
         one_step()
@@ -915,6 +948,7 @@ def main():
             # f32x3: six 8-pass bf16 MFMAs per 16 reduction steps -> the matrix pipe's ceiling for these products is the bf16 peak / 6
             peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16r": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
             traffic, tsrc = pmc_class_traffic(dom) if (cfg_idx == 1) else (None, None)
+            sq, sq_src = sq_mfma_busy() if (cfg_idx == 1 and a.dtype == "f32") else (None, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak,
                                "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
                                "traffic_source": (f"{tsrc}: launch-weighted mean HBM bytes per launch over the kernel instances of this class "
@@ -924,8 +958,13 @@ def main():
                                "ms_per_step": d["ms_per_step"],
                                "with_reduce_launches": ({"ms_per_step": d["ms_per_step"] + red_ms,
                                                          "tflops": d["tflops"] * d["ms_per_step"] / (d["ms_per_step"] + red_ms)} if dom == "conv_wgrad" else None),
-                               "mfma_classes": {k: {"tflops": prof[k]["tflops"], "frac": prof[k]["tflops"] / peak, "ms_per_step": prof[k]["ms_per_step"]}
+                               "mfma_classes": {k: {"tflops": prof[k]["tflops"], "frac": prof[k]["tflops"] / peak, "ms_per_step": prof[k]["ms_per_step"],
+                                                    "mfma_busy": (sq or {}).get(k, {}).get("mfma_busy") if (cfg_idx == 1 and a.dtype == "f32") else None}
                                                 for k in prof if prof[k]["tflops"]},
+                               "mfma_busy": (sq or {}).get(dom, {}).get("mfma_busy") if (cfg_idx == 1 and a.dtype == "f32") else None,
+                               "mfma_busy_source": ((sq_src + ": SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs), summed "
+                                                     "over every dispatch of the class in the single-stream step (replayed, not a counter read of this run)")
+                                                    if sq_src else _SQ_NOTE[0]) if (cfg_idx == 1 and a.dtype == "f32") else None,
                                "whole_step": {"algorithmic_tflop_per_step": TRAIN_GFLOP_PER_SEG.get((a.mels, T), 0.0) * B / 1e3,
                                               "tflops": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps)) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None,
                                               "frac": (TRAIN_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (elapsed / a.steps) / peak) if (a.mels, T) in TRAIN_GFLOP_PER_SEG else None}}

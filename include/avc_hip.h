@@ -28,7 +28,9 @@
  *    creation (avc_plan_create_tuned); the op-level entry points at the end of
  *    this header read a THREAD-LOCAL avc_tuning that avc_set_tuning edits for
  *    the calling thread only (micro-benchmarks and kernel tests).  No
- *    environment variable is read anywhere.
+ *    environment variable is read by the LIBRARY.  (The Python loader, _lib.py, honours
+ *    AVC_HIP_LIB = path of an alternative build of this library: which .so is loaded for
+ *    same-box A/B measurements, never how it behaves.)
  *  - the gradient all-reduce of data-parallel training deliberately lives in
  *    the host framework (torch.distributed "nccl" = RCCL over xGMI):
  *    this library exposes where to cut (avc_plan_param_range) and when each
@@ -157,6 +159,12 @@ typedef struct avc_tuning {
                              * as launches of only dec_wgrad_wgs persistent workgroups; 0 = all of them are held until the dense-stack backward
                              * kernel of the speaker branch has been launched (round 4's first schedule) */
     long dec_wgrad_wgs;     /* workgroups (= CUs occupied) of those early launches */
+    long conv_walk;         /* conv_gemm tile walk (round 5, opt-in; exact-fp32 k = 5 / bank / 1x1 launches): a launch with at least conv_walk_min
+                             * tiles per resident workgroup runs as PERSISTENT workgroups -- at most this many per CU (further bounded by LDS and
+                             * registers) -- that each walk a list of column tiles, the next tile's first chunk in flight under the epilogue of
+                             * this one.  Bit-identical results.  0 (default) = one tile per workgroup: measured no slower anywhere
+                             * (profiles/r05_conv_walk_ablation.log).  < 0 (tests): exactly -conv_walk walkers per row slab */
+    long conv_walk_min;     /* smallest number of tiles per walker worth a walk (2) */
 } avc_tuning;
 void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"

@@ -40,7 +40,7 @@ def pytest_cmdline_main(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
-    config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "slow: long-running test; a test that is BOTH gpu and slow runs only when the mark expression names `slow`")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -49,9 +49,15 @@ def pytest_collection_modifyitems(config, items):
     simulator on the GPU box (71 skips of noise in the driver's log, and tests/emu/libavc_emu.so mapped into a GPU-test process).
     Deselect it, so that a `-m gpu` run touches exactly one native library: the product's."""
     keep, drop = [], []
+    # `gpu` + `slow` (the long property-test examples on the GPU, ~4 of the suite's 13 minutes): part of a `-m "gpu and slow"` / `-m slow`
+    # run (scripts/gpu_suite.sh runs both halves; the tail of the last one is committed under profiles/), not of the plain `-m gpu` run the
+    # driver gives 20 minutes -- VERDICT r4 item 8(c).  Their simulator twins run in every CPU suite.
+    want_slow = "slow" in (getattr(config.option, "markexpr", "") or "")
     for it in items:
         cs = getattr(it, "callspec", None)
         if cs is not None and cs.params.get("kind") == "emu" and it.get_closest_marker("gpu") is not None:
+            drop.append(it)
+        elif it.get_closest_marker("gpu") is not None and it.get_closest_marker("slow") is not None and not want_slow:
             drop.append(it)
         else:
             keep.append(it)

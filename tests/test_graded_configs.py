@@ -96,7 +96,8 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
             continue
         e_eng, e_ref = e_eng / d, e_ref / d
         errs.append(e_eng)
-        assert e_eng <= max(_FLOOR[0], 2.0 * e_ref), (k, e_eng, e_ref)
+        floor = _FLOOR[0] if (not _FLOOR_ONLY[0] or k in _FLOOR_ONLY[0]) else 1e-4
+        assert e_eng <= max(floor, 2.0 * e_ref), f"{k}: engine {e_eng:.3e} vs fp64, fp32 oracle {e_ref:.3e}, floor {floor:.0e}"
         worst_e, worst_r = max(worst_e, e_eng), max(worst_r, e_ref)
         worst_ratio = max(worst_ratio, e_eng / max(e_ref, 1e-12))
     errs.sort()
@@ -106,6 +107,7 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
 
 
 _FLOOR = [1e-4]   # per-tensor gradient floor of test_train_step_matches_oracle_at_graded_shape (the fp32x3 test states its one known deviation through it)
+_FLOOR_ONLY = [None]   # ... and the tensors that relaxed floor applies to (None: all)
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU), pytest.param("gpu", "m80", 4, 1024, marks=GPU),
@@ -119,11 +121,13 @@ def test_fp32x3_mode_meets_the_same_bars(kind, cfgname, B, T):
     # own batch (T = 1024, B = 64: 65,536-term reductions) the per-tensor floor is 4e-4 instead of 1e-4 -- measured 2.1e-4 (round 3) / 2.9e-4 (round 4: other split-K order) on
     # content_encoder.conv_bank.0.weight (the exact-fp32 engine: 6.7e-6; profiles/r03_gpu_parity_report.txt); every other bar is unchanged.
     _FLOOR[0] = 4e-4 if (B, T) == (64, 1024) else 1e-4
+    _FLOOR_ONLY[0] = {"content_encoder.conv_bank.0.weight"} if (B, T) == (64, 1024) else None   # (THAT tensor only, 1e-4 elsewhere)
     try:
         test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, f"fp32x3 mode at B={B}, T={T}")
     finally:
         _COMPUTE[0] = "fp32"
         _FLOOR[0] = 1e-4
+        _FLOOR_ONLY[0] = None
 
 
 def _rel(a, b):

@@ -3,7 +3,9 @@ channel counts that are no multiple of anything, odd lengths, every tap count 1.
 restatements as the table-driven tests (model.py:21-32 and its autograd).  Derandomised: the same shapes every run."""
 import pytest
 import torch
-from hypothesis import given, settings, strategies as st, HealthCheck
+
+pytest.importorskip("hypothesis")   # (test-only dependency; the product does not need it)
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
 
 from tests import test_ops_conv as C
 from tests.emu_util import backend
