@@ -78,6 +78,23 @@ struct ConvRag {
     int ntiles;
 };
 
+// InstanceNorm1d(affine=False) + AdaIN affine + activation + residual join of the conv's OUTPUT rows, inside the conv epilogue (round 5):
+// for output rows of 16 / 32 / 64 frames a 64-column tile holds whole rows of whole samples, so the statistics need no second kernel
+// (model.py:296,341 + append_cond :77-83 + the block bodies :309-320 / :353-369).  The conv's own output `g.out` is the pre-norm row y
+// (the backward pass reads it), contiguous [B][C][T] with T = Tout x ops; `out`, `res` and the statistics are those of instnorm_fwd_kernel.
+struct ConvINFuse {
+    float* out;         // act(((y - mean) rstd) gamma + beta) [+ resmap(res)]; null: nothing fused
+    float* mean;        // [B][C] (already offset to the launch's first sample)
+    float* rstd;
+    const float* cond;  // AdaIN affine [B][cond_sb]: beta = cond[off + c], gamma = cond[off + C + c]; null = plain IN
+    long cond_sb;
+    int cond_off;
+    int res_mode, Tres; // residual rows [B][C][Tres] (contiguous), AVC_RES_IDENTITY / AVGPOOL2 / UP2
+    const float* res;
+    int C;              // channels of the normalised tensor (= M / ops)
+    int relu;
+};
+
 struct ConvArgs {
     ConvSrc x;
     int B, Cred, Tsrc;
@@ -105,6 +122,7 @@ struct ConvArgs {
     int walk_n;    // tiles of the longest walk (1: one tile per workgroup)
     int walk_rem;  // walkers [0, walk_rem) take walk_n tiles, the others walk_n - 1
     int walk_db;   // samples between two tiles of a walker (the first frame of the tile never changes along a walk)
+    ConvINFuse in;  // fused InstanceNorm epilogue (in.out == null: none)
     ConvGroup g[AVC_MAX_GROUPS];
 };
 

@@ -218,7 +218,11 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // own dispatch of the next workgroup already overlaps prologue and epilogue with the neighbours' products: walk 201 us vs 202 us, and the
 // shared kernel body paid 3-5 % for carrying the walk's state through its epilogue (registers 100 -> 120, ~80 spilled scalars).  Hence a
 // compile-time flag: WALK = false IS the round-4 kernel; the WALK instances exist for the tests and `avc_tuning.conv_walk` (default 0).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false, bool WALK = false>
+// INF instances (round 5): the InstanceNorm / AdaIN / activation / residual rows of the conv's output inside the epilogue (ConvINFuse,
+// conv_shared.h: conv_epilogue_in) -- forward launches on 64 x 64 tiles whose columns are whole rows.  A compile-time flag like WALK: as a
+// run-time branch in the one kernel body the second epilogue cost every instance its register budget (100 -> 280 VGPRs, ~130 spilled
+// scalars: the compiler evaluates both epilogues' launch-uniform conditions in front of the chunk loop).
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false, bool WALK = false, bool INF = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -535,6 +539,12 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
     }
 
     // ---- epilogue
+    if constexpr (INF) {   // fused InstanceNorm rows (conv_shared.h): the tile goes through the (now free) stage memory
+        static_assert(WM == 1 && WN == 1 && BF == 0 && !PAR && !RAG && !WALK && !MIRROR, "fused InstanceNorm epilogue: exact-fp32 forward, 64 x 64 tiles");
+        if (KG > 1) __syncthreads();   // (the other waves of this group may still be reading the split-K partials)
+        conv_epilogue_in(a, g, acc[0][0], smem, tid, wave_m, wave_n, li, h, m_tile0, q.b0);
+        return;
+    }
     if (!(a.dbg & 8)) {
         if constexpr (WALK) {
             // The epilogue's parameters (strides, bases, pointers: ~40 scalar registers) and its row / column arithmetic are invariant along a
@@ -620,7 +630,8 @@ __global__ void __launch_bounds__(AVC_THREADS) pack_weight_table_kernel(const Pa
     PackArgs p = tab[bi.x];
     for (int k = 0; k < p.nsrc; ++k) p.src[k] = (const float*)((const char*)params + (size_t)p.src[k]);
     p.dst = (float*)((char*)ws + (size_t)p.dst);
-    pack_one(p, (long)bi.y * AVC_PACK_PIECE + threadIdx.x, AVC_THREADS, (long)(bi.y + 1) * AVC_PACK_PIECE);
+    const int unit = (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) ? AVC_PACK_PIECE / 4 : AVC_PACK_PIECE;   // (K4 images are packed in 16-byte groups)
+    pack_one(p, (long)bi.y * unit + threadIdx.x, AVC_THREADS, (long)(bi.y + 1) * unit);
 }
 
 __global__ void __launch_bounds__(AVC_THREADS) pack_weight_kernel(const PackArgs p) {
@@ -633,47 +644,82 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
         return;
     }
     long total = (long)p.nchunk * p.KS * p.CK * p.Mp;
-    total = total < limit ? total : limit;
     const int GR = p.CK >> 3;
     // (the gather is one scattered read per element; with run-time integer divisions -- ~25 instructions each, five per element -- it
     // was ALU-bound: exact float-reciprocal divisions instead, valid below 2^22 = every image of the model; larger ones take the slow path)
     const bool fastok = total < (1L << 22);
     const float inv_Mp = 1.0f / (float)p.Mp, inv_KS = 1.0f / (float)p.KS, inv_GR = 1.0f / (float)GR, inv_CK = 1.0f / (float)p.CK;
+    auto value = [&](int m, int c, int j) -> float {   // (output row m, reduction channel c, tap j)
+        if (!p.dgrad) {
+            if (m < p.M && c < p.Cin) {
+                int s = p.nsrc == 1 ? 0 : m / p.rows_per_src, mm = m - s * p.rows_per_src;
+                return p.src[s][((long)mm * p.Cin + c) * p.KS + j];
+            }
+        } else {
+            if (m < p.M && c < p.Cout) {
+                int s = p.nsrc == 1 ? 0 : c / p.rows_per_src, rr = c - s * p.rows_per_src;
+                return p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
+            }
+        }
+        return 0.f;
+    };
+    if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
+        // K4 images, round 5: a thread packs one 16-BYTE GROUP -- the four k-steps u of one (chunk, tap, unit, h, row): four (K4H: eight)
+        // independent gathered reads in flight behind ONE index decode, one 16-byte store.  first / stride / limit count GROUPS here.
+        // (One element per dependent round trip -- the round-4 kernel -- was a latency chain: 93 us per step at 0.8 TB/s.)
+        const long total4 = total >> 2;   // (CK is a multiple of 8)
+        const long lim = total4 < limit ? total4 : limit;
+        for (long g4 = first; g4 < lim; g4 += stride) {
+            int m, h, unit, j, chunk;
+            if (fastok) {
+                int q = avc_fastdiv((int)g4, p.Mp, inv_Mp);
+                m = (int)g4 - q * p.Mp;
+                h = q & 1;
+                q >>= 1;
+                const int q2 = avc_fastdiv(q, GR, inv_GR);
+                unit = q - q2 * GR;
+                chunk = avc_fastdiv(q2, p.KS, inv_KS);
+                j = q2 - chunk * p.KS;
+            } else {
+                long rest = g4;
+                m = (int)(rest % p.Mp);
+                rest /= p.Mp;
+                h = (int)(rest & 1);
+                rest >>= 1;
+                unit = (int)(rest % GR);
+                rest /= GR;
+                j = (int)(rest % p.KS);
+                chunk = (int)(rest / p.KS);
+            }
+            const int red0 = chunk * p.CK + 8 * unit + h;   // reduction channel of u = 0; u steps it by 2
+            if (p.img == AVC_IMG_K4H) {   // CK / nchunk count DWORD channels: dword = bf16 pair of channels 2 red, 2 red + 1
+                float lo[4], hi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lo[u] = value(m, 2 * (red0 + 2 * u), j);
+                    hi[u] = value(m, 2 * (red0 + 2 * u) + 1, j);
+                }
+                avc_u32x4 w = {bh_pack(lo[0], hi[0]), bh_pack(lo[1], hi[1]), bh_pack(lo[2], hi[2]), bh_pack(lo[3], hi[3])};
+                *(avc_u32x4*)((unsigned*)p.dst + 4 * g4) = w;
+            } else {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = value(m, red0 + 2 * u, j);
+                *(f32x4*)(p.dst + 4 * g4) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        return;
+    }
+    total = total < limit ? total : limit;
     for (long e = first; e < total; e += stride) {
         int m, r, j, chunk;
         if (fastok) {
-            if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
-                const int u = (int)(e & 3);
-                int rest = (int)(e >> 2);
-                int q = avc_fastdiv(rest, p.Mp, inv_Mp);
-                m = rest - q * p.Mp;
-                const int h = q & 1;
-                q >>= 1;
-                int q2 = avc_fastdiv(q, GR, inv_GR);
-                const int unit = q - q2 * GR;
-                chunk = avc_fastdiv(q2, p.KS, inv_KS);
-                j = q2 - chunk * p.KS;
-                r = 8 * unit + 2 * u + h;
-            } else {
-                int q = avc_fastdiv((int)e, p.Mp, inv_Mp);
-                m = (int)e - q * p.Mp;
-                int q2 = avc_fastdiv(q, p.CK, inv_CK);
-                r = q - q2 * p.CK;
-                chunk = avc_fastdiv(q2, p.KS, inv_KS);
-                j = q2 - chunk * p.KS;
-            }
-        } else if (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) {
-            const int u = (int)(e & 3);
-            long rest = e >> 2;
-            m = (int)(rest % p.Mp);
-            rest /= p.Mp;
-            const int h = (int)(rest & 1);
-            rest >>= 1;
-            const int unit = (int)(rest % GR);
-            rest /= GR;
-            j = (int)(rest % p.KS);
-            chunk = (int)(rest / p.KS);
-            r = 8 * unit + 2 * u + h;
+            int q = avc_fastdiv((int)e, p.Mp, inv_Mp);
+            m = (int)e - q * p.Mp;
+            int q2 = avc_fastdiv(q, p.CK, inv_CK);
+            r = q - q2 * p.CK;
+            chunk = avc_fastdiv(q2, p.KS, inv_KS);
+            j = q2 - chunk * p.KS;
         } else {
             m = (int)(e % p.Mp);
             long rest = e / p.Mp;
@@ -682,23 +728,7 @@ static __device__ __forceinline__ void pack_one(const PackArgs& p, long first, l
             j = (int)(rest % p.KS);
             chunk = (int)(rest / p.KS);
         }
-        const int red = chunk * p.CK + r;
-        auto value = [&](int c) -> float {   // (m, reduction channel c, tap j)
-            if (!p.dgrad) {
-                if (m < p.M && c < p.Cin) {
-                    int s = p.nsrc == 1 ? 0 : m / p.rows_per_src, mm = m - s * p.rows_per_src;
-                    return p.src[s][((long)mm * p.Cin + c) * p.KS + j];
-                }
-            } else {
-                if (m < p.M && c < p.Cout) {
-                    int s = p.nsrc == 1 ? 0 : c / p.rows_per_src, rr = c - s * p.rows_per_src;
-                    return p.src[s][((long)rr * p.Cin + m) * p.KS + (p.KS - 1 - j)];
-                }
-            }
-            return 0.f;
-        };
-        if (p.img == AVC_IMG_K4H) ((unsigned*)p.dst)[e] = bh_pack(value(2 * red), value(2 * red + 1));   // CK / nchunk count DWORD channels
-        else p.dst[e] = value(red);
+        p.dst[e] = value(m, chunk * p.CK + r, j);
     }
 }
 
@@ -803,6 +833,15 @@ static bool conv_launch_walk(const ConvArgs& a, int tile, bool mir, int fast, di
     else return false;
     return true;
 }
+// fused InstanceNorm epilogue (ConvINFuse): forward launches on 64 x 64 tiles -- the k = 5 chunk at 8 / 16 channels, the 1x1 chunk, the generic
+// chunk loop (other kernel sizes), each with one or two split-K wave groups
+template <int KG>
+static void conv_launch_inf(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
+}
 static bool conv_walk_instance(int tile, bool mir, int fast) {
     return (tile == 11 && (fast == 1 || ((fast == -1 || fast == 14) && !mir))) || (tile == 21 && fast == 14 && !mir);
 }
@@ -821,6 +860,20 @@ static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, di
     else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
     else if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, true>), grid, block, lds, stream, a);
+}
+
+// Can the InstanceNorm of this conv's output rows run inside its epilogue (ConvINFuse)?  Exact-fp32 forward launches on 64 x 64 tiles whose
+// 64 columns are whole rows of whole samples, contiguous [B][C][T] outputs, nothing else in the epilogue.
+bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun) {
+    if (!tun.conv_in_fuse || a.mode != 0 || a.ngroups != 1 || a.rag.tile || a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4) return false;
+    if (a.Tout != 16 && a.Tout != 32 && a.Tout != 64) return false;
+    if (a.ops != 1 && a.ops != 2) return false;
+    if (a.ops == 2 && (a.M & 1)) return false;
+    if (a.act || a.res_mode != AVC_RES_NONE || a.g[0].out2 || a.g[0].mask || a.pairs) return false;
+    const int C = a.M / a.ops, Tn = a.Tout * a.ops;
+    if (a.ot != 1 || a.oc != Tn || a.ob != (long)C * Tn) return false;
+    if (conv_geom(0, a.stride, a.Tout, a.g[0].KS, 64, 0).SPT != 64 / a.Tout) return false;
+    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS) == 11;
 }
 
 // returns 0 on success, negative on unsupported geometry
@@ -844,6 +897,12 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
             if ((long)(a.Mp / 64) * ntn >= tun.tile12_wgs) tile = 12;
         }
     }
+    if (a.in.out) {   // fused InstanceNorm epilogue: only what avc_conv_in_fusable admits, on the tile it assumed
+        if (!avc_conv_in_fusable(a, tun) || (force_tile != 0 && force_tile != 11) || tile != 11) return -2;
+        if (!a.in.mean || !a.in.rstd || a.in.C != a.M / a.ops) return -2;
+        if (a.in.res && a.in.res_mode != AVC_RES_IDENTITY && a.in.res_mode != AVC_RES_UP2 && a.in.res_mode != AVC_RES_AVGPOOL2) return -2;
+        if (a.in.res && a.in.res_mode == AVC_RES_AVGPOOL2 && a.in.Tres != 2 * a.Tout * a.ops) return -2;
+    }
     if (tile == 12 && !wide_ok) return -2;
     if (tile != 11 && tile != 21 && tile != 12) return -2;
     const int BM = (tile == 21) ? 128 : 64, BN = (tile == 12) ? 128 : 64;
@@ -862,6 +921,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     // profiles/r03_bf16s_tune.log)
     if (!rag && a.bf16 != AVC_COMPUTE_BF16S && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
+    if (a.in.out && lds < AVC_IN_LDS_BYTES) lds = AVC_IN_LDS_BYTES;
     if (lds > 160 * 1024) return -5;
     if (tun.conv_min_lds > 0 && (size_t)tun.conv_min_lds > lds && tun.conv_min_lds <= 160 * 1024) lds = (size_t)tun.conv_min_lds;   // (fewer co-resident workgroups)
     dim3 block(AVC_THREADS * kgroups);
@@ -885,7 +945,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     a.walk_rem = (int)grid.x;
     a.walk_db = 0;
     bool walk = false;
-    if (tun.conv_walk != 0 && !rag && !a.par && bf == 0 && kgroups == 1 && AVC_CONV_STAGES == 2 && conv_walk_instance(tile, mir, fast)) {
+    if (tun.conv_walk != 0 && !a.in.out && !rag && !a.par && bf == 0 && kgroups == 1 && AVC_CONV_STAGES == 2 && conv_walk_instance(tile, mir, fast)) {
         const int ntn = (int)grid.x;
         const int tps = a.Tout >= BN ? avc_cdiv(a.Tout, BN) : 1;
         const int SPT = a.Tout >= BN ? 1 : conv_geom(a.mode, a.stride, a.Tout, a.g[0].KS, BN, 0).SPT;
@@ -912,7 +972,11 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         else if (bf == 1) { CALL_(1); }      \
         else { CALL_(0); }                   \
     } while (0)
-    if (walk) {
+    if (a.in.out) {
+        const int f = (fast == 1 || fast == 2 || fast == 14) ? fast : 0;   // (the k = 5 chunk at 32 channels takes the generic loop)
+        if (kgroups == 2) conv_launch_inf<2>(a, f, grid, block, lds, stream);
+        else conv_launch_inf<1>(a, f, grid, block, lds, stream);
+    } else if (walk) {
         if (!conv_launch_walk(a, tile, mir, fast, grid, block, lds, stream)) return -2;
     } else if (rag) {
         if (bf == 2) return -2;   // (ragged plans run fp32 storage)

@@ -185,6 +185,114 @@ static __device__ __forceinline__ void conv_store_frag(const ConvEpi& a, const C
     }
 }
 
+// ---- InstanceNorm / AdaIN / activation / residual fused into the epilogue of a 64 x 64 tile whose columns are whole rows of whole samples
+// (Tout = 16 | 32 | 64: 4 | 2 | 1 samples per tile).  The accumulator fragments (+ bias) go through LDS once, row-major; then every lane
+// owns 16 consecutive frames of one conv row: statistics by xor-shuffles over the 1 / 2 / 4 lanes of a row segment (and the partner row of
+// a pixel-shuffling conv, model.py:52-59, whose rows 2c, 2c + 1 ARE frames 2t, 2t + 1 of channel c), the same two-pass arithmetic and the
+// same explicitly rounded x_hat / pre-activation sequence as instnorm_fwd_kernel (rowops.hip), 64-byte contiguous stores of y and out.
+#define AVC_IN_LDT 68   // floats per tile row in LDS (16-byte aligned rows)
+#define AVC_IN_LDS_BYTES (64 * AVC_IN_LDT * 4)
+static __device__ __forceinline__ float4 conv_in_res4(const float* rrow, int mode, int t, int Tres) {   // = res4 of rowops.hip
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == AVC_RES_IDENTITY) {
+        r = *(const float4*)(rrow + t);
+    } else if (mode == AVC_RES_UP2) {
+        float2 ab = *(const float2*)(rrow + (t >> 1));
+        r = make_float4(ab.x, ab.x, ab.y, ab.y);
+    } else if (mode == AVC_RES_AVGPOOL2) {   // (fused rows: Tres == 2 T, multiples of 16)
+        float4 p = *(const float4*)(rrow + 2 * t), q = *(const float4*)(rrow + 2 * t + 4);
+        r = make_float4((p.x + p.y) * 0.5f, (p.z + p.w) * 0.5f, (q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
+    }
+    return r;
+}
+static __device__ void conv_epilogue_in(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, float* tile, int tid, int wave_m, int wave_n,
+                                        int li, int h, int m_tile0, int b0) {
+    const ConvINFuse& f = a.in;
+    const int col = wave_n * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m_tile0 + row;
+        const float bs = g.bias ? g.bias[m < a.M ? m : a.M - 1] : 0.f;
+        tile[row * AVC_IN_LDT + col] = acc[r] + bs;
+    }
+    __syncthreads();
+    const int r = tid >> 2, qd = tid & 3;
+    const int m = m_tile0 + r;
+    const int Tout = a.Tout, lpr = Tout >> 4;             // lanes per row segment of one sample: 1, 2, 4
+    const int bl = (16 * qd) / Tout, t0 = 16 * qd - bl * Tout;
+    const int b = b0 + bl;
+    const bool valid = m < a.M && b < a.B;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 x = *(const float4*)(tile + r * AVC_IN_LDT + 16 * qd + 4 * k);
+        v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
+    }
+    const int ops = a.ops;                                  // 1, or 2 = pixel shuffle
+    const int c = ops == 2 ? m >> 1 : m, j = ops == 2 ? (m & 1) : 0;
+    const int Tn = Tout * ops;
+    const float invT = 1.0f / (float)Tn;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (v[4 * k] + v[4 * k + 1]) + (v[4 * k + 2] + v[4 * k + 3]);
+    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+    if (ops == 2) s += __shfl_xor(s, 4);
+    const float mean = s * invT;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = v[4 * k] - mean, dy = v[4 * k + 1] - mean, dz = v[4 * k + 2] - mean, dw = v[4 * k + 3] - mean;
+        ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o);
+    if (ops == 2) ss += __shfl_xor(ss, 4);
+    const float rstd = 1.0f / sqrtf(ss * invT + AVC_IN_EPS);
+    int fbase = t0;                                         // first frame of this lane's 16 values inside the normalised row
+    if (ops == 2) {   // the two lanes of a channel exchange halves: each then holds 16 CONSECUTIVE frames
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float rcv = __shfl_xor(j ? v[i] : v[8 + i], 4);
+            w[2 * i] = j ? rcv : v[i];
+            w[2 * i + 1] = j ? v[8 + i] : rcv;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = w[i];
+        fbase = 2 * t0 + 16 * j;
+    }
+    if (!valid) return;
+    const long rowi = (long)b * f.C + c;
+    if (qd % lpr == 0 && j == 0) {
+        f.mean[rowi] = mean;
+        f.rstd[rowi] = rstd;
+    }
+    float gamma = 1.f, beta = 0.f;
+    if (f.cond) {
+        const float* cr = f.cond + (long)b * f.cond_sb + f.cond_off;
+        beta = cr[c];
+        gamma = cr[f.C + c];
+    }
+    float4 rv[4];
+    const float* rrow = f.res ? f.res + rowi * f.Tres : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rv[k] = rrow ? conv_in_res4(rrow, f.res_mode, fbase + 4 * k, f.Tres) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* yrow = g.out + rowi * Tn + fbase;
+    float* orow = f.out + rowi * Tn + fbase;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(float4*)(yrow + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = in_preact(in_xhat(v[4 * k + e], mean, rstd), gamma, beta);
+            o[e] = f.relu ? avc_act(w, a.slope) : w;
+        }
+        *(float4*)(orow + 4 * k) = make_float4(o[0] + rv[k].x, o[1] + rv[k].y, o[2] + rv[k].z, o[3] + rv[k].w);
+    }
+}
+
 // ---- the same epilogue on bf16 PAIR tensors (bf16_pairs.h): rows m (even) and m + 1 of the lane's column are one dword.
 // Strides are dword strides of the [B][C/2][T] tensors; M is even; time stride 1.
 // the (up to two) dwords of a residual pair row that conv_res_value's modes combine, as element offsets inside the row (time stride 1)

@@ -999,6 +999,26 @@ static int in_fwd(float slope, const float* y, int Bn, int C, int T, const float
     return avc_launch_in_fwd(a, s);
 }
 
+// conv + the InstanceNorm rows of its output: inside the conv's epilogue where a 64-column tile holds whole rows (avc_conv_in_fusable:
+// rows of 16 / 32 / 64 frames, exact fp32), else the row kernel behind the conv.  a.g[0].out = y (pre-norm, read by the backward pass).
+static int conv_in_fwd(const avc_plan* p, ConvArgs& a, float slope, int Bn, int C, int T, const float* cond, long cond_sb, int cond_off,
+                       const float* res, int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0,
+                       bool pairs = false, int planar = 0, int nv = 0) {
+    if (Bfull == 0) Bfull = Bn;
+    if (!pairs && avc_conv_in_fusable(a, p->tun)) {
+        a.in.out = out;
+        a.in.mean = stats + (long)b0 * C;
+        a.in.rstd = stats + (long)Bfull * C + (long)b0 * C;
+        a.in.cond = cond; a.in.cond_sb = cond_sb; a.in.cond_off = cond_off;
+        a.in.res = res; a.in.res_mode = res ? res_mode : 0; a.in.Tres = Tres;
+        a.in.C = C; a.in.relu = 1;
+        return avc_launch_conv(a, s, 0, p->tun);
+    }
+    int rc = avc_launch_conv(a, s, 0, p->tun);
+    if (rc) return rc;
+    return in_fwd(slope, a.g[0].out, Bn, C, T, cond, cond_sb, cond_off, res, res_mode, Tres, out, stats, s, Bfull, b0, pairs, planar, nv);
+}
+
 static int in_bwd(float slope, const float* g, const float* y, const float* stats, int Bn, int C, int T, const float* cond,
                   long cond_sb, int cond_off, float* dy, float* dcond, hipStream_t s, bool pairs = false, int nv = 0) {
     INBwdArgs a;
@@ -1090,8 +1110,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
         RUN(enc_front(p, e, params, ws, x, sxb, sxc, sxt, s));
         ConvArgs a = mk_fwd(p, SL, p->layers[e.in_conv], params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 0);
-        RUN(avc_launch_conv(a, s, 0, p->tun));
-        RUN(in_fwd(SL, ws + e.h0, B, Cc, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s, 0, 0, bh, 0, NV));
+        RUN(conv_in_fwd(p, a, SL, B, Cc, e.T[0], nullptr, 0, 0, nullptr, 0, 0, ws + e.out[0], ws + e.st0, s, 0, 0, bh, 0, NV));
         return 0;
     };
     // ---------------- speaker encoder (model.py:265-277), concurrent with the content encoder
@@ -1161,12 +1180,10 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y1[l], B, Cc, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s, 0, 0, bh, 0, NV));
+            RUN(conv_in_fwd(p, a, SL, B, Cc, Ti, nullptr, 0, 0, nullptr, 0, 0, ws + e.a1[l], ws + e.st1[l], s, 0, 0, bh, 0, NV));
             ConvArgs b = mk_fwd(p, SL, p->layers[e.c2[l]], params, ws, ws + e.a1[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y2[l], (long)C * To, To, 1, 0);
             const int rmode = e.c.subsample[l] > 1 ? AVC_RES_AVGPOOL2 : AVC_RES_IDENTITY;
-            RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + e.y2[l], B, Cc, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s, 0, 0, bh, 0, NV));
+            RUN(conv_in_fwd(p, b, SL, B, Cc, To, nullptr, 0, 0, ws + e.out[l], rmode, Ti, ws + e.out[l + 1], ws + e.st2[l], s, 0, 0, bh, 0, NV));
         }
         const int Tb = p->Tb;
         ConvArgs h = mk_fwd(p, SL, p->layers[e.heads], params, ws, ws + e.out[e.n], (long)C * Tb, Tb, 1, B, Tb, ws + p->muls, (long)2 * e.c.c_out * Tb, Tb, 1, 0);
@@ -1198,8 +1215,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             const float* cond = ws + d.cond + (long)b0 * csb;
             if (ph == 0) {
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.in_conv], params, ws, ws + d.z + oz, (long)Cz * Tb, Tb, 1, Bn, Tb, ws + d.y0 + ob0, (long)C * Tb, Tb, 1, 0);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y0 + ob0, Bn, Cc, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0, bh, 0, NV));
+                RUN(conv_in_fwd(p, a, SL, Bn, Cc, Tb, nullptr, 0, 0, nullptr, 0, 0, ws + d.out[0] + ob0, ws + d.st0, s, B, b0, bh, 0, NV));
                 return 0;
             }
             if (ph == 2 * d.n + 1) {
@@ -1215,8 +1231,7 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             const long oi = (long)b0 * C * Ti, oo = (long)b0 * C * To;
             if ((ph - 1) % 2 == 0) {
                 ConvArgs a = mk_fwd(p, SL, p->layers[d.c1[l]], params, ws, ws + d.out[l] + oi, (long)C * Ti, Ti, 1, Bn, Ti, ws + d.y1[l] + oi, (long)C * Ti, Ti, 1, 0);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
-                RUN(in_fwd(SL, ws + d.y1[l] + oi, Bn, Cc, Ti, cond, csb, (2 * l) * 2 * Cc, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0, bh, 0, NV));
+                RUN(conv_in_fwd(p, a, SL, Bn, Cc, Ti, cond, csb, (2 * l) * 2 * Cc, nullptr, 0, 0, ws + d.a1[l] + oi, ws + d.st1[l], s, B, b0, bh, 0, NV));
                 return 0;
             }
             // second conv: C*up channels, pixel-shuffled on store into [B, C, Ti*up]  (model.py:359-361)
@@ -1226,9 +1241,8 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
                 b.ops = 1;
                 b.ob = (long)C * To; b.oc = Ti;
             }
-            RUN(avc_launch_conv(b, s, 0, p->tun));
-            RUN(in_fwd(SL, ws + d.y2[l] + oo, Bn, Cc, To, cond, csb, (2 * l + 1) * 2 * Cc, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
-                                ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0, bh, (bh && up > 1) ? 1 : 0, NV));
+            RUN(conv_in_fwd(p, b, SL, Bn, Cc, To, cond, csb, (2 * l + 1) * 2 * Cc, ws + d.out[l] + oi, up > 1 ? AVC_RES_UP2 : AVC_RES_IDENTITY, Ti,
+                            ws + d.out[l + 1] + oo, ws + d.st2[l], s, B, b0, bh, (bh && up > 1) ? 1 : 0, NV));
             return 0;
         };
         const int nph = 2 * d.n + 2;

@@ -35,6 +35,7 @@ static avc_tuning make_default_tuning() {
     t.dec_wgrad_wgs = 128;
     t.conv_walk = 0;
     t.conv_walk_min = 2;
+    t.conv_in_fuse = 1;
     return t;
 }
 const avc_tuning& avc_default_tuning() {
@@ -62,7 +63,7 @@ int avc_set_tuning(const char* name, int value) {
     AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
     AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(side_prio) AVC_TUNE_FIELD(wgrad_batch_units)
     AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(wgrad_cw8) AVC_TUNE_FIELD(dec_wgrad_flush) AVC_TUNE_FIELD(dec_wgrad_wgs)
-    AVC_TUNE_FIELD(conv_walk) AVC_TUNE_FIELD(conv_walk_min)
+    AVC_TUNE_FIELD(conv_walk) AVC_TUNE_FIELD(conv_walk_min) AVC_TUNE_FIELD(conv_in_fuse)
 #undef AVC_TUNE_FIELD
     if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }
     return -1;
@@ -94,6 +95,9 @@ static void op_compute(ConvArgs& a) {
     a.bf16 = d == 4 ? AVC_COMPUTE_BF16S : d;
     a.pairs = d == AVC_COMPUTE_BF16S ? 1 : 0;
 }
+
+int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
+                     int Tres, float* out, float* mean, float* rstd, void* stream);
 
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
     int CK = avc_conv_ck(avc_op_tuning(), KS);
@@ -154,6 +158,45 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
     a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
     if (tile == 97) { a.img = AVC_IMG_X3; a.g[0].CK = KS == 1 ? 32 : 16; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK); }   // wp is a split-bf16 image (avc_pack_weight_x3)
     return avc_launch_conv(a, (hipStream_t)stream, tile, avc_op_tuning());
+}
+
+// y = conv1d(reflect_pad(x)) + bias (pixel-shuffled on store when ops == 2), then out = act(InstanceNorm(y) * gamma + beta) [+ resmap(res)] with the
+// statistics saved -- ONE launch where the conv's 64-column tile holds whole rows (rows of 16 / 32 / 64 conv frames: the fused epilogue
+// of csrc/conv_shared.h), else the conv and the row kernel.  *fused (optional) reports which.  y / out / res are contiguous [B][C][T],
+// C = Cout / ops, T = Tout x ops.  Reference: model.py:309-320 / :353-369 (conv -> norm -> [append_cond] -> act [-> + residual]).
+int avc_conv1d_in_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp, const float* bias, int Cout, int KS,
+                      int stride, int ops, float* y, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
+                      int Tres, float* out, float* mean, float* rstd, int* fused, void* stream) {
+    if (op_bh() || (ops != 1 && ops != 2) || Cout % ops) return -2;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    op_compute(a);
+    a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
+    a.B = B; a.Cred = Cin; a.Tsrc = Tin;
+    a.mode = 0; a.stride = stride;
+    const int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
+    a.M = Cout; a.Mp = avc_cdiv(Cout, 128) * 128;
+    a.Tout = (Tin + padL + padR - KS) / stride + 1;
+    const int C = Cout / ops, T = a.Tout * ops;
+    a.ob = (long)C * T; a.oc = T; a.ot = 1; a.ops = ops;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.ngroups = 1;
+    a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
+    a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = y;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
+    a.img = AVC_IMG_K4;
+    const bool fuse = avc_conv_in_fusable(a, avc_op_tuning());
+    if (fused) *fused = fuse ? 1 : 0;
+    if (fuse) {
+        a.in.out = out; a.in.mean = mean; a.in.rstd = rstd;
+        a.in.cond = cond; a.in.cond_sb = cond_sb; a.in.cond_off = cond_off;
+        a.in.res = res; a.in.res_mode = res ? res_mode : 0; a.in.Tres = Tres;
+        a.in.C = C; a.in.relu = relu ? 1 : 0;
+        return avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
+    }
+    int rc = avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
+    if (rc) return rc;
+    return avc_instnorm_fwd(y, B, C, T, cond, cond_sb, cond_off, relu, res, res_mode, Tres, out, mean, rstd, stream);
 }
 
 // dx = conv1d_input_grad(dy) including the adjoint of the reflect padding

@@ -165,6 +165,8 @@ typedef struct avc_tuning {
                              * this one.  Bit-identical results.  0 (default) = one tile per workgroup: measured no slower anywhere
                              * (profiles/r05_conv_walk_ablation.log).  < 0 (tests): exactly -conv_walk walkers per row slab */
     long conv_walk_min;     /* smallest number of tiles per walker worth a walk (2) */
+    long conv_in_fuse;      /* 1: InstanceNorm / AdaIN / activation / residual of rows of 16 / 32 / 64 frames run inside the producing conv's epilogue
+                             * (the 64-column tile holds whole rows; csrc/conv_shared.h: conv_epilogue_in) instead of a row kernel of their own */
 } avc_tuning;
 void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"
@@ -345,6 +347,14 @@ int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, lon
 int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const float* rstd, int B, int C, int T,
                      const float* cond, long cond_sb, int cond_off, int relu, float* dy, float* dcond, long dcond_sb,
                      int dcond_off, void* stream);
+/* conv -> InstanceNorm -> [append_cond] -> act [-> + residual] of one block half (model.py:309-320 / :353-369), exact fp32:
+ * y = conv1d(reflect_pad(x)) + bias, pixel-shuffled on store when ops == 2 (model.py:52-59); out / mean / rstd as avc_instnorm_fwd over the
+ * rows of y.  y, out, res are contiguous [B][C][T] with C = Cout / ops, T = Tout * ops.  Where the conv's output rows are 16 / 32 / 64
+ * frames long, a 64-column tile of the conv holds whole rows and the normalisation runs INSIDE the conv's epilogue (one launch;
+ * avc_tuning.conv_in_fuse); otherwise the conv launch is followed by the row kernel.  *fused (may be NULL) reports which happened. */
+int avc_conv1d_in_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp, const float* bias, int Cout, int KS,
+                      int stride, int ops, float* y, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
+                      int Tres, float* out, float* mean, float* rstd, int* fused, void* stream);
 
 #ifdef __cplusplus
 }

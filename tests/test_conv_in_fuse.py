@@ -1,0 +1,105 @@
+"""InstanceNorm / AdaIN / activation / residual rows inside the producing conv's epilogue (round 5, csrc/conv_shared.h: conv_epilogue_in)
+against the oracle's restatement of the block halves (model.py:309-320 conv -> norm -> act [-> + pooled residual], :353-369 conv ->
+[pixel shuffle] -> norm -> append_cond -> act [-> + upsampled residual]) -- and against the two-launch path (conv, then the row kernel):
+same y bit for bit, same statistics and outputs to rounding (the sums run in another order)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import avc_oracle as O
+from tests.emu_util import KINDS, P, backend
+from tests.test_ops_conv import pack
+
+GPU = pytest.mark.gpu
+
+
+def run(lib, dev, x, w, b, stride, ops, cond, cond_off, relu, res, res_mode):
+    B, Cin, Tin = x.shape
+    Cout, _, KS = w.shape
+    wp = pack(lib, dev, [w], 0)
+    To = O.pad_conv(torch.zeros(1, Cin, Tin), torch.zeros(Cout, Cin, KS), None, stride).shape[2]
+    C, T = Cout // ops, To * ops
+    y = torch.full((B, C, T), float("nan"), device=dev)
+    out = torch.full_like(y, float("nan"))
+    mean = torch.full((B * C,), float("nan"), device=dev)
+    rstd = torch.full_like(mean, float("nan"))
+    fused = ctypes.c_int(-1)
+    rc = lib.avc_conv1d_in_fwd(P(x), x.stride(0), x.stride(1), x.stride(2), B, Cin, Tin, P(wp), P(b), Cout, KS, stride, ops, P(y),
+                               P(cond), cond.stride(0) if cond is not None else 0, cond_off, relu, P(res), res_mode,
+                               res.shape[2] if res is not None else 0, P(out), P(mean), P(rstd), ctypes.byref(fused), None)
+    assert rc == 0, rc
+    return y, out, mean, rstd, fused.value
+
+
+def reference(x, w, b, stride, ops, cond, cond_off, relu, res, res_mode):
+    y = O.pad_conv(x, w, b, stride)
+    if ops == 2:
+        y = O.pixel_shuffle_1d(y, 2)
+    C = y.shape[1]
+    o = F.instance_norm(y, eps=1e-5)
+    if cond is not None:
+        beta, gamma = cond[:, cond_off:cond_off + C], cond[:, cond_off + C:cond_off + 2 * C]
+        o = o * gamma[:, :, None] + beta[:, :, None]
+    if relu == 1:
+        o = torch.relu(o)
+    elif relu == 2:
+        o = F.leaky_relu(o, 0.01)
+    if res is not None:
+        o = o + {1: lambda r: r, 2: lambda r: O.avg_pool_ceil(r, 2), 5: lambda r: O.upsample_nearest(r, 2)}[res_mode](res)
+    return y, o
+
+
+# B, Cin, Cout, Tin, KS, stride, ops, affine, relu, res_mode, fused expected
+CASES = [
+    (3, 16, 32, 64, 5, 1, 1, False, 1, 0, 1),     # one sample per tile, plain IN + ReLU
+    (5, 16, 40, 32, 5, 1, 1, False, 1, 1, 1),     # two samples per tile (odd batch: ragged last tile), identity residual, 40 of 64 rows valid
+    (7, 24, 64, 16, 5, 1, 1, True, 2, 0, 1),      # four samples per tile, AdaIN + LeakyReLU
+    (3, 16, 32, 64, 5, 2, 1, False, 1, 2, 1),     # stride 2 -> rows of 32, ceil-mode pooled residual (model.py:319)
+    (3, 16, 64, 32, 5, 1, 2, True, 1, 5, 1),      # pixel shuffle: rows of 64 from conv rows (2c, 2c + 1), upsampled residual (model.py:362-369)
+    (2, 16, 128, 64, 5, 1, 2, True, 1, 1, 1),     # ... rows of 128 frames out of 64-frame conv rows, two row tiles
+    (9, 128, 128, 16, 5, 1, 1, False, 1, 0, 1),   # 16 K-chunks: the split-K wave groups in front of the fused epilogue
+    (2, 16, 32, 128, 5, 1, 1, False, 1, 0, 0),    # rows of 128 frames: not fusable -> conv + row kernel
+    (2, 16, 32, 24, 5, 1, 1, False, 1, 0, 0),     # a length that does not tile 64 columns: not fusable
+    pytest.param(64, 128, 128, 64, 5, 1, 1, True, 1, 1, 1, marks=GPU),
+    pytest.param(64, 128, 256, 32, 5, 1, 2, True, 1, 5, 1, marks=GPU),
+    pytest.param(256, 128, 128, 32, 5, 2, 1, False, 1, 2, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,Tin,KS,stride,ops,affine,relu,res_mode,want_fused", CASES)
+def test_conv_in_fused_epilogue(kind, B, Cin, Cout, Tin, KS, stride, ops, affine, relu, res_mode, want_fused):
+    if kind == "emu" and B * Cin * Cout * Tin * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 13 + Tin)
+    x = torch.randn(B, Cin, Tin, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    C = Cout // ops
+    To = O.pad_conv(torch.zeros(1, Cin, Tin), torch.zeros(Cout, Cin, KS), None, stride).shape[2] * ops
+    cond = torch.randn(B, 4 * C + 8, generator=g) if affine else None
+    cond_off = 2 * C + 8 if affine else 0
+    Tres = {0: 0, 1: To, 2: 2 * To, 5: To // 2}[res_mode]
+    res = torch.randn(B, C, Tres, generator=g) if res_mode else None
+    y_ref, o_ref = reference(x, w, b, stride, ops, cond, cond_off, relu, res, res_mode)
+    d = lambda t: None if t is None else t.to(dev)
+    y, out, mean, rstd, fused = run(lib, dev, d(x), d(w), d(b), stride, ops, d(cond), cond_off, relu, d(res), res_mode)
+    assert fused == want_fused
+    torch.testing.assert_close(y.cpu(), y_ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(out.cpu(), o_ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(mean.cpu().view(B, C), y_ref.mean(2), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu().view(B, C), 1.0 / torch.sqrt(y_ref.var(2, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
+    if fused:   # the two-launch path: the same conv kernel in front of the row kernel
+        assert lib.avc_set_tuning(b"conv_in_fuse", 0) == 0
+        try:
+            y2, out2, mean2, rstd2, fused2 = run(lib, dev, d(x), d(w), d(b), stride, ops, d(cond), cond_off, relu, d(res), res_mode)
+        finally:
+            lib.avc_set_tuning(b"conv_in_fuse", 1)
+        assert fused2 == 0
+        assert torch.equal(y, y2)   # y = accumulator + bias either way
+        torch.testing.assert_close(out, out2, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(mean, mean2, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rstd, rstd2, rtol=1e-5, atol=1e-6)
