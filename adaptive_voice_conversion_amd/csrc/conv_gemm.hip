@@ -540,9 +540,10 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
 
     // ---- epilogue
     if constexpr (INF) {   // fused InstanceNorm rows (conv_shared.h): the tile goes through the (now free) stage memory
-        static_assert(WM == 1 && WN == 1 && BF == 0 && !PAR && !RAG && !WALK && !MIRROR, "fused InstanceNorm epilogue: exact-fp32 forward, 64 x 64 tiles");
+        static_assert(WM == 1 && WN == 1 && (BF == 0 || BF == 2) && !PAR && !RAG && !WALK && !MIRROR, "fused InstanceNorm epilogue: forward, 64 x 64 tiles, fp32 or bf16 pairs");
         if (KG > 1) __syncthreads();   // (the other waves of this group may still be reading the split-K partials)
-        conv_epilogue_in(a, g, acc[0][0], smem, tid, wave_m, wave_n, li, h, m_tile0, q.b0);
+        if constexpr (BF == 2) conv_epilogue_in_pairs(a, g, acc[0][0], smem, tid, wave_m, wave_n, li, h, m_tile0, q.b0);
+        else conv_epilogue_in(a, g, acc[0][0], smem, tid, wave_m, wave_n, li, h, m_tile0, q.b0);
         return;
     }
     if (!(a.dbg & 8)) {
@@ -835,12 +836,12 @@ static bool conv_launch_walk(const ConvArgs& a, int tile, bool mir, int fast, di
 }
 // fused InstanceNorm epilogue (ConvINFuse): forward launches on 64 x 64 tiles -- the k = 5 chunk at 8 / 16 channels, the 1x1 chunk, the generic
 // chunk loop (other kernel sizes), each with one or two split-K wave groups
-template <int KG>
+template <int KG, int BF>
 static void conv_launch_inf(const ConvArgs& a, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
-    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
-    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, 0, false, false, false, true>), grid, block, lds, stream, a);
+    if (fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
 }
 static bool conv_walk_instance(int tile, bool mir, int fast) {
     return (tile == 11 && (fast == 1 || ((fast == -1 || fast == 14) && !mir))) || (tile == 21 && fast == 14 && !mir);
@@ -864,16 +865,23 @@ static void conv_launch_par(const ConvArgs& a, bool mir, int fast, dim3 grid, di
 
 // Can the InstanceNorm of this conv's output rows run inside its epilogue (ConvINFuse)?  Exact-fp32 forward launches on 64 x 64 tiles whose
 // 64 columns are whole rows of whole samples, contiguous [B][C][T] outputs, nothing else in the epilogue.
-bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun) {
-    if (!tun.conv_in_fuse || a.mode != 0 || a.ngroups != 1 || a.rag.tile || a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4) return false;
+bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun, int res_mode, int Tres) {
+    // the residual the fused rows join: whole 16-byte vectors of a row of the matching length (an odd-length source of a ceil-mode pool,
+    // model.py:319, keeps the row kernel)
+    const int Tn_ = a.Tout * a.ops;
+    if (res_mode != AVC_RES_NONE && !((res_mode == AVC_RES_IDENTITY && Tres == Tn_) || (res_mode == AVC_RES_UP2 && 2 * Tres == Tn_) ||
+                                      (res_mode == AVC_RES_AVGPOOL2 && Tres == 2 * Tn_))) return false;
+    if (!tun.conv_in_fuse || a.mode != 0 || a.ngroups != 1 || a.rag.tile) return false;
+    const bool bh = a.bf16 == AVC_COMPUTE_BF16S;   // bf16 pair storage: pair rows in, pair rows out, no pixel shuffle (its rows are "planar")
+    if (bh ? (a.img != AVC_IMG_K4H || !a.pairs || a.ops != 1 || (a.M & 1) || a.x.ps != 1 || a.x.st != 1) : (a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4 || a.pairs)) return false;
     if (a.Tout != 16 && a.Tout != 32 && a.Tout != 64) return false;
     if (a.ops != 1 && a.ops != 2) return false;
     if (a.ops == 2 && (a.M & 1)) return false;
-    if (a.act || a.res_mode != AVC_RES_NONE || a.g[0].out2 || a.g[0].mask || a.pairs) return false;
-    const int C = a.M / a.ops, Tn = a.Tout * a.ops;
+    if (a.act || a.res_mode != AVC_RES_NONE || a.g[0].out2 || a.g[0].mask) return false;
+    const int C = (bh ? a.M / 2 : a.M) / a.ops, Tn = a.Tout * a.ops;   // rows per sample (pair rows with bh)
     if (a.ot != 1 || a.oc != Tn || a.ob != (long)C * Tn) return false;
     if (conv_geom(0, a.stride, a.Tout, a.g[0].KS, 64, 0).SPT != 64 / a.Tout) return false;
-    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS) == 11;
+    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS * (bh ? 2 : 1)) == 11;
 }
 
 // returns 0 on success, negative on unsupported geometry
@@ -898,10 +906,8 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         }
     }
     if (a.in.out) {   // fused InstanceNorm epilogue: only what avc_conv_in_fusable admits, on the tile it assumed
-        if (!avc_conv_in_fusable(a, tun) || (force_tile != 0 && force_tile != 11) || tile != 11) return -2;
+        if (!avc_conv_in_fusable(a, tun, a.in.res ? a.in.res_mode : AVC_RES_NONE, a.in.Tres) || (force_tile != 0 && force_tile != 11) || tile != 11) return -2;
         if (!a.in.mean || !a.in.rstd || a.in.C != a.M / a.ops) return -2;
-        if (a.in.res && a.in.res_mode != AVC_RES_IDENTITY && a.in.res_mode != AVC_RES_UP2 && a.in.res_mode != AVC_RES_AVGPOOL2) return -2;
-        if (a.in.res && a.in.res_mode == AVC_RES_AVGPOOL2 && a.in.Tres != 2 * a.Tout * a.ops) return -2;
     }
     if (tile == 12 && !wide_ok) return -2;
     if (tile != 11 && tile != 21 && tile != 12) return -2;
@@ -974,8 +980,9 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     } while (0)
     if (a.in.out) {
         const int f = (fast == 1 || fast == 2 || fast == 14) ? fast : 0;   // (the k = 5 chunk at 32 channels takes the generic loop)
-        if (kgroups == 2) conv_launch_inf<2>(a, f, grid, block, lds, stream);
-        else conv_launch_inf<1>(a, f, grid, block, lds, stream);
+        if (bf == 2) conv_launch_inf<1, 2>(a, f, grid, block, lds, stream);   // (pair storage runs without split-K wave groups)
+        else if (kgroups == 2) conv_launch_inf<2, 0>(a, f, grid, block, lds, stream);
+        else conv_launch_inf<1, 0>(a, f, grid, block, lds, stream);
     } else if (walk) {
         if (!conv_launch_walk(a, tile, mir, fast, grid, block, lds, stream)) return -2;
     } else if (rag) {

@@ -293,6 +293,116 @@ static __device__ void conv_epilogue_in(const ConvArgs& a, const ConvGroup& g, c
     }
 }
 
+// ... on bf16 PAIR tensors (compute_dtype "bf16", bf16_pairs.h; ops == 1): y is rounded to bf16 FIRST -- statistics, x_hat and the activation
+// decision are taken from the stored values, exactly what instnorm_fwd_pairs_kernel reads back and what the backward pass recomputes --
+// then the lanes of rows (2p, 2p + 1) exchange halves: each packs 8 frames of the pair row (two 16-byte stores per tensor).
+typedef unsigned conv_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned conv_u32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void conv_in_res_pairs4(const unsigned* rrow, int mode, int t, float (&lo)[4], float (&hi)[4]) {   // = res_pairs4 of rowops_pairs.hip
+    if (mode == AVC_RES_IDENTITY) {
+        const conv_u32x4 v = *(const conv_u32x4*)(rrow + t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = bh_lo(v[k]); hi[k] = bh_hi(v[k]); }
+    } else if (mode == AVC_RES_UP2) {
+        const conv_u32x2 v = *(const conv_u32x2*)(rrow + (t >> 1));
+        lo[0] = lo[1] = bh_lo(v[0]); hi[0] = hi[1] = bh_hi(v[0]);
+        lo[2] = lo[3] = bh_lo(v[1]); hi[2] = hi[3] = bh_hi(v[1]);
+    } else if (mode == AVC_RES_AVGPOOL2) {
+        const conv_u32x4 p = *(const conv_u32x4*)(rrow + 2 * t), q = *(const conv_u32x4*)(rrow + 2 * t + 4);
+        lo[0] = (bh_lo(p[0]) + bh_lo(p[1])) * 0.5f; hi[0] = (bh_hi(p[0]) + bh_hi(p[1])) * 0.5f;
+        lo[1] = (bh_lo(p[2]) + bh_lo(p[3])) * 0.5f; hi[1] = (bh_hi(p[2]) + bh_hi(p[3])) * 0.5f;
+        lo[2] = (bh_lo(q[0]) + bh_lo(q[1])) * 0.5f; hi[2] = (bh_hi(q[0]) + bh_hi(q[1])) * 0.5f;
+        lo[3] = (bh_lo(q[2]) + bh_lo(q[3])) * 0.5f; hi[3] = (bh_hi(q[2]) + bh_hi(q[3])) * 0.5f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lo[k] = hi[k] = 0.f;
+    }
+}
+static __device__ void conv_epilogue_in_pairs(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, float* tile, int tid, int wave_m, int wave_n,
+                                              int li, int h, int m_tile0, int b0) {
+    const ConvINFuse& f = a.in;
+    const int col = wave_n * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m_tile0 + row;
+        const float bs = g.bias ? g.bias[m < a.M ? m : a.M - 1] : 0.f;
+        tile[row * AVC_IN_LDT + col] = acc[r] + bs;
+    }
+    __syncthreads();
+    const int r = tid >> 2, qd = tid & 3;
+    const int m = m_tile0 + r, odd = m & 1;
+    const int Tout = a.Tout, lpr = Tout >> 4;
+    const int bl = (16 * qd) / Tout, t0 = 16 * qd - bl * Tout;
+    const int b = b0 + bl;
+    const bool valid = m < a.M && b < a.B;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 x = *(const float4*)(tile + r * AVC_IN_LDT + 16 * qd + 4 * k);
+        v[4 * k] = bh_lo(bh_pack(x.x, 0.f)); v[4 * k + 1] = bh_lo(bh_pack(x.y, 0.f));
+        v[4 * k + 2] = bh_lo(bh_pack(x.z, 0.f)); v[4 * k + 3] = bh_lo(bh_pack(x.w, 0.f));
+    }
+    const float invT = 1.0f / (float)Tout;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (v[4 * k] + v[4 * k + 1]) + (v[4 * k + 2] + v[4 * k + 3]);
+    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * invT;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float d = v[i] - mean;
+        ss += d * d;
+    }
+    for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss * invT + AVC_IN_EPS);
+    const int mc = m < a.M ? m : a.M - 1;
+    float gamma = 1.f, beta = 0.f;
+    if (f.cond) {
+        const float* cr = f.cond + (long)(b < a.B ? b : a.B - 1) * f.cond_sb + f.cond_off;
+        beta = cr[mc];
+        gamma = cr[f.C + mc];
+    }
+    if (valid && qd % lpr == 0) {
+        f.mean[(long)b * f.C + m] = mean;
+        f.rstd[(long)b * f.C + m] = rstd;
+    }
+    // rows (2p, 2p + 1): the even row's lane keeps frames [0, 8) of its segment, the odd row's lane frames [8, 16), each with BOTH channels
+    float lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float rcv = __shfl_xor(odd ? v[i] : v[8 + i], 4);
+        lo[i] = odd ? rcv : v[i];
+        hi[i] = odd ? v[8 + i] : rcv;
+    }
+    const float pmean = __shfl_xor(mean, 4), prstd = __shfl_xor(rstd, 4), pgamma = __shfl_xor(gamma, 4), pbeta = __shfl_xor(beta, 4);
+    const float mean0 = odd ? pmean : mean, mean1 = odd ? mean : pmean, rstd0 = odd ? prstd : rstd, rstd1 = odd ? rstd : prstd;
+    const float g0 = odd ? pgamma : gamma, g1 = odd ? gamma : pgamma, be0 = odd ? pbeta : beta, be1 = odd ? beta : pbeta;
+    if (!valid) return;
+    const int fb = t0 + 8 * odd;
+    const long prow = (long)b * (f.C >> 1) + (m >> 1);
+    unsigned* yrow = (unsigned*)g.out + prow * Tout + fb;
+    unsigned* orow = (unsigned*)f.out + prow * Tout + fb;
+    const unsigned* rrow = f.res ? (const unsigned*)f.res + prow * f.Tres : nullptr;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float rl[4], rh[4];
+        if (rrow) conv_in_res_pairs4(rrow, f.res_mode, fb + 4 * k, rl, rh);
+        else { rl[0] = rl[1] = rl[2] = rl[3] = rh[0] = rh[1] = rh[2] = rh[3] = 0.f; }
+        conv_u32x4 yv, ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y0 = lo[4 * k + e], y1 = hi[4 * k + e];
+            yv[e] = bh_pack(y0, y1);
+            const float w0 = in_preact(in_xhat(y0, mean0, rstd0), g0, be0), w1 = in_preact(in_xhat(y1, mean1, rstd1), g1, be1);
+            ov[e] = bh_pack((f.relu ? avc_act(w0, a.slope) : w0) + rl[e], (f.relu ? avc_act(w1, a.slope) : w1) + rh[e]);
+        }
+        *(conv_u32x4*)(yrow + 4 * k) = yv;
+        *(conv_u32x4*)(orow + 4 * k) = ov;
+    }
+}
+
 // ---- the same epilogue on bf16 PAIR tensors (bf16_pairs.h): rows m (even) and m + 1 of the lane's column are one dword.
 // Strides are dword strides of the [B][C/2][T] tensors; M is even; time stride 1.
 // the (up to two) dwords of a residual pair row that conv_res_value's modes combine, as element offsets inside the row (time stride 1)

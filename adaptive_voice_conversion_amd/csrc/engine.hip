@@ -1005,7 +1005,7 @@ static int conv_in_fwd(const avc_plan* p, ConvArgs& a, float slope, int Bn, int 
                        const float* res, int res_mode, int Tres, float* out, float* stats, hipStream_t s, int Bfull = 0, int b0 = 0,
                        bool pairs = false, int planar = 0, int nv = 0) {
     if (Bfull == 0) Bfull = Bn;
-    if (!pairs && avc_conv_in_fusable(a, p->tun)) {
+    if (!planar && avc_conv_in_fusable(a, p->tun, res ? res_mode : AVC_RES_NONE, Tres)) {   // (pair tensors too; a pixel-shuffling conv's "planar" rows keep the row kernel)
         a.in.out = out;
         a.in.mean = stats + (long)b0 * C;
         a.in.rstd = stats + (long)Bfull * C + (long)b0 * C;

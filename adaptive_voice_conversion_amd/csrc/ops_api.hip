@@ -98,6 +98,8 @@ static void op_compute(ConvArgs& a) {
 
 int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
                      int Tres, float* out, float* mean, float* rstd, void* stream);
+int avc_instnorm_fwd_pairs(const void* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const void* res, int res_mode,
+                           int Tres, int planar, void* out, float* mean, float* rstd, void* stream);
 
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
     int CK = avc_conv_ck(avc_op_tuning(), KS);
@@ -167,25 +169,27 @@ int avc_conv1d_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, 
 int avc_conv1d_in_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp, const float* bias, int Cout, int KS,
                       int stride, int ops, float* y, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
                       int Tres, float* out, float* mean, float* rstd, int* fused, void* stream) {
-    if (op_bh() || (ops != 1 && ops != 2) || Cout % ops) return -2;
+    const bool bh = op_bh();   // op_compute_dtype 3: x / y / out / res are bf16 pair tensors (dwords [B][C/2][T]), wp a pair image; no pixel shuffle
+    if ((ops != 1 && ops != 2) || Cout % ops) return -2;
+    if (bh && (avc_op_tuning().op_compute_dtype != AVC_COMPUTE_BF16S || ops != 1 || (Cin & 1) || (Cout & 1))) return -2;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     op_compute(a);
     a.x.ptr = x; a.x.sb = sxb; a.x.sc = sxc; a.x.st = sxt; a.x.ps = 1;
-    a.B = B; a.Cred = Cin; a.Tsrc = Tin;
+    a.B = B; a.Cred = bh ? Cin / 2 : Cin; a.Tsrc = Tin;
     a.mode = 0; a.stride = stride;
     const int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
     a.M = Cout; a.Mp = avc_cdiv(Cout, 128) * 128;
     a.Tout = (Tin + padL + padR - KS) / stride + 1;
     const int C = Cout / ops, T = a.Tout * ops;
-    a.ob = (long)C * T; a.oc = T; a.ot = 1; a.ops = ops;
+    a.ob = (long)(bh ? C / 2 : C) * T; a.oc = T; a.ot = 1; a.ops = ops;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     a.ngroups = 1;
     a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wp; a.g[0].bias = bias; a.g[0].out = y;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cin, a.g[0].CK);
-    a.img = AVC_IMG_K4;
-    const bool fuse = avc_conv_in_fusable(a, avc_op_tuning());
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(a.Cred, a.g[0].CK);
+    a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
+    const bool fuse = avc_conv_in_fusable(a, avc_op_tuning(), res ? res_mode : AVC_RES_NONE, Tres);
     if (fused) *fused = fuse ? 1 : 0;
     if (fuse) {
         a.in.out = out; a.in.mean = mean; a.in.rstd = rstd;
@@ -196,6 +200,7 @@ int avc_conv1d_in_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Ci
     }
     int rc = avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
     if (rc) return rc;
+    if (bh) return avc_instnorm_fwd_pairs(y, B, C, T, cond, cond_sb, cond_off, relu, res, res_mode, Tres, 0, out, mean, rstd, stream);
     return avc_instnorm_fwd(y, B, C, T, cond, cond_sb, cond_off, relu, res, res_mode, Tres, out, mean, rstd, stream);
 }
 

@@ -121,6 +121,8 @@ class Solver(object):
         self._eps_gen = None
         self._comm_stream = None
         self._wire = None   # persistent bf16 gradient bucket (allreduce_dtype: bf16)
+        self.measure_allreduce = False
+        self._ar_events = []
 
     # ---- one training step (solver.py:81-97) -------------------------------------
     def _draw_eps(self, B, C, Tb, device):
@@ -149,30 +151,67 @@ class Solver(object):
             d.all_reduce(wire)
             seg.copy_(wire)
         parts = [plan.param_range(k) for k in (_lib.GRADS_DECODER, _lib.GRADS_SPEAKER, _lib.GRADS_CONTENT)]
-        wires = [None, None, None]
+        # `allreduce_buckets` (config; default 3): 3 = decoder | speaker encoder | content encoder, the first two under the backward pass;
+        # 2 = decoder under the backward pass, the two encoders (one contiguous range: the head of the flat buffer) after it -- one
+        # collective launch fewer on a step this short; 1 = the whole buffer after the backward pass (no overlap)
+        nb = int(self.config.get("allreduce_buckets", 3))
+        early = [(_lib.GRADS_DECODER, parts[0]), (_lib.GRADS_SPEAKER, parts[1])]
+        late = [parts[2]]
+        if nb <= 2:
+            lo = min(parts[1][0], parts[2][0])
+            hi = max(parts[1][0] + parts[1][1], parts[2][0] + parts[2][1])
+            if hi - lo != parts[1][1] + parts[2][1]:   # (the two encoders are not adjacent in this plan: keep them apart)
+                late = [parts[1], parts[2]]
+            else:
+                late = [(lo, hi - lo)]
+            early = early[:1]
+        if nb <= 1:
+            early, late = [], [(0, grads.numel())]
+        wire = None
         if wire_bf16:
             if self._wire is None or self._wire.device != grads.device or self._wire.numel() != grads.numel():
                 self._wire = torch.empty(grads.numel(), dtype=torch.bfloat16, device=grads.device)
-            wires = [self._wire[o:o + n] for o, n in parts]
+            wire = self._wire
+        w = (lambda o, n: wire[o:o + n]) if wire is not None else (lambda o, n: None)
         if not grads.is_cuda:
-            for (o, n), w in zip(parts, wires):
-                reduce(grads[o:o + n], w)
+            for _, (o, n) in early:
+                reduce(grads[o:o + n], w(o, n))
+            for (o, n) in late:
+                reduce(grads[o:o + n], w(o, n))
             return
         if self._comm_stream is None or self._comm_stream.device != grads.device:
             self._comm_stream = torch.cuda.Stream(device=grads.device)
         cs, main = self._comm_stream, torch.cuda.current_stream(grads.device)
-        # Three buckets in the order the backward pass finishes them (avc_backward: decoder -> speaker encoder's branch -> content
-        # encoder's longer branch): the first two are reduced on the communication stream UNDER the rest of the backward, only the
-        # content encoder's 7 MB start after it.
-        for k, ((o, n), w) in zip((_lib.GRADS_DECODER, _lib.GRADS_SPEAKER), zip(parts[:2], wires[:2])):
+        # Buckets in the order the backward pass finishes them (avc_backward: decoder -> speaker encoder's branch -> content encoder's
+        # longer branch): the early ones are reduced on the communication stream UNDER the rest of the backward, only the late one(s)
+        # start after it.
+        for k, (o, n) in early:
             if not plan.stream_wait_grads(k, cs):
                 cs.wait_stream(main)               # a plan without helper streams / events: order behind the whole backward
             with torch.cuda.stream(cs):
-                reduce(grads[o:o + n], w)
+                reduce(grads[o:o + n], w(o, n))
         cs.wait_stream(main)                       # the whole backward (avc_backward joins its helper streams into main)
         with torch.cuda.stream(cs):
-            reduce(grads[parts[2][0]:parts[2][0] + parts[2][1]], wires[2])
-        main.wait_stream(cs)
+            for (o, n) in late:
+                reduce(grads[o:o + n], w(o, n))
+        # the time the compute stream WAITS here is the all-reduce the schedule could not hide: measured when asked for
+        # (Solver.measure_allreduce = True; bench.py --gpus N reports the mean as config.exposed_allreduce_ms)
+        if getattr(self, "measure_allreduce", False):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            main.wait_stream(cs)
+            e1.record(main)
+            self._ar_events.append((e0, e1))
+        else:
+            main.wait_stream(cs)
+
+    def exposed_allreduce_ms(self, last=None):
+        """Mean time per step the compute stream waited for the gradient all-reduce (needs measure_allreduce = True; synchronises)."""
+        ev = self._ar_events[-last:] if last else self._ar_events
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def ae_step(self, data, lambda_kl, eps=None, sync=True):
         model = self.model

@@ -913,6 +913,9 @@ def main():
     for _ in range(a.warmup):
         one_step()
     barrier()
+    if world > 1:   # how much of the gradient all-reduce the schedule did NOT hide (event pair around the compute stream's wait)
+        solver.measure_allreduce = True
+        solver._ar_events.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         if a.presleep_ms > 0:
@@ -920,6 +923,8 @@ def main():
         one_step()
     barrier()
     elapsed, per_rank = rank_times(time.perf_counter() - t0)
+    exposed_ar = solver.exposed_allreduce_ms() if world > 1 else None
+    solver.measure_allreduce = False
     meta = solver.ae_step(x, 1.0, eps=eps, sync=True)
     if not all(v == v and abs(v) < 1e6 for v in meta.values()):
         raise SystemExit(f"non-finite training state: {meta}")
@@ -934,6 +939,7 @@ def main():
             "config": {"workload": workload + (" + device-side segment gather from an HBM-resident corpus inside the timed loop" if feed else ""),
                        "baseline_config_index": cfg_idx, "global_batch": world * B, "segment": [a.mels, T], "parallelism": f"dp{world}",
                        "world_size": world, "dist_backend": (a.dist_backend if world > 1 else None), "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
+                       "exposed_allreduce_ms": exposed_ar, "allreduce_buckets": (int(cfg.get("allreduce_buckets", 3)) if world > 1 else None),
                        "tuning": a.tune or None,
                        "allreduce": ("decoder range on a communication stream under the encoders' backward, encoders' range after it; "
                                      + ("RCCL via torch.distributed nccl" if a.dist_backend == "nccl" else f"torch.distributed {a.dist_backend} (staged through the host: executes the path, not a scaling number)")) if world > 1 else None,

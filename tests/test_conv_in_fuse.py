@@ -62,6 +62,8 @@ CASES = [
     (9, 128, 128, 16, 5, 1, 1, False, 1, 0, 1),   # 16 K-chunks: the split-K wave groups in front of the fused epilogue
     (2, 16, 32, 128, 5, 1, 1, False, 1, 0, 0),    # rows of 128 frames: not fusable -> conv + row kernel
     (2, 16, 32, 24, 5, 1, 1, False, 1, 0, 0),     # a length that does not tile 64 columns: not fusable
+    (3, 16, 32, 31, 5, 2, 1, False, 1, 2, 0),     # rows of 16 joined by the ceil-mode pool of a 31-frame residual (odd source, model.py:319):
+                                                  # found by tests/test_engine_random_configs.py -- the row kernel keeps that case
     pytest.param(64, 128, 128, 64, 5, 1, 1, True, 1, 1, 1, marks=GPU),
     pytest.param(64, 128, 256, 32, 5, 1, 2, True, 1, 5, 1, marks=GPU),
     pytest.param(256, 128, 128, 32, 5, 2, 1, False, 1, 2, 1, marks=GPU),
@@ -82,7 +84,7 @@ def test_conv_in_fused_epilogue(kind, B, Cin, Cout, Tin, KS, stride, ops, affine
     To = O.pad_conv(torch.zeros(1, Cin, Tin), torch.zeros(Cout, Cin, KS), None, stride).shape[2] * ops
     cond = torch.randn(B, 4 * C + 8, generator=g) if affine else None
     cond_off = 2 * C + 8 if affine else 0
-    Tres = {0: 0, 1: To, 2: 2 * To, 5: To // 2}[res_mode]
+    Tres = {0: 0, 1: To, 2: (Tin if stride == 2 else 2 * To), 5: To // 2}[res_mode]   # (the pooled residual is the block's input: Tin frames)
     res = torch.randn(B, C, Tres, generator=g) if res_mode else None
     y_ref, o_ref = reference(x, w, b, stride, ops, cond, cond_off, relu, res, res_mode)
     d = lambda t: None if t is None else t.to(dev)
@@ -103,3 +105,83 @@ def test_conv_in_fused_epilogue(kind, B, Cin, Cout, Tin, KS, stride, ops, affine
         torch.testing.assert_close(out, out2, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(mean, mean2, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(rstd, rstd2, rtol=1e-5, atol=1e-6)
+
+
+# ---- bf16 pair storage (compute_dtype "bf16"): the same fusion on pair tensors; y is rounded to bf16 first, statistics / output from the
+# rounded values -- the two-launch path's arithmetic (conv -> pair rows -> instnorm_fwd_pairs_kernel), summation order aside
+PAIR_CASES = [
+    (3, 32, 32, 64, 5, 1, False, 1, 0),
+    (5, 32, 40, 32, 5, 1, True, 1, 1),     # ragged last tile, 40 of 64 rows valid, AdaIN, identity residual
+    (6, 48, 64, 16, 5, 1, True, 2, 0),     # four samples per tile, LeakyReLU
+    (3, 32, 32, 64, 5, 2, False, 1, 2),    # stride 2 -> rows of 32 with the ceil-mode pooled residual
+    (2, 32, 64, 32, 1, 1, True, 1, 5),     # 1x1 conv, upsampled residual
+    pytest.param(64, 128, 128, 64, 5, 1, True, 1, 1, marks=GPU),
+    pytest.param(256, 128, 128, 32, 5, 2, False, 1, 2, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,Tin,KS,stride,affine,relu,res_mode", PAIR_CASES)
+def test_conv_in_fused_epilogue_on_pair_tensors(kind, B, Cin, Cout, Tin, KS, stride, affine, relu, res_mode):
+    from tests.test_bf16_pairs import bf16r, close_bf16, from_pairs, op_dtype, to_pairs
+    if kind == "emu" and B * Cin * Cout * Tin * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 17 + Tin)
+    x = torch.randn(B, Cin, Tin, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    To = O.pad_conv(torch.zeros(1, Cin, Tin), torch.zeros(Cout, Cin, KS), None, stride).shape[2]
+    cond = torch.randn(B, 2 * Cout + 4, generator=g) if affine else None
+    cond_off = 4 if affine else 0
+    Tres = {0: 0, 1: To, 2: 2 * To, 5: To // 2}[res_mode]
+    res = torch.randn(B, Cout, Tres, generator=g) if res_mode else None
+    # reference: bf16 operands, y rounded once, everything after it from the rounded y, the output rounded once
+    y_ref = bf16r(O.pad_conv(bf16r(x).double(), bf16r(w).double(), b.double(), stride).float())
+    _, o_ref = reference_from_y(y_ref, cond, cond_off, relu, bf16r(res) if res is not None else None, res_mode)
+
+    def go():
+        xp, rp = to_pairs(x).to(dev), (to_pairs(res).to(dev) if res is not None else None)
+        wd, bd, cd = w.to(dev), b.to(dev), (cond.to(dev) if cond is not None else None)
+        wp = pack(lib, dev, [wd], 0)
+        y = torch.zeros(B, Cout // 2, To, dtype=torch.int32, device=dev)
+        out = torch.zeros_like(y)
+        mean = torch.full((B * Cout,), float("nan"), device=dev)
+        rstd = torch.full_like(mean, float("nan"))
+        fused = ctypes.c_int(-1)
+        rc = lib.avc_conv1d_in_fwd(P(xp), xp.stride(0), xp.stride(1), 1, B, Cin, Tin, P(wp), P(bd), Cout, KS, stride, 1, P(y), P(cd),
+                                   cd.stride(0) if cd is not None else 0, cond_off, relu, P(rp), res_mode, Tres, P(out), P(mean), P(rstd),
+                                   ctypes.byref(fused), None)
+        assert rc == 0, rc
+        return from_pairs(y.cpu()), from_pairs(out.cpu()), mean.cpu(), rstd.cpu(), fused.value
+
+    with op_dtype(lib, 3):
+        y, out, mean, rstd, fused = go()
+        assert fused == 1
+        assert lib.avc_set_tuning(b"conv_in_fuse", 0) == 0
+        try:
+            y2, out2, mean2, rstd2, fused2 = go()
+        finally:
+            lib.avc_set_tuning(b"conv_in_fuse", 1)
+        assert fused2 == 0
+    close_bf16(y, y_ref, ulps=2.0, atol=1e-3)      # (one bf16 ulp is up to 2^-7 of the value: an fp32 sum of 640 products lands on the other side of a rounding boundary now and then)
+    close_bf16(out, o_ref, ulps=2.0, atol=2e-2)
+    assert torch.equal(y, y2)                      # the same rounded conv output either way
+    torch.testing.assert_close(mean, mean2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd, rstd2, rtol=1e-5, atol=1e-6)
+    close_bf16(out, out2, ulps=1.0, atol=1e-6)     # (a statistic that differs in its last bit may move an output across a rounding boundary)
+
+
+def reference_from_y(y, cond, cond_off, relu, res, res_mode):
+    C = y.shape[1]
+    o = F.instance_norm(y, eps=1e-5)
+    if cond is not None:
+        beta, gamma = cond[:, cond_off:cond_off + C], cond[:, cond_off + C:cond_off + 2 * C]
+        o = o * gamma[:, :, None] + beta[:, :, None]
+    if relu == 1:
+        o = torch.relu(o)
+    elif relu == 2:
+        o = F.leaky_relu(o, 0.01)
+    if res is not None:
+        o = o + {1: lambda r: r, 2: lambda r: O.avg_pool_ceil(r, 2), 5: lambda r: O.upsample_nearest(r, 2)}[res_mode](res)
+    return y, o

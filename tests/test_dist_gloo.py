@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, wire="fp32", compute=None):
+def _worker(rank, world, port, out_dir, wire="fp32", compute=None, buckets=3):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +33,7 @@ def _worker(rank, world, port, out_dir, wire="fp32", compute=None):
     lib, _ = backend("emu")
     cfg = O.tiny_config()
     cfg["allreduce_dtype"] = wire
+    cfg["allreduce_buckets"] = buckets
     if compute:
         cfg["compute_dtype"] = compute
     sd = O.make_state_dict(cfg, 4)
@@ -83,6 +84,13 @@ def test_two_rank_step_equals_global_batch_step(tmp_path):
     # after 2 steps: identical except a handful of ~0-gradient elements (Adam's sign-like first step)
     assert (diff > 2e-6).float().mean().item() < 5e-3
     assert diff.max().item() <= 4.2 * cfg["optimizer"]["lr"]
+    # `allreduce_buckets: 2` (decoder | both encoders as one range) and `1` (the whole buffer) reduce the same numbers: with the fp32 wire the
+    # replicas end bit-identical to the three-bucket run
+    for nb in (2, 1):
+        dn = tmp_path / f"buckets{nb}"
+        dn.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(dn), "fp32", None, nb), nprocs=world, join=True)
+        assert torch.equal(torch.load(dn / "rank0.pt")["params"], r0["params"]), nb
     # BASELINE configs[2]'s wire format (`allreduce_dtype: bf16`, the default under `compute_dtype: bf16`): the flat gradient
     # buffer is all-reduced as bf16.  Replicas must stay bit-identical (every rank receives the same sum) and the step must stay
     # within bf16 rounding of the fp32-wire step.
