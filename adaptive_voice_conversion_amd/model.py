@@ -288,11 +288,24 @@ class AE(nn.Module):
         key = (int(B), int(T), int(Tc), str(device))
 
         def make():
-            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self.compute_dtype, mode=mode, device=device, tuning=self._tuning)
+            plan = Plan(self.config, B, T, Tc, lib=self._lib, compute_dtype=self._compute_for(mode), mode=mode, device=device, tuning=self._tuning)
             if [(o, n) for o, n, _ in plan.param_info] != [(o, n) for o, n, _ in self._layout]:
                 raise RuntimeError("flat parameter layout of the C plan differs from the module's")
             return _Entry(plan, torch.zeros(plan.workspace_floats, dtype=torch.float32, device=device))
         return self._plans.get(mode, key, make)
+
+    def _compute_for(self, mode):
+        """ONE rounding model per compute mode and use: under ``compute_dtype: bf16`` the TRAINING plans run the bf16 pair-storage engine
+        (BASELINE configs[2]); every forward-only plan -- ``AE.inference``, ``get_speaker_embeddings``, no-grad forwards -- rounds the
+        operands of the matrix products to bf16 on fp32 storage ("bf16r"), which is what the ragged plan of ``inference_ragged`` /
+        ``Inferencer.convert_batch`` runs and what the uniform plan falls back to at lengths outside the pair kernels anyway: the same
+        utterance converts to the same numbers (to fp32 summation order) whichever entry point it comes through.
+        ``inference_compute_dtype`` in the config overrides it (e.g. "bf16s": pair storage for uniform inference batches, faster, its own
+        rounding points)."""
+        cd = str(self.compute_dtype).lower()
+        if mode != "train" and cd in ("bf16", "bfloat16"):
+            return (self.config.get("inference_compute_dtype") if isinstance(self.config, dict) else None) or "bf16r"
+        return self.compute_dtype
 
     def _plan(self, B, T, Tc, device, mode="train"):
         e = self._entry(mode, B, T, Tc, device)

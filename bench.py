@@ -837,6 +837,7 @@ def main():
         a.dtype = "bf16"
     if a.dtype == "bf16":    # configs[2] on the bf16 storage engine (bf16 channel-pair tensors)
         cfg["compute_dtype"] = "bf16s"
+        cfg["inference_compute_dtype"] = "bf16s"   # (--mode infer --dtype bf16 measures the pair-storage engine; AE's default for inference is "bf16r")
     if a.dtype == "bf16r":   # ... on fp32 storage with operand rounding (round 2's bf16 mode)
         cfg["compute_dtype"] = "bf16r"
     if a.dtype == "f32x3":   # opt-in: fp32-accurate products from three bf16 terms on the bf16 matrix core

@@ -113,3 +113,41 @@ def test_ragged_plan_converts_utterances_of_different_lengths_in_one_launch_set(
         torch.testing.assert_close(outs[b].cpu(), ref, msg=lambda m: f"pair {b} (T={T[b]}, T_cond={Tc[b]}): {m}", **tol)
     with pytest.raises(RuntimeError, match="Padding size should be less"):
         RaggedPlan(cfg, [40, 2], [40, 40], lib=lib)
+
+
+@pytest.mark.parametrize("kind,cfgname,n,lo,hi", [("emu", "tiny", 4, 24, 60), pytest.param("gpu", "m80", 8, 40, 400, marks=pytest.mark.gpu)])
+def test_bf16_inference_has_one_rounding_model(kind, cfgname, n, lo, hi):
+    """compute_dtype "bf16": AE.inference (uniform plan) and AE.inference_ragged / Inferencer.convert_batch (ragged plan) round the SAME
+    points -- the operands of every Conv1d / Linear product, fp32 everything else ("bf16r") -- so an utterance converts to the same numbers
+    through either; both against the oracle's bf16-operand twin (O.bf16_operands) of that pair alone."""
+    from adaptive_voice_conversion_amd.model import AE
+    from tests.test_engine import get_cfg
+    lib, dev = backend(kind)
+    cfg = dict(get_cfg(cfgname))
+    cfg["compute_dtype"] = "bf16"
+    M = cfg["ContentEncoder"]["c_in"]
+    sd = O.make_state_dict(cfg, 3)
+    model = AE(cfg, lib=lib if kind == "emu" else None)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    rng = np.random.RandomState(11)
+    T = [int(v) for v in rng.randint(lo, hi + 1, size=n)]
+    Tc = [int(v) for v in rng.randint(lo, hi + 1, size=n)]
+    T[0] = Tc[0] = 64 if hi >= 64 else 32      # a length the pair-storage engine WOULD take: it must not be chosen for inference
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(t, M, generator=g) for t in T]
+    cs = [torch.randn(t, M, generator=g) for t in Tc]
+    rag = [o.cpu() for o in model.inference_ragged([x.to(dev) for x in xs], [c.to(dev) for c in cs])]
+    assert model.last_ragged_compute == "bf16r"
+    for b in range(n):
+        uni = model.inference(xs[b].t()[None].contiguous().to(dev), cs[b].t()[None].contiguous().to(dev))[0].cpu()
+        plan_u = model._plan(1, T[b], Tc[b], dev, "inference")[0]
+        assert plan_u.compute_dtype == "bf16r", plan_u.compute_dtype
+        with O.bf16_operands():
+            twin = O.ae_inference(xs[b].t()[None], cs[b].t()[None], sd, cfg)[0]
+        ref = O.ae_inference(xs[b].t()[None], cs[b].t()[None], sd, cfg)[0]
+        rel = lambda a, r: ((a - r).norm() / r.norm()).item()
+        # the two entry points: same rounding model, different summation orders -> far inside the mode's own distance from fp32
+        assert rel(rag[b], uni) <= 5e-3, (b, T[b], Tc[b], rel(rag[b], uni))
+        assert rel(rag[b], twin) <= 1.5e-2 and rel(uni, twin) <= 1.5e-2, (b, rel(rag[b], twin), rel(uni, twin))
+        assert rel(rag[b], ref) <= 3e-2      # BASELINE.md: bf16 forward bar against the fp32 oracle
