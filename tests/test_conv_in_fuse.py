@@ -169,7 +169,7 @@ def test_conv_in_fused_epilogue_on_pair_tensors(kind, B, Cin, Cout, Tin, KS, str
     assert torch.equal(y, y2)                      # the same rounded conv output either way
     torch.testing.assert_close(mean, mean2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(rstd, rstd2, rtol=1e-5, atol=1e-6)
-    close_bf16(out, out2, ulps=1.0, atol=1e-6)     # (a statistic that differs in its last bit may move an output across a rounding boundary)
+    close_bf16(out, out2, ulps=2.0, atol=1e-6)     # (a statistic that differs in its last bit may move an output across a rounding boundary: one bf16 ulp, up to 2^-7 of the value)
 
 
 def reference_from_y(y, cond, cond_off, relu, res, res_mode):
