@@ -280,7 +280,7 @@ def _pmc_load():
         meta = d.get("_meta", {})
         if meta.get("build_fingerprint") != fp:
             _PMC_NOTE[0] = (f"profiles/{fn} was taken on build {meta.get('build_fingerprint')} (git {meta.get('git_head')}), this library is build {fp}: "
-                            "refused (traffic = null) -- re-run scripts/gpu_pmc.sh on this build")
+                            "refused (traffic = null) -- re-run the PMC passes of scripts/gpu_r5_final.sh on this build")
             continue
         return d, f"profiles/{fn} (build {fp}, git {meta.get('git_head')})"
     if _PMC_NOTE[0] is None:
