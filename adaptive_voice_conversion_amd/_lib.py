@@ -133,6 +133,9 @@ def declare(lib):
                                      c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]
     lib.avc_conv1d_in_fwd.argtypes = [c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.avc_conv1d_dgrad_in_bwd.argtypes = [c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int,
+                                            c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]
     # bf16 pair rows
     lib.avc_instnorm_fwd_pairs.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                            c_void_p, c_void_p, c_void_p, c_void_p]

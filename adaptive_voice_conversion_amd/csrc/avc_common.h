@@ -95,6 +95,24 @@ struct ConvINFuse {
     int relu;
 };
 
+// ... and its backward twin (round 5): the InstanceNorm / AdaIN / activation BACKWARD of the rows an input-gradient launch produces.  The
+// launch's own result g = conv^T(dy) [+ residual-gradient join] is d(loss)/d(out) of an InstanceNorm layer; where its rows are 16 / 32 / 64
+// frames long the tile holds them whole and the epilogue turns g into d(loss)/d(y) = `dy` (what that layer's dgrad and wgrad read) and the
+// AdaIN gradients -- the formulas of instnorm_bwd_kernel (rowops.hip).  g itself is still written to `g.out` when that is not null (the
+// block's residual path reads it too).
+struct ConvINBwd {
+    float* dy;          // null: nothing fused
+    const float* y;     // the normalised conv's saved output rows [B][C][T] (contiguous)
+    const float* mean;  // [B][C] (offset to the launch's first sample)
+    const float* rstd;
+    const float* cond;  // AdaIN affine [B][cond_sb] or null
+    long cond_sb;
+    float* dcond;       // [B][dcond_sb]: dbeta -> [off + c], dgamma -> [off + C + c]; null for plain IN
+    long dcond_sb;
+    int cond_off, dcond_off;
+    int C, relu;
+};
+
 struct ConvArgs {
     ConvSrc x;
     int B, Cred, Tsrc;
@@ -123,6 +141,7 @@ struct ConvArgs {
     int walk_rem;  // walkers [0, walk_rem) take walk_n tiles, the others walk_n - 1
     int walk_db;   // samples between two tiles of a walker (the first frame of the tile never changes along a walk)
     ConvINFuse in;  // fused InstanceNorm epilogue (in.out == null: none)
+    ConvINBwd inb;  // fused InstanceNorm-backward epilogue of an input-gradient launch (inb.dy == null: none)
     ConvGroup g[AVC_MAX_GROUPS];
 };
 

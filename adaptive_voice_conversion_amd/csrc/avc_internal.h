@@ -24,7 +24,8 @@ int avc_conv_pick_tile(const avc_tuning& tun, int Mp, int B, int Tout, int ngrou
 long avc_conv_num_wgs(int tile, int Mp, int B, int Tout, int ngroups);
 int avc_conv_ck_for(const avc_tuning& tun, int KS, long wgs, int mode, int stride, int Tout, int tile);
 int avc_launch_conv(const ConvArgs& a, hipStream_t stream, int force_tile, const avc_tuning& tun);
-bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun, int res_mode, int Tres);   // ConvINFuse: may the InstanceNorm of this launch's output rows run in its epilogue?
+bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun, int res_mode, int Tres);
+bool avc_conv_inb_fusable(const ConvArgs& a, const avc_tuning& tun);   // ConvINBwd: may the InstanceNorm backward of this dgrad launch's output rows run in its epilogue?   // ConvINFuse: may the InstanceNorm of this launch's output rows run in its epilogue?
 int avc_launch_pack(const PackArgs& p, hipStream_t stream);
 // split-bf16 conv (conv_x3.hip): ConvArgs.img == AVC_IMG_X3
 bool avc_conv_x3_eligible(const avc_tuning& tun, int mode, int Cred, int KS, int stride, int Tout, int B, int M);

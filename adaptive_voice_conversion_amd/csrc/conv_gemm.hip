@@ -222,7 +222,9 @@ static __device__ __forceinline__ void conv_chunk_mma(f32x16 (&acc)[WM][WN], con
 // conv_shared.h: conv_epilogue_in) -- forward launches on 64 x 64 tiles whose columns are whole rows.  A compile-time flag like WALK: as a
 // run-time branch in the one kernel body the second epilogue cost every instance its register budget (100 -> 280 VGPRs, ~130 spilled
 // scalars: the compiler evaluates both epilogues' launch-uniform conditions in front of the chunk loop).
-template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false, bool WALK = false, bool INF = false>
+// INB instances: the backward twin -- an input-gradient launch whose output rows are d(loss)/d(out) of an InstanceNorm layer turns them into
+// d(loss)/d(y) in its epilogue (ConvINBwd, conv_shared.h: conv_epilogue_in_bwd).
+template <int WM, int WN, bool MIRROR, int KSC, int GRC, int KG, int BF, bool PAR = false, bool RAG = false, bool WALK = false, bool INF = false, bool INB = false>
 __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = AVC_THREADS * KG;
@@ -546,6 +548,12 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         else conv_epilogue_in(a, g, acc[0][0], smem, tid, wave_m, wave_n, li, h, m_tile0, q.b0);
         return;
     }
+    if constexpr (INB) {
+        static_assert(WM == 1 && WN == 1 && BF == 0 && !RAG && !WALK && !INF, "fused InstanceNorm-backward epilogue: exact-fp32 input gradient, 64 x 64 tiles");
+        if (KG > 1) __syncthreads();
+        conv_epilogue_in_bwd(a, g, acc[0][0], smem, tid, wave_m, h, m_tile0, q.b0, q.t0, colb[0] - q.b0, colt[0], colv[0]);
+        return;
+    }
     if (!(a.dbg & 8)) {
         if constexpr (WALK) {
             // The epilogue's parameters (strides, bases, pointers: ~40 scalar registers) and its row / column arithmetic are invariant along a
@@ -843,6 +851,20 @@ static void conv_launch_inf(const ConvArgs& a, int fast, dim3 grid, dim3 block, 
     else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, BF, false, false, false, true>), grid, block, lds, stream, a);
 }
+// fused InstanceNorm-backward epilogue (ConvINBwd): input-gradient launches on 64 x 64 tiles -- the mirrored k = 5 chunk at 8 / 16 channels with
+// and without the stride-2 column-parity split, the 1x1 chunk, the generic chunk loop, each with one or two split-K wave groups
+template <int KG>
+static void conv_launch_inb(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    if (a.par && mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par && mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 0, 0, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+}
 static bool conv_walk_instance(int tile, bool mir, int fast) {
     return (tile == 11 && (fast == 1 || ((fast == -1 || fast == 14) && !mir))) || (tile == 21 && fast == 14 && !mir);
 }
@@ -884,6 +906,22 @@ bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun, int res_mode,
     return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS * (bh ? 2 : 1)) == 11;
 }
 
+// ... and of an input-gradient launch: may the InstanceNorm BACKWARD of its output rows run in its epilogue (ConvINBwd)?  Exact-fp32 dgrad on
+// 64 x 64 tiles whose columns are whole rows; contiguous [B][M][T] output and residual-gradient rows; only the "to primary" join.
+bool avc_conv_inb_fusable(const ConvArgs& a, const avc_tuning& tun) {
+    if (!tun.conv_in_fuse || a.mode != 1 || a.ngroups != 1 || a.rag.tile || a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4 || a.pairs) return false;
+    if (a.Tout != 16 && a.Tout != 32 && a.Tout != 64) return false;
+    if (a.ops != 1 || a.act || a.g[0].out2 || a.g[0].mask || a.g[0].bias) return false;
+    if (a.ot != 1 || a.oc != a.Tout || a.ob != (long)a.M * a.Tout) return false;
+    if (a.res_mode != AVC_RES_NONE) {
+        if (!a.res_to_primary || a.rt != 1 || a.rc != a.Tres || a.rb != (long)a.M * a.Tres) return false;
+        if (!((a.res_mode == AVC_RES_IDENTITY && a.Tres == a.Tout) || (a.res_mode == AVC_RES_POOLT && 2 * a.Tres == a.Tout) ||
+              (a.res_mode == AVC_RES_UPT && a.Tres == 2 * a.Tout))) return false;
+    }
+    if (conv_geom(1, a.stride, a.Tout, a.g[0].KS, 64, 0).SPT != 64 / a.Tout) return false;
+    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS) == 11;
+}
+
 // returns 0 on success, negative on unsupported geometry
 int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, const avc_tuning& tun) {
     if (a_in.img == AVC_IMG_X3 || force_tile == 97) return avc_launch_conv_x3(a_in, stream, tun);
@@ -909,6 +947,10 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         if (!avc_conv_in_fusable(a, tun, a.in.res ? a.in.res_mode : AVC_RES_NONE, a.in.Tres) || (force_tile != 0 && force_tile != 11) || tile != 11) return -2;
         if (!a.in.mean || !a.in.rstd || a.in.C != a.M / a.ops) return -2;
     }
+    if (a.inb.dy) {   // fused InstanceNorm-backward epilogue
+        if (a.in.out || !avc_conv_inb_fusable(a, tun) || (force_tile != 0 && force_tile != 11) || tile != 11) return -2;
+        if (!a.inb.y || !a.inb.mean || !a.inb.rstd || a.inb.C != a.M) return -2;
+    }
     if (tile == 12 && !wide_ok) return -2;
     if (tile != 11 && tile != 21 && tile != 12) return -2;
     const int BM = (tile == 21) ? 128 : 64, BN = (tile == 12) ? 128 : 64;
@@ -927,7 +969,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     // profiles/r03_bf16s_tune.log)
     if (!rag && a.bf16 != AVC_COMPUTE_BF16S && tile == 11 && a.ngroups == 1 && (long)grid.x * grid.y <= tun.kg_wgs && a.g[0].nchunk >= 4 && 2 * lds <= 160 * 1024 && !a.dbg) kgroups = 2;
     lds *= kgroups;
-    if (a.in.out && lds < AVC_IN_LDS_BYTES) lds = AVC_IN_LDS_BYTES;
+    if ((a.in.out || a.inb.dy) && lds < AVC_IN_LDS_BYTES) lds = AVC_IN_LDS_BYTES;
     if (lds > 160 * 1024) return -5;
     if (tun.conv_min_lds > 0 && (size_t)tun.conv_min_lds > lds && tun.conv_min_lds <= 160 * 1024) lds = (size_t)tun.conv_min_lds;   // (fewer co-resident workgroups)
     dim3 block(AVC_THREADS * kgroups);
@@ -951,7 +993,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     a.walk_rem = (int)grid.x;
     a.walk_db = 0;
     bool walk = false;
-    if (tun.conv_walk != 0 && !a.in.out && !rag && !a.par && bf == 0 && kgroups == 1 && AVC_CONV_STAGES == 2 && conv_walk_instance(tile, mir, fast)) {
+    if (tun.conv_walk != 0 && !a.in.out && !a.inb.dy && !rag && !a.par && bf == 0 && kgroups == 1 && AVC_CONV_STAGES == 2 && conv_walk_instance(tile, mir, fast)) {
         const int ntn = (int)grid.x;
         const int tps = a.Tout >= BN ? avc_cdiv(a.Tout, BN) : 1;
         const int SPT = a.Tout >= BN ? 1 : conv_geom(a.mode, a.stride, a.Tout, a.g[0].KS, BN, 0).SPT;
@@ -978,7 +1020,10 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         else if (bf == 1) { CALL_(1); }      \
         else { CALL_(0); }                   \
     } while (0)
-    if (a.in.out) {
+    if (a.inb.dy) {
+        if (kgroups == 2) conv_launch_inb<2>(a, mir, fast, grid, block, lds, stream);
+        else conv_launch_inb<1>(a, mir, fast, grid, block, lds, stream);
+    } else if (a.in.out) {
         const int f = (fast == 1 || fast == 2 || fast == 14) ? fast : 0;   // (the k = 5 chunk at 32 channels takes the generic loop)
         if (bf == 2) conv_launch_inf<1, 2>(a, f, grid, block, lds, stream);   // (pair storage runs without split-K wave groups)
         else if (kgroups == 2) conv_launch_inf<2, 0>(a, f, grid, block, lds, stream);

@@ -293,6 +293,117 @@ static __device__ void conv_epilogue_in(const ConvArgs& a, const ConvGroup& g, c
     }
 }
 
+// ---- the backward twin: an input-gradient launch whose output rows g are d(loss)/d(out) of an InstanceNorm layer (ConvINBwd).  The
+// fragments go through LDS by (sample, frame) -- the stride-2 instances deal their columns to the waves by parity, so the tile column is
+// computed from the lane's own (sample, frame) -- then every lane owns 16 consecutive frames of one channel row: the residual-gradient
+// join the epilogue would have applied (identity / pool^T / up^T, all "to primary"), g stored if somebody else reads it, and
+//   gm = g * 1[xh gamma + beta > 0];  dbeta = sum gm;  dgamma = sum gm xh;  dy = rstd (gm gamma - mean_T(gm gamma) - xh mean_T(gm gamma xh))
+// with xh and the activation decision recomputed from the saved y, mean, rstd by the forward pass's own rounding sequence.
+static __device__ void conv_epilogue_in_bwd(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, float* tile, int tid, int wave_m, int h,
+                                            int m_tile0, int b0, int t0_tile, int bl_lane, int t_lane, bool col_valid) {
+    const ConvINBwd& f = a.inb;
+    const int Tout = a.Tout, lpr = Tout >> 4;
+    if (col_valid) {
+        const int col = bl_lane * Tout + (t_lane - t0_tile);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[row * AVC_IN_LDT + col] = acc[r];
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 2, qd = tid & 3;
+    const int m = m_tile0 + r;
+    const int bl = (16 * qd) / Tout, t0 = 16 * qd - bl * Tout;
+    const int b = b0 + bl;
+    const bool valid = m < a.M && b < a.B;
+    const int mc = m < a.M ? m : a.M - 1, bc = b < a.B ? b : a.B - 1;   // (clamped: every lane takes part in the shuffles)
+    float gv[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 x = *(const float4*)(tile + r * AVC_IN_LDT + 16 * qd + 4 * k);
+        gv[4 * k] = x.x; gv[4 * k + 1] = x.y; gv[4 * k + 2] = x.z; gv[4 * k + 3] = x.w;
+    }
+    const long rowi = (long)bc * f.C + mc;
+    // saved forward row + statistics + AdaIN parameters: requested in front of the residual join
+    float yv[16];
+    const float* yrow = f.y + rowi * Tout + t0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 x = *(const float4*)(yrow + 4 * k);
+        yv[4 * k] = x.x; yv[4 * k + 1] = x.y; yv[4 * k + 2] = x.z; yv[4 * k + 3] = x.w;
+    }
+    const float mean = f.mean[rowi], rstd = f.rstd[rowi];
+    float gamma = 1.f, beta = 0.f;
+    if (f.cond) {
+        const float* cr = f.cond + (long)bc * f.cond_sb + f.cond_off;
+        beta = cr[mc];
+        gamma = cr[f.C + mc];
+    }
+    if (a.res_mode != AVC_RES_NONE) {   // residual-gradient join (contiguous rows [B][M][Tres]; res_to_primary)
+        const float* rrow = g.res + ((long)bc * a.M + mc) * a.Tres;
+        if (a.res_mode == AVC_RES_IDENTITY) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 x = *(const float4*)(rrow + t0 + 4 * k);
+                gv[4 * k] += x.x; gv[4 * k + 1] += x.y; gv[4 * k + 2] += x.z; gv[4 * k + 3] += x.w;
+            }
+        } else if (a.res_mode == AVC_RES_POOLT) {   // adjoint of the ceil-mode pool: g[t / 2] / 2 (Tout even: no clipped window)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float4 x = *(const float4*)(rrow + (t0 >> 1) + 4 * k);
+                gv[8 * k] += x.x * 0.5f; gv[8 * k + 1] += x.x * 0.5f; gv[8 * k + 2] += x.y * 0.5f; gv[8 * k + 3] += x.y * 0.5f;
+                gv[8 * k + 4] += x.z * 0.5f; gv[8 * k + 5] += x.z * 0.5f; gv[8 * k + 6] += x.w * 0.5f; gv[8 * k + 7] += x.w * 0.5f;
+            }
+        } else {   // AVC_RES_UPT: adjoint of nearest x2: g[2t] + g[2t + 1]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 x = *(const float4*)(rrow + 2 * t0 + 4 * k);
+                gv[2 * k] += x.x + x.y;
+                gv[2 * k + 1] += x.z + x.w;
+            }
+        }
+    }
+    if (valid && g.out) {   // the block's residual path reads g too
+        float* grow = g.out + ((long)b * a.M + m) * Tout + t0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(float4*)(grow + 4 * k) = make_float4(gv[4 * k], gv[4 * k + 1], gv[4 * k + 2], gv[4 * k + 3]);
+    }
+    float xh[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float hh = in_xhat(yv[i], mean, rstd);
+        const float w = in_preact(hh, gamma, beta);
+        const float gme = avc_act_grad(gv[i], !f.relu || w > 0.f, a.slope);
+        xh[i] = hh;
+        gv[i] = gme;
+        s1 += gme;
+        s2 += gme * hh;
+    }
+    for (int o = 1; o < lpr; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (!valid) return;
+    if (f.dcond && qd % lpr == 0) {
+        float* dc = f.dcond + (long)b * f.dcond_sb + f.dcond_off;
+        dc[m] = s1;
+        dc[f.C + m] = s2;
+    }
+    const float invT = 1.0f / (float)Tout;
+    const float m1 = gamma * s1 * invT, m2 = gamma * s2 * invT;
+    float* drow = f.dy + rowi * Tout + t0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 o;
+        o.x = rstd * (gv[4 * k] * gamma - m1 - xh[4 * k] * m2);
+        o.y = rstd * (gv[4 * k + 1] * gamma - m1 - xh[4 * k + 1] * m2);
+        o.z = rstd * (gv[4 * k + 2] * gamma - m1 - xh[4 * k + 2] * m2);
+        o.w = rstd * (gv[4 * k + 3] * gamma - m1 - xh[4 * k + 3] * m2);
+        *(float4*)(drow + 4 * k) = o;
+    }
+}
+
 // ... on bf16 PAIR tensors (compute_dtype "bf16", bf16_pairs.h; ops == 1): y is rounded to bf16 FIRST -- statistics, x_hat and the activation
 // decision are taken from the stored values, exactly what instnorm_fwd_pairs_kernel reads back and what the backward pass recomputes --
 // then the lanes of rows (2p, 2p + 1) exchange halves: each packs 8 frames of the pair row (two 16-byte stores per tensor).

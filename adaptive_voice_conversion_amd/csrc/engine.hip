@@ -1372,6 +1372,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // offset, and InstanceNorm / AdaIN statistics and d(cond) rows are per sample.
         struct ChainSt {
             float *gA, *gB, *gC;
+            bool fused;   // the InstanceNorm backward that opens the NEXT phase already ran inside this phase's input-gradient launch
         };
         // phase 0: out_conv input gradient; phases 1 .. 2n walk the blocks from the last one: (AdaIN backward of the second conv + its input
         // gradient) / (AdaIN backward of the first conv + its input gradient joined with the skip path); phase 2n + 1: IN backward + in_conv
@@ -1389,15 +1390,35 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 }
                 return avc_launch_in_bwd(a, s);
             };
+            // An input-gradient launch whose output rows are the d(out) of the NEXT phase's InstanceNorm layer runs that layer's backward
+            // in its epilogue where the tile holds whole rows (rows of 16 / 32 / 64 frames, fp32: avc_conv_inb_fusable); the next phase
+            // then skips its row kernel.  `keep_g`: the launch's own output is read again (the block's skip path).
+            auto dgrad_inb = [&](ConvArgs& a, bool keep_g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy) -> int {
+                st.fused = false;
+                if (!bh && a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {
+                    a.inb.dy = dy + off; a.inb.y = ws + yoff + off;
+                    a.inb.mean = ws + stoff + (long)b0 * Cc; a.inb.rstd = ws + stoff + (long)B * Cc + (long)b0 * Cc;
+                    a.inb.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.inb.cond_sb = csb; a.inb.cond_off = coff;
+                    a.inb.dcond = cond ? ws + d.dcond + (long)b0 * csb : nullptr; a.inb.dcond_sb = csb; a.inb.dcond_off = coff;
+                    a.inb.C = Cc; a.inb.relu = 1;
+                    if (!keep_g) a.g[0].out = nullptr;
+                    st.fused = true;
+                }
+                return avc_launch_conv(a, s, 0, p->tun);
+            };
+            const bool was_fused = st.fused;   // (set by the previous phase of THIS chain)
             if (ph == 0) {
                 const long oi = (long)b0 * Mr * To, oo = (long)b0 * C * To;
                 ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, Mr * To, To, 1, 1, Bn, To, To, st.gA + oo, (long)C * To, To, 1);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
+                // next: the AdaIN backward of the last block's second conv (rows of To frames)
+                const int ln = d.n - 1;
+                RUN(dgrad_inb(a, true, oo, d.y2[ln], d.st2[ln], d.T[ln + 1], (2 * ln + 1) * 2 * Cc, true, dy2[ln]));
                 return 0;
             }
             if (ph == 2 * d.n + 1) {
                 const long ob = (long)b0 * C * Tb;
-                RUN(half_in_bwd(st.gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
+                if (!was_fused) RUN(half_in_bwd(st.gA, ob, d.y0, d.st0, Tb, 0, false, dy0));
+                st.fused = false;
                 ConvArgs a = mk_dgrad(SL, Li, ws, dy0 + ob, (long)C * Tb, Tb, 1, 1, Bn, Tb, Tb, ws + p->dz + (long)b0 * Czc * Tb, (long)Czc * Tb, Tb, 1);
                 a.pairs = 0;   // d(z) is fp32: the latent backward combines it with the fp32 mu / log_sigma
                 RUN(avc_launch_conv(a, s, 0, p->tun));
@@ -1407,18 +1428,21 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             const int Ti = d.T[l], T2 = d.T[l + 1], up = d.c.upsample[l];
             const long o2 = (long)b0 * C * T2, o1 = (long)b0 * C * Ti;
             if ((ph - 1) % 2 == 0) {
-                RUN(half_in_bwd(st.gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * Cc, true, dy2[l], (bh && up > 1) ? 1 : 0));
+                if (!was_fused) RUN(half_in_bwd(st.gA, o2, d.y2[l], d.st2[l], T2, (2 * l + 1) * 2 * Cc, true, dy2[l], (bh && up > 1) ? 1 : 0));
                 // dy2 is the pixel-shuffled layout [B, C, Ti*up]; view it as the conv output [B, C*up, Ti]
                 // (pair plans: dy2 was written planar = as the conv-output pairs [B][c_h up / 2][Ti], a plain stride-1 source)
                 ConvArgs a = bh ? mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, Ti, 1, 1, Bn, Ti, Ti, st.gB + o1, (long)C * Ti, Ti, 1)
                                 : mk_dgrad(SL, p->layers[d.c2[l]], ws, dy2[l] + o2, (long)C * T2, T2, up, up, Bn, Ti, Ti, st.gB + o1, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
+                // next: the AdaIN backward of this block's first conv (rows of Ti frames); gB has no other reader
+                RUN(dgrad_inb(a, false, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
                 return 0;
             }
-            RUN(half_in_bwd(st.gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
+            if (!was_fused) RUN(half_in_bwd(st.gB, o1, d.y1[l], d.st1[l], Ti, (2 * l) * 2 * Cc, true, dy1[l]));
             ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, st.gC + o1, (long)C * Ti, Ti, 1);
             set_res(a, st.gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
+            // next: the AdaIN backward of the previous block's second conv, or the in_conv's InstanceNorm (rows of Ti frames); gC feeds the skip path too
+            if (l > 0) RUN(dgrad_inb(a, true, o1, d.y2[l - 1], d.st2[l - 1], Ti, (2 * (l - 1) + 1) * 2 * Cc, true, dy2[l - 1]));
+            else RUN(dgrad_inb(a, true, o1, d.y0, d.st0, Tb, 0, false, dy0));
             float* t = st.gA; st.gA = st.gC; st.gC = t;
             return 0;
         };
@@ -1441,7 +1465,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         };
         {
             const int nph = 2 * d.n + 2;
-            ChainSt st0 = {ws + p->gA, ws + p->gB, ws + p->gC}, st1 = st0;
+            ChainSt st0 = {ws + p->gA, ws + p->gB, ws + p->gC, false}, st1 = st0;
             const bool split = !dry && B >= p->tun.dec_split_min && side_ready(p);
             const int Bh = B / 2;
             const hipStream_t s2 = split ? fork_side(p, s) : s;
@@ -1514,33 +1538,49 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         const float* dmuls = ws + (bh ? p->dmulsp : p->dmuls);
         const LayerP& Lh = p->layers[e.heads];
         RUN(wgrad_layer(c, Lh, ws + e.out[e.n], (long)C * Tb, Tb, 1, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb));
-        if (!dry) {
+        // An input-gradient launch whose output rows are the d(out) of the NEXT InstanceNorm layer runs that layer's backward in its
+        // epilogue where the tile holds whole rows (avc_conv_inb_fusable); the row kernel then stays out of the chain.
+        auto dgrad_inb = [&](ConvArgs& a, bool keep_g, const float* y, const float* st, int T, float* dy) -> bool {
+            bool fused = false;
+            if (!bh && a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {
+                a.inb.dy = dy; a.inb.y = y; a.inb.mean = st; a.inb.rstd = st + (long)B * Cc;
+                a.inb.C = Cc; a.inb.relu = 1;
+                if (!keep_g) a.g[0].out = nullptr;
+                fused = true;
+            }
+            return fused;
+        };
+        bool fused = false;
+        dyA = c.fresh((long)B * C * e.T[e.n]);   // d(y2) of the last block
+        {
             ConvArgs a = mk_dgrad(SL, Lh, ws, dmuls, (long)Co2 * Tb, Tb, 1, 1, B, Tb, Tb, gA, (long)C * Tb, Tb, 1);
-            RUN(avc_launch_conv(a, s, 0, p->tun));
+            fused = dgrad_inb(a, true, ws + e.y2[e.n - 1], ws + e.st2[e.n - 1], e.T[e.n], dyA);
+            if (!dry) RUN(avc_launch_conv(a, s, 0, p->tun));
         }
         for (int l = e.n - 1; l >= 0; --l) {
             const int Ti = e.T[l], T2 = e.T[l + 1], sub = e.c.subsample[l];
             const LayerP& L1 = p->layers[e.c1[l]];
             const LayerP& L2 = p->layers[e.c2[l]];
-            dyA = c.fresh((long)B * C * T2);
-            if (!dry) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, Cc, T2, nullptr, 0, 0, dyA, nullptr, s, bh, NV));
-            if (!dry) {
+            if (!dry && !fused) RUN(in_bwd(SL, gA, ws + e.y2[l], ws + e.st2[l], B, Cc, T2, nullptr, 0, 0, dyA, nullptr, s, bh, NV));
+            dyB = c.fresh((long)B * C * Ti);
+            {
                 ConvArgs a = mk_dgrad(SL, L2, ws, dyA, (long)C * T2, T2, 1, 1, B, T2, Ti, gB, (long)C * Ti, Ti, 1);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
+                fused = dgrad_inb(a, false, ws + e.y1[l], ws + e.st1[l], Ti, dyB);   // gB has no other reader
+                if (!dry) RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L2, ws + e.a1[l], (long)C * Ti, Ti, 1, dyA, (long)C * T2, T2, 1, 1, B, Ti, T2));
-            dyB = c.fresh((long)B * C * Ti);
-            if (!dry) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, Cc, Ti, nullptr, 0, 0, dyB, nullptr, s, bh, NV));
-            if (!dry) {
+            if (!dry && !fused) RUN(in_bwd(SL, gB, ws + e.y1[l], ws + e.st1[l], B, Cc, Ti, nullptr, 0, 0, dyB, nullptr, s, bh, NV));
+            dyA = c.fresh((long)B * C * Ti);   // d(y2) of block l - 1, or d(in_conv output) for l == 0: rows of Ti frames either way
+            {
                 ConvArgs a = mk_dgrad(SL, L1, ws, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti, gC, (long)C * Ti, Ti, 1);
                 set_res(a, gA, sub > 1 ? AVC_RES_POOLT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
-                RUN(avc_launch_conv(a, s, 0, p->tun));
+                fused = dgrad_inb(a, true, l > 0 ? ws + e.y2[l - 1] : ws + e.h0, l > 0 ? ws + e.st2[l - 1] : ws + e.st0, Ti, dyA);   // gC feeds the skip path too
+                if (!dry) RUN(avc_launch_conv(a, s, 0, p->tun));
             }
             RUN(wgrad_layer(c, L1, ws + e.out[l], (long)C * Ti, Ti, 1, dyB, (long)C * Ti, Ti, 1, 1, B, Ti, Ti));
             rot();
         }
-        dyA = c.fresh((long)B * C * e.T[0]);
-        if (!dry) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh, NV));
+        if (!dry && !fused) RUN(in_bwd(SL, gA, ws + e.h0, ws + e.st0, B, Cc, e.T[0], nullptr, 0, 0, dyA, nullptr, s, bh, NV));
         RUN(enc_back_front(c, e, x, sxb, sxc, sxt, dyA));
         if (!dry) avc_prof_mark(3, s);
         RUN(flush_wgrads(c));

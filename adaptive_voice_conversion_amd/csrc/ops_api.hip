@@ -100,6 +100,8 @@ int avc_instnorm_fwd(const float* y, int B, int C, int T, const float* cond, lon
                      int Tres, float* out, float* mean, float* rstd, void* stream);
 int avc_instnorm_fwd_pairs(const void* y, int B, int C, int T, const float* cond, long cond_sb, int cond_off, int relu, const void* res, int res_mode,
                            int Tres, int planar, void* out, float* mean, float* rstd, void* stream);
+int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const float* rstd, int B, int C, int T, const float* cond, long cond_sb,
+                     int cond_off, int relu, float* dy, float* dcond, long dcond_sb, int dcond_off, void* stream);
 
 long avc_packed_weight_floats(int Cout, int Cin, int KS, int dgrad) {
     int CK = avc_conv_ck(avc_op_tuning(), KS);
@@ -245,6 +247,49 @@ static void op_wgrad_args(WgradArgs& a, int B, int Cin, int Cout, int Tin, int T
     a.x.ps = 1; a.dy.ps = 1;
     a.cw8 = t.wgrad_cw8 ? 1 : 0;
 }
+// The backward twin of avc_conv1d_in_fwd: g = conv1d_input_grad(dy) [+ resT(res)] is d(loss)/d(out) of an InstanceNorm / AdaIN layer whose saved
+// forward rows are y / mean / rstd; returns d(loss)/d(y) in dy_out (+ dcond) -- inside the input-gradient launch's epilogue where its tile holds
+// whole rows (rows of 16 / 32 / 64 frames, exact fp32; *fused = 1), otherwise as that launch followed by the row kernel.  g itself is written
+// to g_out when it is not NULL (a fused launch whose g nobody else reads may pass NULL; the two-launch path needs it as scratch).
+int avc_conv1d_dgrad_in_bwd(const float* dy, long syb, long syc, int syt, int yps, int B, int Cout, int Tdy, const float* wpd, int Cin, int KS,
+                            int stride, int Tin, float* g_out, const float* res, int res_mode, int Tres, const float* y, const float* mean,
+                            const float* rstd, const float* cond, long cond_sb, int cond_off, int relu, float* dy_out, float* dcond,
+                            long dcond_sb, int dcond_off, int* fused, void* stream) {
+    if (op_bh()) return -2;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    op_compute(a);
+    a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
+    a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
+    a.mode = 1; a.stride = stride;
+    const int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
+    a.mirror = (KS > 1) ? 1 : 0;
+    a.M = Cin; a.Mp = avc_cdiv(Cin, 128) * 128;
+    a.Tout = Tin;
+    a.ob = (long)Cin * Tin; a.oc = Tin; a.ot = 1; a.ops = 1;
+    a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
+    a.res_mode = res ? res_mode : AVC_RES_NONE; a.res_to_primary = 1;
+    a.rb = (long)Cin * Tres; a.rc = Tres; a.rt = 1; a.Tres = Tres;
+    a.ngroups = 1;
+    a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
+    a.g[0].wp = wpd; a.g[0].out = g_out; a.g[0].res = res;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
+    a.img = AVC_IMG_K4;
+    const bool fuse = avc_conv_inb_fusable(a, avc_op_tuning());
+    if (fused) *fused = fuse ? 1 : 0;
+    if (fuse) {
+        a.inb.dy = dy_out; a.inb.y = y; a.inb.mean = mean; a.inb.rstd = rstd;
+        a.inb.cond = cond; a.inb.cond_sb = cond_sb; a.inb.cond_off = cond_off;
+        a.inb.dcond = dcond; a.inb.dcond_sb = dcond_sb; a.inb.dcond_off = dcond_off;
+        a.inb.C = Cin; a.inb.relu = relu ? 1 : 0;
+        return avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
+    }
+    if (!g_out) return -1;
+    int rc = avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
+    if (rc) return rc;
+    return avc_instnorm_bwd(g_out, y, mean, rstd, B, Cin, Tin, cond, cond_sb, cond_off, relu, dy_out, dcond, dcond_sb, dcond_off, stream);
+}
+
 long avc_conv1d_wgrad_ws_floats(int B, int Cin, int Cout, int Tout, int KS) {
     long need = 0;
     for (int stride = 1; stride <= 2; ++stride) {   // (the query does not know the stride: both geometries fit)

@@ -355,6 +355,15 @@ int avc_instnorm_bwd(const float* g, const float* y, const float* mean, const fl
 int avc_conv1d_in_fwd(const float* x, long sxb, long sxc, int sxt, int B, int Cin, int Tin, const float* wp, const float* bias, int Cout, int KS,
                       int stride, int ops, float* y, const float* cond, long cond_sb, int cond_off, int relu, const float* res, int res_mode,
                       int Tres, float* out, float* mean, float* rstd, int* fused, void* stream);
+/* ... and its autograd counterpart one layer up: g = conv1d_input_grad(dy) [+ resT(res): res_mode 1 identity, 3 pool^T, 4 up^T] is the gradient
+ * wrt the OUTPUT of an InstanceNorm / AdaIN / activation layer whose saved forward rows are y / mean / rstd ([B][Cin][Tin] contiguous); the call
+ * returns the gradient wrt that layer's INPUT rows in dy_out, and dbeta / dgamma in dcond (avc_instnorm_bwd's layout).  One launch where the
+ * input-gradient tile holds whole rows (Tin = 16 / 32 / 64: the normalisation's backward runs in the epilogue), two otherwise.  g_out (may be
+ * NULL when fused): g itself, for callers that read it again (the skip path of a block). */
+int avc_conv1d_dgrad_in_bwd(const float* dy, long syb, long syc, int syt, int yps, int B, int Cout, int Tdy, const float* wpd, int Cin, int KS,
+                            int stride, int Tin, float* g_out, const float* res, int res_mode, int Tres, const float* y, const float* mean,
+                            const float* rstd, const float* cond, long cond_sb, int cond_off, int relu, float* dy_out, float* dcond,
+                            long dcond_sb, int dcond_off, int* fused, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,3 +185,68 @@ def reference_from_y(y, cond, cond_off, relu, res, res_mode):
     if res is not None:
         o = o + {1: lambda r: r, 2: lambda r: O.avg_pool_ceil(r, 2), 5: lambda r: O.upsample_nearest(r, 2)}[res_mode](res)
     return y, o
+
+
+# ---- the backward twin: InstanceNorm / AdaIN / activation BACKWARD inside the epilogue of the input-gradient launch that produces its g
+# (autograd of model.py:309-320 / :353-369 one layer up).  Against the two-launch path (dgrad, then the row kernel): g bit for bit, dy / dcond
+# to summation order -- the two-launch path itself is pinned to torch autograd by tests/test_ops_conv.py and tests/test_ops_rowops.py.
+# B, Cin (= channels of the normalised rows), Cout, T (rows), KS, stride of the conv whose dgrad this is, res_mode (0, 1 identity, 3 pool^T, 4 up^T), affine, relu, fused expected
+BWD_CASES = [
+    (3, 32, 16, 64, 5, 1, 0, False, 1, 1),
+    (5, 40, 16, 32, 5, 1, 1, True, 1, 1),      # two samples per tile, ragged last tile, 40 of 64 rows, AdaIN gradients, identity join
+    (6, 64, 24, 16, 5, 1, 4, True, 2, 1),      # four samples per tile, the upsample's adjoint (model.py:61-63), LeakyReLU
+    (3, 32, 16, 64, 5, 2, 3, False, 1, 1),     # stride-2 conv: its input gradient deals columns to the waves by parity; pool^T join
+    (4, 32, 16, 32, 5, 2, 0, False, 1, 1),     # ... short rows
+    (9, 128, 128, 16, 5, 1, 1, False, 1, 1),   # split-K wave groups in front of the fused epilogue
+    (2, 32, 48, 32, 1, 1, 0, True, 1, 1),      # 1x1 (the heads / in_conv input gradients)
+    (2, 32, 16, 128, 5, 1, 0, False, 1, 0),    # rows of 128 frames: not fusable
+    pytest.param(64, 128, 128, 64, 5, 1, 1, True, 1, 1, marks=GPU),
+    pytest.param(256, 128, 128, 32, 5, 2, 3, False, 1, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride,res_mode,affine,relu,want_fused", BWD_CASES)
+def test_conv_dgrad_in_bwd_fused_epilogue(kind, B, Cin, Cout, T, KS, stride, res_mode, affine, relu, want_fused):
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 7 + T)
+    Tdy = O.pad_conv(torch.zeros(1, Cin, T), torch.zeros(Cout, Cin, KS), None, stride).shape[2]
+    w = (torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5).to(dev)
+    dy = torch.randn(B, Cout, Tdy, generator=g).to(dev)
+    y = torch.randn(B, Cin, T, generator=g)
+    mean = y.mean(2).reshape(-1).to(dev)
+    rstd = (1.0 / torch.sqrt(y.var(2, unbiased=False) + 1e-5)).reshape(-1).to(dev)
+    y = y.to(dev)
+    cond = torch.randn(B, 2 * Cin + 6, generator=g).to(dev) if affine else None
+    coff = 6 if affine else 0
+    Tres = {0: 0, 1: T, 3: T // 2, 4: 2 * T}[res_mode]
+    res = torch.randn(B, Cin, Tres, generator=g).to(dev) if res_mode else None
+    wpd = pack(lib, dev, [w], 1)
+
+    def go():
+        gout = torch.full((B, Cin, T), float("nan"), device=dev)
+        dyo = torch.full((B, Cin, T), float("nan"), device=dev)
+        dcond = torch.zeros_like(cond) if affine else None
+        fused = ctypes.c_int(-1)
+        rc = lib.avc_conv1d_dgrad_in_bwd(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, Tdy, P(wpd), Cin, KS, stride, T, P(gout), P(res),
+                                         res_mode, Tres, P(y), P(mean), P(rstd), P(cond), cond.stride(0) if affine else 0, coff, relu, P(dyo),
+                                         P(dcond), dcond.stride(0) if affine else 0, coff, ctypes.byref(fused), None)
+        assert rc == 0, rc
+        return gout, dyo, dcond, fused.value
+
+    g1, d1, c1, fused = go()
+    assert fused == want_fused
+    assert lib.avc_set_tuning(b"conv_in_fuse", 0) == 0
+    try:
+        g2, d2, c2, fused2 = go()
+    finally:
+        lib.avc_set_tuning(b"conv_in_fuse", 1)
+    assert fused2 == 0
+    assert torch.isfinite(d1).all() and torch.isfinite(g1).all()
+    assert torch.equal(g1, g2)                                  # the same accumulators + the same join
+    scale = d2.abs().max().item()
+    torch.testing.assert_close(d1, d2, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    if affine:
+        torch.testing.assert_close(c1, c2, rtol=1e-4, atol=1e-4)
