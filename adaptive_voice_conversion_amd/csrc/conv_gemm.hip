@@ -938,7 +938,7 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
     if (tile == 0) {
         tile = avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, a.ngroups, a.Cred * a.g[0].KS * (a.bf16 == AVC_COMPUTE_BF16S ? 2 : 1));
         // 64 x 128: half the weight-image traffic per column; only while the launch keeps the chip full
-        if (tile == 11 && wide_ok && tun.tile12_wgs > 0) {
+        if (tile == 11 && wide_ok && tun.tile12_wgs > 0 && !a.in.out && !a.inb.dy) {   // (the fused InstanceNorm epilogues live on 64 x 64 tiles)
             const long ntn = a.Tout >= 128 ? (long)a.B * avc_cdiv(a.Tout, 128) : (long)avc_cdiv(a.B, 128 / a.Tout);
             if ((long)(a.Mp / 64) * ntn >= tun.tile12_wgs) tile = 12;
         }

@@ -250,3 +250,23 @@ def test_conv_dgrad_in_bwd_fused_epilogue(kind, B, Cin, Cout, T, KS, stride, res
     torch.testing.assert_close(d1, d2, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
     if affine:
         torch.testing.assert_close(c1, c2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fused_epilogues_keep_their_tile_under_the_wide_tile_switch(kind):
+    """avc_tuning.tile12_wgs (opt-in: 64 x 128 tiles for k = 5 layers that keep the chip full) must not pull a launch that carries a fused
+    InstanceNorm epilogue off its 64 x 64 tile: same result, still one launch."""
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 16, 64, generator=g).to(dev)
+    w = (torch.randn(32, 16, 5, generator=g) / 9).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    ref = run(lib, dev, x, w, b, 1, 1, None, 0, 1, None, 0)
+    assert lib.avc_set_tuning(b"tile12_wgs", 1) == 0
+    try:
+        got = run(lib, dev, x, w, b, 1, 1, None, 0, 1, None, 0)
+    finally:
+        lib.avc_set_tuning(b"tile12_wgs", 0)
+    assert got[4] == 1 and ref[4] == 1
+    for a, c in zip(ref[:4], got[:4]):
+        assert torch.equal(a, c)
