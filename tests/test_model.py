@@ -363,3 +363,36 @@ def test_weights_packed_behind_the_optimizer_step(kind, tmp_path):
     c, _ = run(False, True)
     d, _ = run(True, True)
     assert c[:2] == a[:2] and c[2] == d[2] and c[2]["loss_rec"] != a[2]["loss_rec"]
+
+
+def test_packed_weights_promise_fails_safe(tmp_path):
+    """writes that bypass torch's version counters (`p.data.copy_`, a foreign kernel, a collective on the flat buffer) must not
+    leave the next forward on stale weight images silently.  (1) `AE.weights_changed()` voids the promise; (2) `repack_every_step: true`
+    gives it up altogether -- a `.data` edit is then picked up; (3) `verify_packed_weights: true` raises on such an edit."""
+    lib, dev = backend("emu")
+    sd = O.make_state_dict(O.tiny_config(), 3)
+    x, eps = O.make_inputs(O.tiny_config(), 2, 32, 3)
+    args = types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir=str(tmp_path / "log"))
+
+    def run(extra, after_edit=None, edit=True):
+        cfg = dict(O.tiny_config())
+        cfg.update(extra)
+        s = Solver(cfg, args, lib=lib)
+        s.model.load_state_dict(sd)
+        s.ae_step(x, 1.0, eps=eps)
+        s.ae_step(x, 1.0, eps=eps)
+        if edit:
+            s.model.decoder.out_conv_layer.weight.data.mul_(0.5)   # bypasses every version counter
+        if after_edit:
+            after_edit(s)
+        return s.ae_step(x, 1.0, eps=eps)["loss_rec"]
+
+    stale = run({})                                             # the documented hazard: the edit is NOT seen (images packed before it)
+    clean = run({}, edit=False)
+    assert stale == clean
+    told = run({}, after_edit=lambda s: s.model.weights_changed())
+    repack = run({"repack_every_step": True})
+    assert told == repack and told != stale                     # both see the edited weights
+    with pytest.raises(RuntimeError, match="changed behind the version counters"):
+        run({"verify_packed_weights": True})
+    assert run({"verify_packed_weights": True}, edit=False) == clean
