@@ -17,6 +17,8 @@ static avc_tuning make_default_tuning() {
     t.struct_size = (int)sizeof(avc_tuning);
     t.dec_split_min = 128;   // r3 (profiles/r03_tune_sweeps.log): B = 64 is 3.6 % faster unsplit (3.12 vs 3.24 ms), B = 256 0.4 % faster split
     t.dgrad_par = 1;
+    t.side_prio = 1;   // round 5 (profiles/r05_tune_sweep.log): 5.89 vs 6.02 ms per step on two boxes, four A/B pairs; neutral in rounds 3-4, before the
+                       // stream-K weight gradient and the fused InstanceNorm epilogues changed what shares the chip with the side branch
     t.bank_switch = 1;
     t.conv_ck5 = 8;
     t.wgrad_batch = 12;

@@ -142,8 +142,9 @@ typedef struct avc_tuning {
     int conv_ablation;      /* timing experiments only, WRONG results when set: bit0 no DMA, bit1 no MFMA, bit2 no barrier, bit3 no store */
     int wgrad_ablation;
     int op_compute_dtype;   /* op-level conv entry points: 0 fp32, 1 bf16 operands (plans: avc_plan_set_compute_dtype) */
-    int side_prio;          /* 1: the plan's side stream (speaker-encoder branch, the longer pole of forward and backward) is created with the
-                             * highest stream priority; 0: normal priority */
+    int side_prio;          /* 1 (default since round 5): the plan's side stream (speaker-encoder branch, the longer pole of forward and backward) is
+                             * created with the highest stream priority -- its kernels are dispatched ahead of the weight-gradient launches and the
+                             * other branch's when CU slots free up (-2.2 % on the B = 256 step); 0: normal priority */
     int tile12_wgs;         /* 64 x 128 column tiles (two fragments per wave share each weight fragment) for stride-1 k = 5 layers whose launch still has
                              * at least this many workgroups; 0 = never */
     long wgrad_batch_units; /* pending (tile x K-chunk) units that trigger a batched launch early (1 << 40 = never) */
