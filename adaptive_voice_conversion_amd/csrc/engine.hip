@@ -594,11 +594,10 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
     if (p->pack_tab_dev) hipFree(p->pack_tab_dev);
     if (p->pack_blk_dev) hipFree(p->pack_blk_dev);
     // every handle that exists, whatever state plan_init_streams ended in
-    if (p->side) hipStreamDestroy(p->side);
+    // (the helper streams belong to the device's shared set: shared_streams())
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_join) hipEventDestroy(p->ev_join);
     for (int i = 0; i < 2; ++i) {
-        if (p->wstream[i]) hipStreamDestroy(p->wstream[i]);
         if (p->wjoin[i]) hipEventDestroy(p->wjoin[i]);
         if (p->ev_pack[i]) hipEventDestroy(p->ev_pack[i]);
     }
@@ -678,16 +677,66 @@ static void plan_init_pack_table(avc_plan* p) {
     p->pack_tab_bytes = bytes;
 }
 
+// The three helper streams of a plan -- the side branch's and the two weight-gradient streams -- are ONE set per device, shared by every plan
+// of the process and kept for its lifetime (round 5).  The runtime deals streams to a handful of hardware queues in creation order: the
+// first plan's three streams and the caller's stream take four of them, a second plan's OWN three land wherever the round-robin has got
+// to -- its side stream on the caller's queue, for one: both branches of a pass then run one after the other (bf16 step 4.9 - 6.1 instead of
+// 2.59 ms, measured: scripts/two_plans_probe.py).  Plans never run their helper streams concurrently in the host code of this package, and if
+// two callers do drive two plans at once the shared streams only add ordering, never a hazard: every wait is on an event recorded earlier.
+// Immutable once created; the lookup is mutex-protected.  (Not "mutable state" in the sense of include/avc_hip.h: nothing here changes
+// how any call behaves.)
+#ifndef AVC_EMU
+#include <mutex>
+#endif
+struct DevStreams {
+    hipStream_t side[2] = {nullptr, nullptr};   // [normal priority, highest priority]
+    hipStream_t w[2] = {nullptr, nullptr};
+    bool ok = false;
+};
+static bool shared_streams(int side_prio, hipStream_t* side, hipStream_t* w0, hipStream_t* w1) {
+#ifdef AVC_EMU
+    static DevStreams pool[1];
+    const int dev = 0;
+#else
+    static std::mutex mu;
+    static DevStreams pool[64];
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return false;
+    }
+#endif
+    DevStreams& d = pool[dev];
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
+    const int sp = side_prio ? 1 : 0;
+    if (!d.side[sp]) {
+        // the side stream carries the speaker-encoder branch: the LONGER pole of both passes (forward: pooling + the latency-bound dense stack
+        // after its convs, before the decoder can start; backward: d_emb -> dense stack -> its whole dgrad chain -> the last weight gradients).
+        // side_prio = 1 dispatches its workgroups ahead of the content branch's and the weight-gradient streams'.
+        if ((sp ? hipStreamCreateWithPriority(&d.side[sp], hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&d.side[sp], hipStreamNonBlocking)) != hipSuccess) {
+            (void)hipGetLastError();  // no device: single-stream plan
+            d.side[sp] = nullptr;
+            return false;
+        }
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!d.w[i] && hipStreamCreateWithPriority(&d.w[i], hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            d.w[i] = nullptr;
+            return false;
+        }
+    *side = d.side[sp]; *w0 = d.w[0]; *w1 = d.w[1];
+    return true;
+}
+
 static void plan_init_streams(avc_plan* p) {
     plan_init_pack_table(p);
     p->side_state = -1;
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
-    // the side stream carries the speaker-encoder branch: the LONGER pole of both passes (forward: pooling + the latency-bound dense stack
-    // after its convs, before the decoder can start; backward: d_emb -> dense stack -> its whole dgrad chain -> the last weight gradients).
-    // side_prio = 1 dispatches its workgroups ahead of the content branch's and the weight-gradient streams'.
-    if ((p->tun.side_prio ? hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking)) != hipSuccess) {
-        (void)hipGetLastError();  // no device: single-stream plan
+    if (!shared_streams(p->tun.side_prio, &p->side, &p->wstream[0], &p->wstream[1])) {
+        p->side = nullptr;
+        p->wstream[0] = p->wstream[1] = nullptr;
         return;
     }
     bool ok = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
@@ -697,7 +746,6 @@ static void plan_init_streams(avc_plan* p) {
               hipEventCreateWithFlags(&p->ev_spk_grads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2; ++i) {
-        ok = ok && hipStreamCreateWithPriority(&p->wstream[i], hipStreamNonBlocking, lo) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&p->ev_pack[i], hipEventDisableTiming) == hipSuccess;
     }

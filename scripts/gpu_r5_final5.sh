@@ -1,0 +1,14 @@
+# shared helper streams per device: the two-plans probe first; if the second plan is healthy, targeted tests + the refresh of the build-locked summaries + the bench line
+OUT=gpurun_out/${1:-r5final5}; mkdir -p $OUT; export TMPDIR=/tmp
+python scripts/two_plans_probe.py 2>&1 | grep side_prio | tee $OUT/probe.txt
+timeout 400 python -m pytest tests/test_engine.py tests/test_model.py tests/test_dist_nccl.py tests/test_feed_infer.py -q -m gpu -x 2>&1 | tail -2 | tee $OUT/tests.txt
+B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-config2 --single-stream"
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sqA -o pmc -- $B > $GRAFT_REPO_ROOT/$OUT/sqA.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/sqB -o pmc -- $B > $GRAFT_REPO_ROOT/$OUT/sqB.log 2>&1)
+AVC_GIT_HEAD=${2:-unknown} python scripts/sq_step_summary.py $OUT/sq_step.json /tmp/sqA /tmp/sqB > $OUT/sq_classes.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-config2 > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
+done
+AVC_GIT_HEAD=${2:-unknown} python scripts/pmc_summary.py $OUT/pmc_fetch_write_summary.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > /dev/null
+cp $OUT/pmc_fetch_write_summary.json profiles/r05_pmc_fetch_write_summary.json; cp $OUT/sq_step.json profiles/r05_sq_step.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 150 $OUT/bench.json
