@@ -32,6 +32,45 @@ static constexpr __host__ __device__ int wg_xrow_lin(int KS) {
 #define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue); CW = 8 instances: 8 + 4 waves = 768 threads
 static constexpr __host__ __device__ int wg_threads(int CW) { return (CW + 4) * 64; }
 
+// LDS stages per operand.  fp32 / bf16-operand / fp32x3 products: 2 -- chunk c + 1 lands while chunk c multiplies (40 us of MFMA per layer
+// hide a round trip per chunk; three / four stages measured neutral there, profiles/r03_wgrad_stages_ab.log).  bf16 PAIR storage (BF == 2,
+// round 6): a chunk multiplies for ~0.15 us and one 9-KB chunk in flight per CU is a LATENCY bound (8.7 KB per ~1-us round trip x 256 CUs
+// = 2 TB/s: the class ran 10x above both its roofs, profiles/r06_*).  So the producers of those instances run NSTG - 1 chunks ahead through a
+// ring of NSTG stages: the wait in front of a chunk's barrier is a PARTIAL s_waitcnt vmcnt(n) -- LDS-DMA loads complete in issue order, so
+// "at most n of this wave's DMA instructions outstanding" with n = (chunks issued behind chunk c + 1) x (this wave's instructions per
+// chunk) says chunk c + 1 has landed -- and the barrier itself is a bare s_barrier (the compiler's own drains vmcnt(0)).
+#ifndef AVC_WGRAD_STAGES_BH
+#define AVC_WGRAD_STAGES_BH 4
+#endif
+static constexpr __host__ __device__ int wg_stages(int BF) { return BF == 2 ? AVC_WGRAD_STAGES_BH : 2; }
+
+// s_waitcnt vmcnt(n), n = 0..63 (gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0]; expcnt / lgkmcnt untouched).  A larger request waits
+// for 63 -- stricter than asked, still correct.
+static __device__ __forceinline__ void wg_wait_dma(int n) {
+#ifndef AVC_EMU
+#define WG_W1(k) case (k): __builtin_amdgcn_s_waitcnt(((k) & 15) | (((k) >> 4) << 14) | (7 << 4) | (15 << 8)); break;
+#define WG_W4(k) WG_W1(k) WG_W1((k) + 1) WG_W1((k) + 2) WG_W1((k) + 3)
+#define WG_W16(k) WG_W4(k) WG_W4((k) + 4) WG_W4((k) + 8) WG_W4((k) + 12)
+    switch (n < 63 ? n : 63) {
+        WG_W16(0) WG_W16(16) WG_W16(32) WG_W16(48)
+    }
+#undef WG_W16
+#undef WG_W4
+#undef WG_W1
+#else
+    (void)n;   // (the simulator's LDS-DMA is synchronous)
+#endif
+}
+// workgroup barrier WITHOUT the compiler's vmcnt(0) drain.  LDS is written by the DMAs (waited for above) and by no ds_write on the
+// paths that use this barrier; ds_reads are consumed by the MFMAs in front of it.
+static __device__ __forceinline__ void wg_bare_barrier() {
+#ifdef AVC_EMU
+    emu::block_barrier();
+#else
+    asm volatile("s_barrier" ::: "memory");
+#endif
+}
+
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
 }
@@ -129,6 +168,7 @@ struct WgCfg {
     static constexpr int TPR = 256 / RCO;  // producer threads per dy row in the bias-gradient partial sum
     static constexpr int CPT = 32 / TPR;
     static constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
+    static constexpr int NSTG = wg_stages(BF);   // LDS stages per operand (wg_stages)
 };
 
 // ---------------- producers: waves 4-7.  Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
@@ -137,6 +177,7 @@ template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, int CW>
 static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
     using C = WgCfg<KS, RT, NB, WCO, LIN, BF, CW>;
     constexpr int TCO = C::TCO, TCI = C::TCI, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NPD = C::NPD, NPX = C::NPX, TPR = C::TPR, CPT = C::CPT;
+    constexpr int NSTG = C::NSTG, DIST = NSTG - 1;   // chunk c + DIST is issued while chunk c multiplies
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
     const int ptid = tid & 255;   // thread index inside the producer group (CW * 64 is a multiple of 256; the mask tells the compiler the range)
@@ -157,8 +198,8 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
         const int XROW = LIN ? wg_xrow_lin(KSr) : ((spc * XSEG) | 1);
         const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
         const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
-        float* dyT = smem;             // [2][RCO][WG_DYROW]
-        float* xT = smem + 2 * DYSP;   // [2][RCI][XROW]
+        float* dyT = smem;                // [NSTG][RCO][WG_DYROW]
+        float* xT = smem + NSTG * DYSP;   // [NSTG][RCI][XROW]
         const float inv_xrow = 1.0f / (float)XROW;
         const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
         const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
@@ -302,13 +343,34 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
             }
         };
 
+        // deep pipeline (NSTG > 2, the fast staging paths: every LDS write of a chunk is a DMA, and every chunk costs this wave the same
+        // number of DMA instructions): partial vmcnt waits + bare barriers; everything else keeps the draining barrier
+        const bool deep = NSTG > 2 && fastp && !(dbg & 5);   // (ablation bits 1 "no DMA" and 4 "no barrier" change the producer's flow: shallow path)
+        int ndma = 0;   // this wave's DMA instructions per chunk (issue_fast)
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) ndma += ((wave + 4 * i) * 64 < DYSP) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) ndma += ((wave + 4 * i) * 64 < XSP) ? 1 : 0;
+        const int nck = c_end - c_begin;
         __syncthreads();  // the zero fill / the previous segment's last reads are complete before the first DMA of this one lands
-        issue(c_begin, 0);
-        __syncthreads();  // (drains the DMA: the compiler's barrier waits for vmcnt(0))
+        if (deep) {
+            const int pre = nck < DIST ? nck : DIST;
+            for (int k = 0; k < pre; ++k) issue_fast(c_begin + k, k);
+            wg_wait_dma((pre - 1) * ndma);   // the first chunk has landed
+            wg_bare_barrier();
+        } else {
+            issue(c_begin, 0);
+            __syncthreads();  // (drains the DMA: the compiler's barrier waits for vmcnt(0))
+        }
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const int buf = (chunk - c_begin) & 1;
-            const bool more = (chunk + 1 < c_end) && !((dbg & 1) && chunk > c_begin);
-            if (more) issue(chunk + 1, buf ^ 1);
+            const int rel = chunk - c_begin;
+            const int buf = NSTG == 2 ? (rel & 1) : rel % NSTG;
+            if (deep) {
+                if (rel + DIST < nck) issue_fast(chunk + DIST, (rel + DIST) % NSTG);   // (that stage was last read during chunk c - 1: free since its barrier)
+            } else {
+                const bool more = (chunk + 1 < c_end) && !((dbg & 1) && chunk > c_begin);
+                if (more) issue(chunk + 1, NSTG == 2 ? (buf ^ 1) : (rel + 1) % NSTG);
+            }
             if (do_db) {   // bias gradient = row sums of the dy tile that is in LDS anyway
                 const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
 #pragma unroll
@@ -322,7 +384,13 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
                     }
                 }
             }
-            if (!(dbg & 4)) __syncthreads();
+            if (deep) {
+                // chunk c + 1 must have landed by this barrier; behind it, chunks c + 2 .. min(c + DIST, last) may still be in flight
+                const int last_issued = rel + DIST < nck - 1 ? rel + DIST : nck - 1;
+                const int behind = last_issued - (rel + 1);
+                wg_wait_dma(behind > 0 ? behind * ndma : 0);
+                wg_bare_barrier();
+            } else if (!(dbg & 4)) __syncthreads();
         }
         // ---- segment end
         auto store_db = [&](float v0, float v1) {   // finished bias gradient of this workgroup's co rows
@@ -368,6 +436,7 @@ template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
     using C = WgCfg<KS, RT, NB, WCO, LIN, BF, CW>;
     constexpr int WCI = C::WCI, TCO = C::TCO, TCI = C::TCI, NACC = C::NACC, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NBROW = C::NBROW;
+    constexpr int NSTG = C::NSTG;
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
     const int wave_m = wave / WCI, wave_n = wave % WCI, li = lane & 31, h = lane >> 5;
@@ -385,7 +454,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
         const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
         const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;
         const float* dyT = smem;
-        const float* xT = smem + 2 * DYSP;
+        const float* xT = smem + NSTG * DYSP;
         const long tile_floats = (long)CW * KSr * NB * 1024;   // consumer waves x (taps x blocks) accumulators x 16 registers x 64 lanes
         const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
         const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
@@ -396,7 +465,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
         __syncthreads();
         __syncthreads();   // the first chunk has landed
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const int buf = (chunk - c_begin) & 1;
+            const int buf = NSTG == 2 ? ((chunk - c_begin) & 1) : (chunk - c_begin) % NSTG;
             if (!(dbg & 2)) {
                 const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * WG_DYROW;
                 const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * XROW;
@@ -751,7 +820,7 @@ static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO, int CW) {
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
-    return (size_t)2 * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;
+    return (size_t)wg_stages(half == 2 ? 2 : 0) * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;
 }
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;

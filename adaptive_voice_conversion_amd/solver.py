@@ -71,15 +71,12 @@ class Solver(object):
             os.replace(tmp, path)
 
     def load_model(self):
-        """solver.py:50-54 loads the model and the optimizer state.  A missing ``.opt`` is tolerated (a bare
-        ``.ckpt`` such as the published vctk_model.ckpt) unless ``--load_opt`` asks for it explicitly."""
+        """solver.py:50-54 loads the model AND the optimizer state, unconditionally: a missing ``.opt`` raises, as it does there.
+        ``args.load_opt = False`` opts out (a bare ``.ckpt`` such as the published vctk_model.ckpt: fresh optimizer state)."""
         dev = self.model.flat_parameters().device
         self.model.load_state_dict(torch.load(f"{self.args.load_model_path}.ckpt", map_location=dev))
-        opt_path = f"{self.args.load_model_path}.opt"
-        if os.path.exists(opt_path):
-            self.opt.load_state_dict(torch.load(opt_path, map_location=dev))
-        elif getattr(self.args, "load_opt", False):
-            raise FileNotFoundError(f"--load_opt: {opt_path} does not exist")
+        if getattr(self.args, "load_opt", True):
+            self.opt.load_state_dict(torch.load(f"{self.args.load_model_path}.opt", map_location=dev))
 
     # ---- data (solver.py:57-68) ----------------------------------------------
     def get_data_loaders(self):

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--frames", type=int, default=128)
 ap.add_argument("--tune", action="append", default=[])
+ap.add_argument("--dtype", default="fp32", help="compute_dtype of the plan: fp32 | bf16s | bf16r | fp32x3")
 ap.add_argument("--presleep-ms", type=float, default=8.0, help="GPU-side sleep in front of the recorded step: the host is then a whole step ahead")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -28,6 +29,8 @@ lib.avc_prof_timeline.restype = ctypes.c_int
 lib.avc_prof_class_name.restype = ctypes.c_char_p
 tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
 cfg = default_config(80)
+if a.dtype != "fp32":
+    cfg["compute_dtype"] = a.dtype
 torch.manual_seed(0)
 solver = Solver(cfg, types.SimpleNamespace(store_model_path=None, load_model=False, data_dir=None, logdir="/tmp/avc_tl_log", tuning=tuning))
 x = torch.randn(a.batch, 80, a.frames, generator=torch.Generator().manual_seed(1)).to(dev)

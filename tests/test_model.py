@@ -120,6 +120,97 @@ def test_solver_step_and_checkpoint_roundtrip(kind, tmp_path):
     assert topt.param_groups[0]["lr"] == cfg["optimizer"]["lr"]
 
 
+def _torch_adam_steps(cfg, sd, x, eps, nsteps):
+    """`nsteps` steps of the reference's own optimizer stack on the oracle's gradients: real torch.optim.Adam built as at solver.py:75-77
+    and real clip_grad_norm_ (solver.py:91-92).  Returns (parameters, optimizer)."""
+    o = cfg["optimizer"]
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    opt = torch.optim.Adam(params, lr=o["lr"], betas=(o["beta1"], o["beta2"]), amsgrad=o["amsgrad"], weight_decay=o["weight_decay"])
+    for _ in range(nsteps):
+        cur = {k: p.detach().clone() for k, p in zip(sd, params)}
+        _, grads = O.loss_and_grads(x, eps, cur, cfg, 1.0)
+        for k, p in zip(sd, params):
+            p.grad = grads[k].clone()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=o["grad_norm"])
+        opt.step()
+    return params, opt
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 2, 32), pytest.param("gpu", "m80", 4, 128, marks=pytest.mark.gpu),
+                                              pytest.param("gpu", "m512", 2, 128, marks=pytest.mark.gpu)])
+def test_checkpoint_written_by_the_reference_optimizer_resumes_here(kind, cfgname, B, T, tmp_path):
+    """The REVERSE direction of the round trip above (reference solver.py:39-55): `<path>.ckpt` + `<path>.opt` as
+    torch.save'd by the reference's own `torch.optim.Adam` after two steps -> `Solver.load_model` -> step 3 here equals torch.optim.Adam's
+    step 3 on the oracle's gradients: parameters, `exp_avg`, `exp_avg_sq`, `max_exp_avg_sq`, step count.  Also at the stock 512-mel
+    width (the published vctk_model.ckpt's layout: 9,040,512 elements)."""
+    from tests.test_engine import get_cfg
+    lib, dev = backend(kind)
+    lib = lib if kind == "emu" else None
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 6)
+    x, eps = O.make_inputs(cfg, B, T, 6)
+    params, topt = _torch_adam_steps(cfg, sd, x, eps, 2)
+    base = str(tmp_path / "ref")
+    torch.save({k: p.detach().clone() for k, p in zip(sd, params)}, base + ".ckpt")   # solver.py:41
+    torch.save(topt.state_dict(), base + ".opt")                                       # solver.py:42
+    args = types.SimpleNamespace(store_model_path=None, load_model_path=base, load_model=True, data_dir=None, logdir=str(tmp_path / "log"))
+    s = Solver(cfg, args, lib=lib)
+    assert s.opt.step_count == 2
+    for (k, a), p in zip(s.model.state_dict().items(), params):
+        assert torch.equal(a.cpu(), p.detach()), k
+    meta = s.ae_step(x.to(dev), 1.0, eps=eps.to(dev))
+    # step 3 of the reference stack
+    cur = {k: p.detach().clone() for k, p in zip(sd, params)}
+    outs, grads = O.loss_and_grads(x, eps, cur, cfg, 1.0)
+    for k, p in zip(sd, params):
+        p.grad = grads[k].clone()
+    gn = torch.nn.utils.clip_grad_norm_(params, max_norm=cfg["optimizer"]["grad_norm"])
+    topt.step()
+    assert meta["loss_rec"] == pytest.approx(float(outs["loss_rec"]), rel=1e-5)
+    assert meta["grad_norm"] == pytest.approx(float(gn), rel=1e-4)
+    assert s.opt.step_count == 3
+    new = s.model.state_dict()
+    lr = cfg["optimizer"]["lr"]
+    bad = tot = 0
+    for k, p in zip(sd, params):
+        diff = (new[k].cpu() - p.detach()).abs()
+        bad += int((diff > 2e-6 + 1e-4 * p.detach().abs()).sum())
+        tot += diff.numel()
+        assert diff.max().item() <= 2.1 * lr, k
+    assert bad / tot < 5e-3, (bad, tot)   # (elements whose gradient is ~0 take sign-like steps: see test_solver_step_and_checkpoint_roundtrip)
+    mine = s.opt.state_dict()["state"]
+    ref = topt.state_dict()["state"]
+
+    from tests.test_engine import zero_grad_bias
+
+    def close(a, b, name, k):
+        d = b.norm().item()
+        if zero_grad_bias(k, cfg):   # analytically zero gradient (SURVEY 8c): the moments hold weight decay + fp32 noise of ~1e-6 per step
+            assert (a.cpu() - b).abs().max().item() <= (2e-7 if name == "exp_avg" else 1e-11), (name, k)
+            return
+        assert (a.cpu() - b).norm().item() <= 1e-4 * d + 1e-12, (name, k)
+    for i, k in enumerate(sd):
+        assert float(mine[i]["step"]) == float(ref[i]["step"]) == 3.0
+        close(mine[i]["exp_avg"], ref[i]["exp_avg"], "exp_avg", k)
+        close(mine[i]["exp_avg_sq"], ref[i]["exp_avg_sq"], "exp_avg_sq", k)
+        close(mine[i]["max_exp_avg_sq"], ref[i]["max_exp_avg_sq"], "max_exp_avg_sq", k)
+
+
+def test_load_model_without_opt_file_raises_like_the_reference(tmp_path):
+    """solver.py:50-54 loads BOTH files unconditionally: a missing `.opt` is an error there, and here -- unless the
+    caller opts out with `load_opt=False` (a bare published `.ckpt` used for inference / fine-tuning from fresh optimizer state)."""
+    lib, _ = backend("emu")
+    cfg = O.tiny_config()
+    base = str(tmp_path / "bare")
+    torch.save(O.make_state_dict(cfg, 2), base + ".ckpt")
+    args = types.SimpleNamespace(store_model_path=None, load_model_path=base, load_model=True, data_dir=None, logdir=str(tmp_path / "log"))
+    with pytest.raises(FileNotFoundError):
+        Solver(cfg, args, lib=lib)
+    args.load_opt = False
+    s = Solver(cfg, args, lib=lib)
+    assert s.opt.step_count == 0
+
+
 def test_default_init_equals_reference_init(golden_dir):
     """Same constructors in the same order => torch.manual_seed(s); AE(config) gives the
     reference's tensors (fixture from the real reference, oracle/make_golden.py)."""
