@@ -39,7 +39,7 @@ class Tuning(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("struct_size", "single_stream", "dec_split_min", "conv_x3", "wgrad_x3", "dgrad_par", "bank_switch",
                                             "conv_ck5", "wgrad_batch", "wgrad_batch_wgs", "wgrad_target_wgs", "conv_ablation", "wgrad_ablation",
                                             "op_compute_dtype", "side_prio", "tile12_wgs")] + \
-               [(n, ctypes.c_long) for n in ("wgrad_batch_units", "tile_thr11", "tile_thr21", "ck16_wgs", "ck32_wgs", "kg_wgs", "conv_min_lds", "in_pairs_nv", "bh_ck5", "wgrad_cw8", "dec_wgrad_flush", "dec_wgrad_wgs", "conv_walk", "conv_walk_min", "conv_in_fuse")]
+               [(n, ctypes.c_long) for n in ("wgrad_batch_units", "tile_thr11", "tile_thr21", "ck16_wgs", "ck32_wgs", "kg_wgs", "conv_min_lds", "in_pairs_nv", "bh_ck5", "wgrad_cw8", "dec_wgrad_flush", "dec_wgrad_wgs", "conv_walk", "conv_walk_min", "conv_in_fuse", "dbg_streams")]
 
 
 PLAN_X3 = 4

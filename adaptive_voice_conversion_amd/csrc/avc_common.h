@@ -342,6 +342,59 @@ static inline avc_s16x4 avc_pack_bf16x4(float a, float b, float c, float d) {
 static inline f32x16 avc_mfma_bf16(avc_s16x4 a, avc_s16x4 b, f32x16 c) { return emu::mfma_32x32x8_bf16(a, b, c); }
 #endif
 
+// ---- lane exchange v[lane ^ O] in the VALU: DPP inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.
+// __shfl_xor compiles to ds_bpermute_b32 -- an LDS-unit round trip per butterfly step, queued behind whatever the co-resident conv
+// workgroups do to the CU's LDS.  Bit-identical to the shuffle (v + partner in either order is the same sum); checked lane by lane on the
+// GPU by scripts/probe/xor_lane_test.hip.  (Built while hunting the run-to-run differences of round 6; those turned out to be the packed-fp32
+// VALU forms -- csrc/build.sh -- not the shuffles.)
+#ifndef AVC_EMU
+template <int CTRL, int BANKS>
+static __device__ __forceinline__ int avc_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, BANKS, false); }
+template <int O>
+static __device__ __forceinline__ float avc_xor_get(float v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "lane xor by a power of two below 64");
+    const int x = __builtin_bit_cast(int, v);
+    if constexpr (O == 1) return __builtin_bit_cast(float, avc_dpp_i<0xB1, 0xf>(x, x));          // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return __builtin_bit_cast(float, avc_dpp_i<0x4E, 0xf>(x, x));     // quad_perm [2,3,0,1]
+    else if constexpr (O == 4) {   // row_ror:4 (lane i <- lane i - 4 mod 16) for the lanes with bit 2 set, row_ror:12 (lane i <- lane i + 4 mod 16) for the others
+        const int t = avc_dpp_i<0x124, 0xA>(x, x);
+        return __builtin_bit_cast(float, avc_dpp_i<0x12C, 0x5>(t, x));
+    } else if constexpr (O == 8) return __builtin_bit_cast(float, avc_dpp_i<0x128, 0xf>(x, x));  // row_ror:8
+    else if constexpr (O == 16) {  // swaps the odd rows of the first operand with the even rows of the second: r[0] = (row0, row0, row2, row2), r[1] = (row1, row1, row3, row3)
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return __builtin_bit_cast(float, (__lane_id() & 16) ? r[0] : r[1]);
+    } else {                       // swaps the upper 32 lanes of the first operand with the lower 32 of the second
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        return __builtin_bit_cast(float, (__lane_id() & 32) ? r[0] : r[1]);
+    }
+}
+#else
+template <int O>
+static inline float avc_xor_get(float v) { return __shfl_xor(v, O); }
+#endif
+// run-time offset (wave-uniform): the offsets the kernels use
+static __device__ __forceinline__ float avc_xor_get_rt(float v, int o) {
+    switch (o) {
+        case 1: return avc_xor_get<1>(v);
+        case 2: return avc_xor_get<2>(v);
+        case 4: return avc_xor_get<4>(v);
+        case 8: return avc_xor_get<8>(v);
+        case 16: return avc_xor_get<16>(v);
+        default: return avc_xor_get<32>(v);
+    }
+}
+// butterfly sum over groups of LPR lanes (LPR a power of two <= 64), largest offset first -- the order the row kernels always used
+template <int LPR>
+static __device__ __forceinline__ float avc_group_sum(float v) {
+    if constexpr (LPR >= 64) v += avc_xor_get<32>(v);
+    if constexpr (LPR >= 32) v += avc_xor_get<16>(v);
+    if constexpr (LPR >= 16) v += avc_xor_get<8>(v);
+    if constexpr (LPR >= 8) v += avc_xor_get<4>(v);
+    if constexpr (LPR >= 4) v += avc_xor_get<2>(v);
+    if constexpr (LPR >= 2) v += avc_xor_get<1>(v);
+    return v;
+}
+
 // f / d for 0 <= f < 2^22 with a precomputed float reciprocal (one fix-up step; integer division
 // by a run-time divisor costs ~25 instructions on gfx950, this costs ~6)
 static __device__ __forceinline__ int avc_fastdiv(int f, int d, float inv_d) {

@@ -581,6 +581,9 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->dyarena_floats = need[1];
         p->ws_top += (need[1] + 63) / 64 * 64;
         p->nev_need = (int)need[2];
+        p->named["wgrad_slab"] = p->slab;      // (diagnostic views: scripts/bf16_repro_probe3.py)
+        p->named["dy_arena"] = p->dyarena;
+        p->named["g_tmp"] = p->gA;
     }
     // helper streams / events belong to the plan from here on (created on the device that is current NOW;
     // a process without a GPU -- host-only plan queries -- simply gets a single-stream plan)
@@ -1379,7 +1382,8 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
     c.p = p; c.params = params; c.grads = grads; c.ws = ws; c.s = s; c.dry = dry; c.slab_used = 0;
     if (!dry) avc_prof_mark(0, s);
     c.nev = 0; c.dy_used = 0; c.pend_units = 0;
-    const bool overlap = !dry && side_ready(p);
+    const bool overlap = !dry && side_ready(p) && !(p->tun.dbg_streams & 1);
+    const bool use_side = !dry && !(p->tun.dbg_streams & 2);
     c.wstream = overlap ? p->wstream[0] : s;
     const int B = p->B;
     const bool bh = p->bh;
@@ -1514,7 +1518,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         {
             const int nph = 2 * d.n + 2;
             ChainSt st0 = {ws + p->gA, ws + p->gB, ws + p->gC, false}, st1 = st0;
-            const bool split = !dry && B >= p->tun.dec_split_min && side_ready(p);
+            const bool split = use_side && B >= p->tun.dec_split_min && side_ready(p);
             const int Bh = B / 2;
             const hipStream_t s2 = split ? fork_side(p, s) : s;
             for (int ph = 0; ph < nph; ++ph) {   // the two half-batch chains are issued in turn (see the forward pass)
@@ -1637,7 +1641,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
 
     // ---------------- speaker encoder (side stream, own temporaries: concurrent with the content encoder)
     const hipStream_t mainS = s;
-    const hipStream_t sideS = dry ? mainS : fork_side(p, mainS);
+    const hipStream_t sideS = use_side ? fork_side(p, mainS) : mainS;
     {
         const hipStream_t s = sideS;
         c.s = sideS;
@@ -1715,7 +1719,15 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         RUN(flush_wgrads(c));
         c.s = mainS;
         c.wstream = overlap ? p->wstream[0] : mainS;
+        if (!dry && (p->tun.dbg_streams & 8) && sideS != mainS) {   // (diagnostic: the content chain starts behind the dense-stack kernel and the speaker's dense weight gradients)
+            hipEventRecord(p->ev_dense, sideS);
+            hipStreamWaitEvent(mainS, p->ev_dense, 0);
+        }
         RUN(content_branch());
+        if (!dry && (p->tun.dbg_streams & 4) && sideS != mainS) {   // (diagnostic: the speaker's conv chain starts behind the content chain)
+            hipEventRecord(p->ev_join, mainS);
+            hipStreamWaitEvent(sideS, p->ev_join, 0);
+        }
         c.s = sideS;
         c.wstream = (overlap && sideS != mainS) ? p->wstream[1] : sideS;
         // pooled -> [B,C,Tn] ; dy2 of the last block masked by its ReLU output

@@ -65,7 +65,7 @@ int avc_set_tuning(const char* name, int value) {
     AVC_TUNE_FIELD(bank_switch) AVC_TUNE_FIELD(conv_ck5) AVC_TUNE_FIELD(wgrad_batch) AVC_TUNE_FIELD(wgrad_batch_wgs) AVC_TUNE_FIELD(wgrad_target_wgs)
     AVC_TUNE_FIELD(conv_ablation) AVC_TUNE_FIELD(wgrad_ablation) AVC_TUNE_FIELD(op_compute_dtype) AVC_TUNE_FIELD(tile12_wgs) AVC_TUNE_FIELD(side_prio) AVC_TUNE_FIELD(wgrad_batch_units)
     AVC_TUNE_FIELD(tile_thr11) AVC_TUNE_FIELD(tile_thr21) AVC_TUNE_FIELD(ck16_wgs) AVC_TUNE_FIELD(ck32_wgs) AVC_TUNE_FIELD(kg_wgs) AVC_TUNE_FIELD(bh_ck5) AVC_TUNE_FIELD(in_pairs_nv) AVC_TUNE_FIELD(conv_min_lds) AVC_TUNE_FIELD(wgrad_cw8) AVC_TUNE_FIELD(dec_wgrad_flush) AVC_TUNE_FIELD(dec_wgrad_wgs)
-    AVC_TUNE_FIELD(conv_walk) AVC_TUNE_FIELD(conv_walk_min) AVC_TUNE_FIELD(conv_in_fuse)
+    AVC_TUNE_FIELD(conv_walk) AVC_TUNE_FIELD(conv_walk_min) AVC_TUNE_FIELD(conv_in_fuse) AVC_TUNE_FIELD(dbg_streams)
 #undef AVC_TUNE_FIELD
     if (!strcmp(name, "compute")) { t.op_compute_dtype = (value == AVC_COMPUTE_BF16) ? AVC_COMPUTE_BF16 : AVC_COMPUTE_F32; return 0; }
     return -1;

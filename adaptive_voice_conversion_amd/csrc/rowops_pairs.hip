@@ -21,11 +21,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int LPR>
-static __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+static __device__ __forceinline__ float group_sum(float v) { return avc_group_sum<LPR>(v); }   // (avc_common.h: no ds_bpermute)
 
 // frames 4 i4 .. 4 i4 + 3 of the dword row (b, p): lo[k] / hi[k] = channel 2p / 2p + 1 at frame 4 i4 + k
 static __device__ __forceinline__ void ld_pairs4(const unsigned* rows, long row, int T, int i4, float (&lo)[4], float (&hi)[4]) {

@@ -38,7 +38,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 # algorithmic GFLOP of one train step per segment (fwd + dgrad + wgrad minus the bank-conv input gradient)
-TRAIN_GFLOP_PER_SEG = {(80, 128): 1.767}
+TRAIN_GFLOP_PER_SEG = {(80, 128): 1.767, (80, 1024): 14.108}   # 3 x forward minus the bank's input gradient (2 x bank forward); T = 1024: 3 x 5.206 - 2 x 0.755
+FWD_GFLOP_PER_SEG = {(80, 128): 0.6519, (80, 1024): 5.206}      # SURVEY 8d (one speaker encoder + one content encoder + decoder = AE.forward = AE.inference)
 
 
 def stock_config(n_mels):
@@ -727,6 +728,32 @@ def config2_in_child(a):
     return rec
 
 
+def extra_config_in_child(a, name):
+    """Driver-visible numbers for the other single-GPU BASELINE configs: bench.py ITSELF in a fresh process with that
+    config's arguments (same harness: `warmup` untimed passes, `steps` timed ones between synchronisations), compacted into a sub-record.
+    config3_infer_b1024 = BASELINE configs[3] (inference B = 1024); config4_t1024_b64 = configs[4] (T = 1024, B = 64 train step: the
+    "HBM-bound InstanceNorm regime" of BASELINE.json -- its roofline_instnorm is taken at [64, 128, 1024])."""
+    import subprocess
+    argv = {"config3_infer_b1024": ["--mode", "infer", "--batch", "1024", "--frames", "128"],
+            "config4_t1024_b64": ["--batch", "64", "--frames", "1024"]}[name]
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--mels", str(a.mels),
+           "--no-cpu-baseline", "--no-config2"] + argv + (["--no-profile"] if a.no_profile else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"{name} worker rc={r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    d = json.loads(lines[-1])
+    rec = {"workload": d["config"]["workload"], "baseline_config_index": d["config"].get("baseline_config_index"), "dtype": d["dtype"],
+           "n_gpus": 1, "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+           "process": "child process of this run (its own HIP context): python bench.py " + " ".join(argv)}
+    for k in ("roofline", "roofline_instnorm", "kernel_classes"):
+        if k in d:
+            rec[k] = d[k]
+    if "final_losses" in d["config"]:
+        rec["final_losses"] = d["config"]["final_losses"]
+    return rec
+
+
 def workload_label(a, world):
     """Which BASELINE.json config (if any) the arguments correspond to, and a metric string that names the real shape."""
     prec = {"f32": "fp32", "bf16r": "bf16 matrix products on fp32 storage: operands rounded as they enter the matrix core (fp32 accumulate, fp32 master "
@@ -787,7 +814,7 @@ def main():
                          "fp32 master weights / optimizer state) -- a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-config2", action="store_true", help="skip the config2_bf16 sub-record of the default (configs[1]) line")
+    ap.add_argument("--no-config2", action="store_true", help="skip the config2_bf16 / config3_infer_b1024 / config4_t1024_b64 sub-records of the default (configs[1]) line")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every kernel on the caller's stream")
     ap.add_argument("--feed", action="store_true", help="draw every batch from an HBM-resident synthetic corpus through the "
                                                         "device-side gather kernel (DeviceSegmentFeed) inside the timed loop")
@@ -903,13 +930,28 @@ def main():
         barrier()
         el, per_rank = rank_times(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"metric": metric, "value": world * B * a.steps / el,
-                              "unit": "utterances/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                              "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": dtype_label, "data": "synthetic",
-                              "config": {"workload": workload, "baseline_config_index": cfg_idx, "world_size": world,
-                                         "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank]}}),
-                  flush=True)
+            rec = {"metric": metric, "value": world * B * a.steps / el,
+                   "unit": "utterances/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": dtype_label, "data": "synthetic",
+                   "config": {"workload": workload, "baseline_config_index": cfg_idx, "world_size": world,
+                              "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank]}}
+            if (a.mels, T) in FWD_GFLOP_PER_SEG and world == 1:
+                peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16r": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[a.dtype]
+                tf = FWD_GFLOP_PER_SEG[(a.mels, T)] * B / 1e3 / (el / a.steps)
+                rec["roofline"] = {"kernel": "whole forward pass (conv_gemm launches: every Conv1d / Linear of AE.inference)", "bound": "mfma", "achieved": tf,
+                                   "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                                   "algorithmic_gflop_per_pass": FWD_GFLOP_PER_SEG[(a.mels, T)] * B}
+                if not a.no_profile:
+                    try:   # the InstanceNorm / AdaIN rows of a forward pass that still run as row kernels, at this batch's dominant shape (forward only)
+                        dom_s = instnorm_dominant_shape(B, cfg["ContentEncoder"]["c_h"], T, pairs=False)
+                        f_ = dom_s["fwd"]
+                        rec["roofline_instnorm"] = {"kernel": f"instnorm_fwd (IN/AdaIN/ReLU) at [{B},{cfg['ContentEncoder']['c_h']},{T}]", "bound": "hbm",
+                                                    "achieved": f_["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_["gbs"] / PEAK_HBM_GBS,
+                                                    "algorithmic_bytes": f_["bytes_per_launch"], "fwd": f_}
+                    except Exception as e:
+                        rec["roofline_instnorm"] = {"error": repr(e)[:200]}
+            print(json.dumps(rec), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1036,6 +1078,11 @@ def main():
                 out["config2_bf16"] = config2_in_child(a)
             except Exception as e:   # never lose the headline line to the sub-record
                 out["config2_bf16"] = {"error": repr(e)[:300]}
+            for name in ("config3_infer_b1024", "config4_t1024_b64"):   # the other single-GPU BASELINE configs, driver-timed (~10 s each)
+                try:
+                    out[name] = extra_config_in_child(a, name)
+                except Exception as e:
+                    out[name] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.mels, T)

@@ -458,6 +458,41 @@ def test_storage_engine_forward_inference_and_determinism(kind, act):
     assert torch.isfinite(g1).all() and torch.equal(g1, g2), "the pair-storage backward is not deterministic"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,compute", [(64, "bf16s"), (256, "bf16s"), (256, "fp32")])
+def test_backward_is_bit_reproducible_in_multi_stream_mode_at_bench_sizes(B, compute):
+    """Round 6 regression.  The determinism check above runs a 3-sample tiny net -- one launch per stream at a time.  At the benchmarked sizes
+    the backward pass runs the two encoder branches (and, from B = 128, the decoder's two half-batch chains) on two streams beside the
+    weight-gradient streams, and the bf16 storage engine's gradients came out different from run to run (7 of 7 consecutive runs; 24 - 160 of
+    the 166 tensors; forward outputs identical; the single-stream schedule reproducible): row kernels whose reductions the compiler had
+    packed into v_pk_*_f32 instructions returned different sums beside the bf16 conv kernels of the other stream (scripts/pairs_race_probe.py,
+    profiles/r06_pairs_race_*.txt).  The library is built without the packed-fp32 VALU forms since (csrc/build.sh); every run must now give
+    the same bits -- on one workspace, and on a second one at another address."""
+    from adaptive_voice_conversion_amd.engine import Plan
+    lib, dev = backend("gpu")
+    cfg = O.stock_config(80)
+    sd = O.make_state_dict(cfg, 0)
+    x, eps = O.make_inputs(cfg, B, 128, 0)
+    plan = Plan(cfg, B, 128, lib=lib, compute_dtype=compute)
+    params = _flat_params(plan, sd, dev)
+    xd, ed = x.to(dev), eps.to(dev)
+
+    def run(ws):
+        plan.forward(params, xd, None, ed, ws)
+        plan.loss(xd, 10.0, ws)
+        g = torch.full((plan.param_floats,), float("nan"), device=dev)
+        plan.backward(params, xd, None, ed, g, ws, lambda_kl=1.0)
+        torch.cuda.synchronize()
+        return g
+    ws = torch.zeros(plan.workspace_floats, device=dev)
+    ref = run(ws)
+    assert torch.isfinite(ref).all()
+    for i in range(6):
+        assert torch.equal(run(ws), ref), f"run {i + 2} differs from run 1"
+    ws2 = torch.full((plan.workspace_floats,), float("nan"), device=dev)
+    assert torch.equal(run(ws2), ref), "a second workspace gives other bits"
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_storage_engine_transposed_input_and_half_batch_chains(kind):
     """The [B, T, M] -> [B, M, T] view of data_utils.py:14-16 enters through the fp32 -> pair seam kernel (explicit strides), and the two
