@@ -43,6 +43,9 @@ static constexpr __host__ __device__ int wg_threads(int CW) { return (CW + 4) * 
 #define AVC_WGRAD_STAGES_BH 4
 #endif
 static constexpr __host__ __device__ int wg_stages(int BF) { return BF == 2 ? AVC_WGRAD_STAGES_BH : 2; }
+#ifndef AVC_WGRAD_BHX_WAVES
+#define AVC_WGRAD_BHX_WAVES 3   // minimum waves per SIMD of the bf16 k = 5 whole-chunk instance: 3 = 168 registers (it takes 137)
+#endif
 
 // s_waitcnt vmcnt(n), n = 0..63 (gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0]; expcnt / lgkmcnt untouched).  A larger request waits
 // for 63 -- stricter than asked, still correct.
@@ -169,7 +172,28 @@ struct WgCfg {
     static constexpr int CPT = 32 / TPR;
     static constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
     static constexpr int NSTG = wg_stages(BF);   // LDS stages per operand (wg_stages)
+    // ---- 16-BYTE staging of the bf16 whole-chunk instances (round 6; `wide` layers, wg_wide16 below).  The dword LDS-DMA that builds the
+    // padded rows above costs one instruction per 256 bytes: 36 instructions per 9-KB chunk, and their issue / landing cadence -- not
+    // latency, not HBM -- was the bf16 weight gradient's bound (0.83 us per chunk with the products ablated, 2.7 TB/s chip-wide:
+    // profiles/r06_wgrad_steady_*.txt).  A dword row of a pair tensor is 16-byte aligned in HBM, so both operand tiles are staged as
+    // rows of TEN 16-byte pieces = frames t0 - 4 .. t0 + 35 of the chunk (dy: t0 .. t0 + 31 and two pieces nobody reads): 1 KiB per
+    // instruction, 10 per chunk.  40-dword rows: the 8 distinct rows a ds_read_b128 service group touches (lanes 2p, 2p + 1 share a pair
+    // row) start 8 banks apart.  No reflection in the loader: the row's first / last piece of a sample's first / last chunk would lie
+    // outside the row -- those lanes fetch the neighbouring piece instead (valid memory, never used) and the CONSUMER takes the mirrored
+    // frames from registers it holds anyway (frame -i is frame i of the same fragment).
+    static constexpr bool BHX = BH && LIN && !RT;   // (the run-time-taps instance of the bank was tried on these rows too -- fragments read at the dword-aligned LDS
+                                                    // address c0 + 4 - padL, mirrored frames by a switch on the tap count: parity-green and SLOWER, wgrad class 1.06 vs
+                                                    // 0.96 ms, step 2.52 vs 2.50 ms, gpurun_out r6n -- and taken out again)
+    static constexpr int ROW16 = 40;
+    static constexpr int ND16 = (RCO * 10 + 63) / 64, NX16 = (RCI * 10 + 63) / 64;   // DMA instructions per operand tile
+    static constexpr int NPD16 = (ND16 + 3) / 4, NPX16 = (NX16 + 3) / 4;               // ... per producer wave
 };
+// may this layer's tiles be staged by 16-byte pieces?  Whole 32-frame chunks of a stride-1 layer (LIN instances) whose rows are 16-byte
+// aligned dword rows.  Both roles of a workgroup evaluate it per segment.
+static __device__ __forceinline__ bool wg_wide16(const WgradArgs& a) {
+    return (a.Tout & 31) == 0 && a.Tin == a.Tout && a.spc == 1 && a.x.st == 1 && a.dy.st == 1 && a.x.ps == 1 && a.dy.ps == 1 &&
+           ((a.x.sc | a.x.sb | a.dy.sc | a.dy.sb) & 3) == 0 && ((((unsigned long)a.x.ptr) | ((unsigned long)a.dy.ptr)) & 15) == 0;
+}
 
 // ---------------- producers: waves 4-7.  Both operand tiles go global -> LDS by dword DMA (each lane its own source address, so the
 // reflect padding and the padded LDS rows cost no staging registers).  Two stages: chunk c+1 lands while chunk c multiplies.
@@ -196,8 +220,10 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
         const int lgTc = 31 - __builtin_clz(Tc);
         const int XSEG = (Tc - 1) * a.stride + KSr;
         const int XROW = LIN ? wg_xrow_lin(KSr) : ((spc * XSEG) | 1);
-        const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
-        const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;  // stage strides: whole 64-float DMA pieces
+        const bool wide = C::BHX && wg_wide16(a);   // 16-byte staging (WgCfg)
+        const int DYROWW = wide ? C::ROW16 : WG_DYROW;
+        const int DYS = wide ? RCO * C::ROW16 : RCO * WG_DYROW, XS = wide ? RCI * C::ROW16 : RCI * XROW;
+        const int DYSP = wide ? (DYS + 255) & ~255 : (DYS + 63) & ~63, XSP = wide ? (XS + 255) & ~255 : (XS + 63) & ~63;  // stage strides: whole DMA pieces
         float* dyT = smem;                // [NSTG][RCO][WG_DYROW]
         float* xT = smem + NSTG * DYSP;   // [NSTG][RCI][XROW]
         const float inv_xrow = 1.0f / (float)XROW;
@@ -212,8 +238,58 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
         // origin is a scalar base: one SADDR-form DMA instruction per piece, ~no address VALU.
         // ... and the same for chunks that hold spc whole short samples (T_l = 16, 8, ...): there even the reflection is chunk-invariant,
         // so the x offsets are complete and only the base moves.
-        const bool fastm = (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
-        const bool fastp = fastm || ((spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256));
+        const bool fastm = !wide && (spc > 1) && (a.Tout == Tc) && (a.B % spc == 0) && (XSP <= NPX * 256);
+        const bool fastp = wide || fastm || ((spc == 1) && (a.Tout % 32 == 0) && (XSP <= NPX * 256));
+        // 16-byte staging: chunk-invariant byte offsets of this wave's pieces; xedge = +1 / -1 for the first / last piece of an x row
+        unsigned dyo16[C::BHX ? C::NPD16 : 1], xo16[C::BHX ? C::NPX16 : 1];
+        int xedge[C::BHX ? C::NPX16 : 1];
+        if constexpr (C::BHX) {
+            if (wide) {
+#pragma unroll
+                for (int i = 0; i < C::NPD16; ++i) {
+                    const int f = (wave + 4 * i) * 64 + lane;
+                    int row = f / 10;
+                    const int pc = f - row * 10;
+                    row = row < RCO ? row : RCO - 1;
+                    int co = co0r + row;
+                    co = co < CoutR ? co : CoutR - 1;
+                    dyo16[i] = 4u * (unsigned)((long)co * a.dy.sc + 4 * (pc < 8 ? pc : 0));   // (pieces 8, 9 of a dy row hold nothing: they re-fetch piece 0)
+                }
+#pragma unroll
+                for (int i = 0; i < C::NPX16; ++i) {
+                    const int f = (wave + 4 * i) * 64 + lane;
+                    int row = f / 10;
+                    const int pc = f - row * 10;
+                    row = row < RCI ? row : RCI - 1;
+                    int ci = ci0r + row;
+                    ci = ci < CinR ? ci : CinR - 1;
+                    xo16[i] = 4u * (unsigned)((long)ci * a.x.sc + 4 * pc);
+                    xedge[i] = pc == 0 ? 1 : (pc == 9 ? -1 : 0);
+                }
+            }
+        }
+        auto issue16 = [&](int chunk, int buf) {
+            if constexpr (C::BHX) {
+                const int cb = chunk / a.chunks_per_sample;
+                const int t0 = (chunk - cb * a.chunks_per_sample) * 32;
+                const float* dyb = dyptr + ((long)cb * a.dy.sb + t0);
+                const float* xb = xptr + ((long)cb * a.x.sb + t0) - 4;   // frame t0 - 4: in front of the row when t0 == 0 -- the lanes of that piece fetch the next one
+                const bool first = t0 == 0, last = t0 + 32 == a.Tout;
+                float* dd = dyT + buf * DYSP;
+                float* xd = xT + buf * XSP;
+#pragma unroll
+                for (int i = 0; i < C::NPD16; ++i)
+                    if (wave + 4 * i < C::ND16) avc_glds16_s(dyb, dyo16[i], dd + (wave + 4 * i) * 256);
+#pragma unroll
+                for (int i = 0; i < C::NPX16; ++i)
+                    if (wave + 4 * i < C::NX16) {
+                        unsigned v = xo16[i];
+                        if (first && xedge[i] > 0) v += 16u;
+                        if (last && xedge[i] < 0) v -= 16u;
+                        avc_glds16_s(xb, v, xd + (wave + 4 * i) * 256);
+                    }
+            }
+        };
         if (fastm) {
 #pragma unroll
             for (int i = 0; i < NPD; ++i) {
@@ -240,7 +316,7 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
                 xo[i] = 4u * (unsigned)((long)sl * a.x.sb + src_chan_off(a.x, ci) + (long)r * a.x.st);
                 xq[i] = 0;
             }
-        } else if (fastp) {
+        } else if (fastp && !wide) {
 #pragma unroll
             for (int i = 0; i < NPD; ++i) {
                 const int f = (wave + 4 * i) * 64 + lane;
@@ -264,6 +340,10 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
             }
         }
         auto issue_fast = [&](int chunk, int buf) {
+            if (wide) {
+                issue16(chunk, buf);
+                return;
+            }
             float* dd = dyT + buf * DYSP;
             float* xd = xT + buf * XSP;
             if (fastm) {
@@ -347,10 +427,17 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
         // number of DMA instructions): partial vmcnt waits + bare barriers; everything else keeps the draining barrier
         const bool deep = NSTG > 2 && fastp && !(dbg & 5);   // (ablation bits 1 "no DMA" and 4 "no barrier" change the producer's flow: shallow path)
         int ndma = 0;   // this wave's DMA instructions per chunk (issue_fast)
+        if (wide) {
 #pragma unroll
-        for (int i = 0; i < NPD; ++i) ndma += ((wave + 4 * i) * 64 < DYSP) ? 1 : 0;
+            for (int i = 0; i < C::NPD16; ++i) ndma += (wave + 4 * i < C::ND16) ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NPX; ++i) ndma += ((wave + 4 * i) * 64 < XSP) ? 1 : 0;
+            for (int i = 0; i < C::NPX16; ++i) ndma += (wave + 4 * i < C::NX16) ? 1 : 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPD; ++i) ndma += ((wave + 4 * i) * 64 < DYSP) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) ndma += ((wave + 4 * i) * 64 < XSP) ? 1 : 0;
+        }
         const int nck = c_end - c_begin;
         __syncthreads();  // the zero fill / the previous segment's last reads are complete before the first DMA of this one lands
         if (deep) {
@@ -372,7 +459,7 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
                 if (more) issue(chunk + 1, NSTG == 2 ? (buf ^ 1) : (rel + 1) % NSTG);
             }
             if (do_db) {   // bias gradient = row sums of the dy tile that is in LDS anyway
-                const float* dr = dyT + buf * DYSP + (ptid / TPR) * WG_DYROW + (ptid % TPR) * CPT;
+                const float* dr = dyT + buf * DYSP + (ptid / TPR) * DYROWW + (ptid % TPR) * CPT;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     if constexpr (BH) {
@@ -451,10 +538,12 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
         const int lgTc = 31 - __builtin_clz(Tc);
         const int XSEG = (Tc - 1) * a.stride + KSr;
         const int XROW = LIN ? wg_xrow_lin(KSr) : ((spc * XSEG) | 1);
-        const int DYS = RCO * WG_DYROW, XS = RCI * XROW;
-        const int DYSP = (DYS + 63) & ~63, XSP = (XS + 63) & ~63;
+        const bool wide = C::BHX && wg_wide16(a);   // 16-byte staging: 40-dword rows, frame t0 - 4 + d at dword d (WgCfg)
+        const int DYS = wide ? RCO * C::ROW16 : RCO * WG_DYROW, XS = wide ? RCI * C::ROW16 : RCI * XROW;
+        const int DYSP = wide ? (DYS + 255) & ~255 : (DYS + 63) & ~63, XSP = wide ? (XS + 255) & ~255 : (XS + 63) & ~63;
         const float* dyT = smem;
         const float* xT = smem + NSTG * DYSP;
+        int tcs = wide ? sg.c_begin % a.chunks_per_sample : 0;   // position of the chunk inside its sample (wide: first / last chunk reflect)
         const long tile_floats = (long)CW * KSr * NB * 1024;   // consumer waves x (taps x blocks) accumulators x 16 registers x 64 lanes
         const int tile = sg.tile, c_begin = sg.c_begin, c_end = sg.c_end;
         const int co0 = (tile / ci_tiles) * TCO, ci0 = (tile % ci_tiles) * TCI;
@@ -464,11 +553,18 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         __syncthreads();
         __syncthreads();   // the first chunk has landed
+        // The chunk loop exists ONCE PER STAGING LAYOUT (compile-time WIDE): with the layout as a run-time branch inside one loop body the two
+        // bodies' accumulator chains met in phi nodes and the compiler copied all 80 accumulator registers around every MFMA
+        // (v_mfma ... v[98:113], ..., v[66:81]: round 6, the consumers alone 764 instead of 418 ns per chunk).
+        auto chunk_loop = [&](auto wtag) {
+        constexpr bool WIDE = decltype(wtag)::value;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const int buf = NSTG == 2 ? ((chunk - c_begin) & 1) : (chunk - c_begin) % NSTG;
+            const bool first_c = tcs == 0, last_c = tcs == a.chunks_per_sample - 1;
+            if (WIDE && ++tcs == a.chunks_per_sample) tcs = 0;
             if (!(dbg & 2)) {
-                const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * WG_DYROW;
-                const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * XROW;
+                const float* arow = dyT + buf * DYSP + (BH ? (wave_m * 32 + li) >> 1 : wave_m * 32 + li) * (WIDE ? C::ROW16 : WG_DYROW);
+                const float* brow = xT + buf * XSP + (BH ? (wave_n * NB * 32 + li) >> 1 : wave_n * NB * 32 + li) * (WIDE ? C::ROW16 : XROW);
                 // one straight-line chunk body.  RT: it is compiled for K = 8 taps and every tap's loads / MFMAs sit behind a WAVE-UNIFORM
                 // test of the layer's own tap count (a scalar branch per MFMA group: nothing beside a 64-cycle MFMA).  (A switch over eight
                 // per-tap-count bodies made the register allocator keep two copies of accumulators at the merge: spills in the loop.)
@@ -499,6 +595,65 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
                     if constexpr (BH) {
                         // two blocks of 16 columns per chunk; lane-half h owns columns 16 kb + 8 h .. + 7 in BOTH operands
                         const unsigned sel = (li & 1) ? 0x07060302u : 0x05040100u;   // this lane's channel = low / high half of its pair row
+                        if constexpr (WIDE) {
+                            {
+                                // 16-byte staged rows: dword d of a row = frame t0 - 4 + d.  The fragment of columns c0 = 16 kb + 8 h .. + 7 is dwords
+                                // c0 .. c0 + 15 (frames c0 - 4 .. c0 + 11); tap j of column c0 + i reads frame c0 + i + j - PADL = fragment dword
+                                // i + j + 4 - PADL.  At a sample's edges the mirrored frames are other dwords of the SAME fragment.
+                                constexpr int PADL = K / 2, PADR = (K & 1) ? K / 2 : K / 2 - 1;
+                                constexpr int P0 = (4 - PADL) / 4, P1 = (11 + PADR) / 4;   // 16-byte pieces of the fragment that are read
+                                auto fetchw = [&](int kb, unsigned (&ad)[8], unsigned (&xr)[NB][16]) {
+                                    const float* ap = arow + 16 * kb + 8 * h;
+                                    const float* bp = brow + 16 * kb + 8 * h;
+#pragma unroll
+                                    for (int i4 = 0; i4 < 2; ++i4) {
+                                        const f32x4 v = *(const f32x4*)(ap + 4 * i4);
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) ad[4 * i4 + i] = bh_as_u32(v[i]);
+                                    }
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                        for (int i4 = P0; i4 <= P1; ++i4) {
+                                            const f32x4 v = *(const f32x4*)(bp + nb * NBROW * C::ROW16 + 4 * i4);
+#pragma unroll
+                                            for (int i = 0; i < 4; ++i) xr[nb][4 * i4 + i] = bh_as_u32(v[i]);
+                                        }
+                                };
+                                auto blockw = [&](int kb, const unsigned (&ad)[8], unsigned (&xr)[NB][16]) {
+                                    if (PADL > 0 && first_c && kb == 0) {   // frames -i of the sample: frame i (reflect padding, model.py:28-30)
+#pragma unroll
+                                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                            for (int i = 1; i <= PADL; ++i) xr[nb][4 - i] = h == 0 ? xr[nb][4 + i] : xr[nb][4 - i];
+                                    }
+                                    if (PADR > 0 && last_c && kb == 1) {    // frames T - 1 + i: frame T - 1 - i
+#pragma unroll
+                                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                            for (int i = 1; i <= PADR; ++i) xr[nb][11 + i] = h == 1 ? xr[nb][11 - i] : xr[nb][11 + i];
+                                    }
+                                    avc_u32x4 at;
+#pragma unroll
+                                    for (int q4 = 0; q4 < 4; ++q4) at[q4] = bh_sel(ad[2 * q4], ad[2 * q4 + 1], sel);
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                        for (int j = 0; j < K; ++j) {
+                                            avc_u32x4 bq;
+#pragma unroll
+                                            for (int q4 = 0; q4 < 4; ++q4) bq[q4] = bh_sel(xr[nb][j + 4 - PADL + 2 * q4], xr[nb][j + 4 - PADL + 2 * q4 + 1], sel);
+                                            acc[nb * KS + j] = avc_mfma_bf16x8(at, bq, acc[nb * KS + j]);
+                                        }
+                                };
+                                unsigned a0[8], a1[8], x0[NB][16], x1[NB][16];
+                                fetchw(0, a0, x0);
+                                fetchw(1, a1, x1);   // (requested before the first block's MFMAs are issued)
+                                blockw(0, a0, x0);
+                                blockw(1, a1, x1);
+                                return;
+                            }
+                        }
                         constexpr int NX = 8 + K - 1;
                         auto fetch = [&](int kb, unsigned (&ad)[8], unsigned (&xd)[NB][LIN ? NX : 8 * K]) {
                             if constexpr (LIN) {   // 16-byte aligned rows: ds_read_b128
@@ -712,6 +867,13 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
             }
             if (!(dbg & 4)) __syncthreads();
         }
+        };
+        if constexpr (C::BHX) {
+            if (wide) chunk_loop(std::true_type{});
+            else chunk_loop(std::false_type{});
+        } else {
+            chunk_loop(std::false_type{});
+        }
 
         // ---------------- segment end
         // thread (wave, lane) owns, per ci block nb and tap j, the 16 accumulator registers of output rows
@@ -769,6 +931,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
 template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, bool X3, int CW>
 struct WgWaves {
     static constexpr int value = CW == 8 ? 3   // 12 waves = 3 per SIMD: 168 registers (at 128: class 2.31 vs 2.21 ms, spills only in the cold store path)
+                                 : (BF == 2 && LIN && !RT && KS == 5) ? AVC_WGRAD_BHX_WAVES   // (137 registers with the chunk loop instantiated per staging layout)
                                  : (KS == 5 && !RT && LIN && !X3 && BF != 2) ? 4
                                  : (((KS == 5 && (LIN || BF == 0)) || (KS == 1 && NB == 1)) ? 3 : 2);   // (run-time-taps bank instance: 256 registers -- at 168 it
                                                                                              // spills in the loop; class and step equal within noise)
@@ -820,7 +983,12 @@ static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO, int CW) {
     const int XSEG = (a.Tc - 1) * a.stride + a.KS;
     const bool lin = a.Tc == 32 && a.stride == 1;   // (the LIN kernel instances, wgrad_key)
     const int XROW = lin ? wg_xrow_lin(a.KS) : ((a.spc * XSEG) | 1), WG_DYROW = wg_dyrow(lin);
-    return (size_t)wg_stages(half == 2 ? 2 : 0) * (((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63)) * 4 + 64;
+    size_t stage = (size_t)((TCO * WG_DYROW + 63) & ~63) + ((TCI * XROW + 63) & ~63);
+    if (half == 2 && lin) {   // the 16-byte staging of the bf16 whole-chunk instances: 40-dword rows, whole 1-KiB pieces per operand
+        const size_t s16 = (size_t)((TCO * 40 + 255) & ~255) + ((TCI * 40 + 255) & ~255);
+        stage = s16 > stage ? s16 : stage;
+    }
+    return (size_t)wg_stages(half == 2 ? 2 : 0) * stage * 4 + 64;
 }
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;

@@ -118,7 +118,6 @@ struct avc_plan {
     mutable hipStream_t wstream[2] = {nullptr, nullptr};
     mutable std::vector<hipEvent_t> wev;   // sized by the dry run of the backward pass (one per ordering edge)
     mutable hipEvent_t wjoin[2] = {nullptr, nullptr};
-    mutable hipEvent_t ev_pack[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_dense = nullptr;       // recorded behind the dense-stack backward kernel (the decoder's weight gradients wait for it)
     mutable hipEvent_t ev_dec_grads = nullptr;   // recorded when the decoder's parameter gradients are final
     mutable hipEvent_t ev_spk_grads = nullptr;   // ... the speaker encoder's
@@ -146,7 +145,6 @@ struct avc_plan {
     mutable void* pack_blk_dev = nullptr;   // (image, piece) of every block of the launch
     int pack_nblk = 0, pack_nblk_early = 0, pack_early_imgs = 0;   // blocks [0, pack_nblk_early) pack the images the step's first kernels read
     double pack_tab_bytes = 0;
-    mutable bool pack_side_pending = false;   // the tail of the last pack ran on a helper stream: ev_pack[1] marks its end
     bool bh = false;
     long ddecp = -1, dmulsp = -1;   // pair copies of d(dec) and d(muls): the conv launches that consume them read pair operands
 
@@ -602,7 +600,6 @@ extern "C" void avc_plan_destroy(avc_plan* p) {
     if (p->ev_join) hipEventDestroy(p->ev_join);
     for (int i = 0; i < 2; ++i) {
         if (p->wjoin[i]) hipEventDestroy(p->wjoin[i]);
-        if (p->ev_pack[i]) hipEventDestroy(p->ev_pack[i]);
     }
     for (hipEvent_t e : p->wev)
         if (e) hipEventDestroy(e);
@@ -684,19 +681,22 @@ static void plan_init_pack_table(avc_plan* p) {
 // of the process and kept for its lifetime (round 5).  The runtime deals streams to a handful of hardware queues in creation order: the
 // first plan's three streams and the caller's stream take four of them, a second plan's OWN three land wherever the round-robin has got
 // to -- its side stream on the caller's queue, for one: both branches of a pass then run one after the other (bf16 step 4.9 - 6.1 instead of
-// 2.59 ms, measured: scripts/two_plans_probe.py).  Plans never run their helper streams concurrently in the host code of this package, and if
-// two callers do drive two plans at once the shared streams only add ordering, never a hazard: every wait is on an event recorded earlier.
-// Immutable once created; the lookup is mutex-protected.  (Not "mutable state" in the sense of include/avc_hip.h: nothing here changes
-// how any call behaves.)
+// 2.59 ms, measured: scripts/two_plans_probe.py).  All three are created together, in a fixed order, by the FIRST plan of the device; the side
+// stream's priority is that plan's `side_prio` and stays: a later plan that asks for the other priority gets the existing stream (round 6: a
+// fourth helper stream created later put the process back into the queue lottery -- 8.2 instead of 5.9 ms per step,
+// profiles/r05_two_plans_probe.log -- so there is none; avc_plan_side_priority reports what a plan really runs with).
+// Consequences for callers (include/avc_hip.h says the same): the helper streams are process-lifetime objects; two plans driven from two
+// host threads share them, i.e. their side-branch / weight-gradient work is serialised stream by stream (every wait is on an event recorded
+// earlier: ordering, never a hazard).  Immutable once created; the lookup is mutex-protected.
 #ifndef AVC_EMU
 #include <mutex>
 #endif
 struct DevStreams {
-    hipStream_t side[2] = {nullptr, nullptr};   // [normal priority, highest priority]
+    hipStream_t side = nullptr;
     hipStream_t w[2] = {nullptr, nullptr};
-    bool ok = false;
+    int side_prio = -1;   // priority class the side stream was created with (0 normal, 1 highest); -1: not created
 };
-static bool shared_streams(int side_prio, hipStream_t* side, hipStream_t* w0, hipStream_t* w1) {
+static bool shared_streams(int side_prio, hipStream_t* side, hipStream_t* w0, hipStream_t* w1, int* prio_used) {
 #ifdef AVC_EMU
     static DevStreams pool[1];
     const int dev = 0;
@@ -711,33 +711,36 @@ static bool shared_streams(int side_prio, hipStream_t* side, hipStream_t* w0, hi
     }
 #endif
     DevStreams& d = pool[dev];
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
-    const int sp = side_prio ? 1 : 0;
-    if (!d.side[sp]) {
+    if (d.side_prio < 0) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
+        const int sp = side_prio ? 1 : 0;
         // the side stream carries the speaker-encoder branch: the LONGER pole of both passes (forward: pooling + the latency-bound dense stack
         // after its convs, before the decoder can start; backward: d_emb -> dense stack -> its whole dgrad chain -> the last weight gradients).
         // side_prio = 1 dispatches its workgroups ahead of the content branch's and the weight-gradient streams'.
-        if ((sp ? hipStreamCreateWithPriority(&d.side[sp], hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&d.side[sp], hipStreamNonBlocking)) != hipSuccess) {
+        hipStream_t s_ = nullptr, w_[2] = {nullptr, nullptr};
+        bool ok = (sp ? hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&s_, hipStreamNonBlocking)) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithPriority(&w_[i], hipStreamNonBlocking, lo) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();  // no device: single-stream plan
-            d.side[sp] = nullptr;
+            if (s_) hipStreamDestroy(s_);
+            for (int i = 0; i < 2; ++i)
+                if (w_[i]) hipStreamDestroy(w_[i]);
             return false;
         }
+        d.side = s_; d.w[0] = w_[0]; d.w[1] = w_[1];
+        d.side_prio = sp;
     }
-    for (int i = 0; i < 2; ++i)
-        if (!d.w[i] && hipStreamCreateWithPriority(&d.w[i], hipStreamNonBlocking, lo) != hipSuccess) {
-            (void)hipGetLastError();
-            d.w[i] = nullptr;
-            return false;
-        }
-    *side = d.side[sp]; *w0 = d.w[0]; *w1 = d.w[1];
+    *side = d.side; *w0 = d.w[0]; *w1 = d.w[1];
+    *prio_used = d.side_prio;
     return true;
 }
 
 static void plan_init_streams(avc_plan* p) {
     plan_init_pack_table(p);
     p->side_state = -1;
-    if (!shared_streams(p->tun.side_prio, &p->side, &p->wstream[0], &p->wstream[1])) {
+    int prio_used = p->tun.side_prio ? 1 : 0;
+    if (!shared_streams(p->tun.side_prio, &p->side, &p->wstream[0], &p->wstream[1], &prio_used)) {
         p->side = nullptr;
         p->wstream[0] = p->wstream[1] = nullptr;
         return;
@@ -750,11 +753,11 @@ static void plan_init_streams(avc_plan* p) {
               hipEventCreateWithFlags(&p->ev_all_grads, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2; ++i) {
         ok = ok && hipEventCreateWithFlags(&p->wjoin[i], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&p->ev_pack[i], hipEventDisableTiming) == hipSuccess;
     }
     p->wev.assign((size_t)p->nev_need, nullptr);
     for (hipEvent_t& e : p->wev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     p->side_state = ok ? 1 : -1;
+    p->tun.side_prio = prio_used;   // (what the device's shared side stream really has)
 }
 static bool side_ready(const avc_plan* p) { return !p->tun.single_stream && p->side_state == 1; }
 static hipStream_t fork_side(const avc_plan* p, hipStream_t mainS) {
@@ -768,6 +771,7 @@ static void join_side(const avc_plan* p, hipStream_t mainS, hipStream_t sideS) {
     hipEventRecord(p->ev_join, sideS);
     hipStreamWaitEvent(mainS, p->ev_join, 0);
 }
+extern "C" int avc_plan_side_priority(const avc_plan* p) { return p->side_state == 1 ? p->tun.side_prio : -1; }
 extern "C" int avc_plan_num_params(const avc_plan* p) { return (int)p->params.size(); }
 extern "C" long avc_plan_param_floats(const avc_plan* p) { return p->param_floats; }
 extern "C" int avc_plan_param_info(const avc_plan* p, int i, long* offset, long* numel, int dims[3]) {
@@ -1125,7 +1129,6 @@ static int pack_all(const avc_plan* p, const float* params, float* ws, hipStream
         // ONE launch on the caller's stream.  (Round 4 ran the tail of the table on a helper stream under the next step's bank convs:
         // measured neutral -- 6.000 vs 6.009 ms/step -- and its read of `params` was ordered only against a later forward of the SAME
         // plan, a formal read / write race with an optimizer step or a parameter write that follows on another plan; removed.)
-        p->pack_side_pending = false;
         return avc_launch_pack_table(p->pack_tab_dev, p->pack_blk_dev, p->pack_nblk, p->pack_tab_bytes, params, ws, s);
     }
     std::vector<PackArgs> all;
@@ -1181,7 +1184,6 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
             ConvArgs a = mk_fwd(p, SL, L, params, ws, ws + e.cat, CCr * e.T[0], e.T[0], 1, B, e.T[0], ws + e.h0, (long)C * e.T[0], e.T[0], 1, 1);
             RUN(avc_launch_conv(a, s, 0, p->tun));
         }
-        if (p->pack_side_pending) hipStreamWaitEvent(s, p->ev_pack[1], 0);   // the other layers' images (packed under the bank convs)
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.a1[l], (long)C * Ti, Ti, 1, 1);
@@ -1227,7 +1229,6 @@ static int forward_impl(const avc_plan* p, const float* params, const float* x, 
         const int Cc = e.c.c_h;
         const long C = bh ? Cc / 2 : Cc, CCr = bh ? e.CC / 2 : e.CC;
         // (conv bank, in_conv and its InstanceNorm were issued by content_front(), above)
-        if (p->pack_side_pending) hipStreamWaitEvent(s, p->ev_pack[1], 0);
         for (int l = 0; l < e.n; ++l) {
             const int Ti = e.T[l], To = e.T[l + 1];
             ConvArgs a = mk_fwd(p, SL, p->layers[e.c1[l]], params, ws, ws + e.out[l], (long)C * Ti, Ti, 1, B, Ti, ws + e.y1[l], (long)C * Ti, Ti, 1, 0);

@@ -12,18 +12,30 @@
  *  - every pointer is a DEVICE pointer unless stated; tensors are fp32.
  *  - activations are [B, C, T] with explicit element strides where a view may
  *    be handed in (the collate view of data_utils.py:14-16 has strides (T*M, 1, M)).
- *  - the library never allocates, frees or synchronises; scratch memory is a
- *    caller-owned workspace whose size the plan reports (graph-capture safe).
+ *  - scratch memory is a caller-owned workspace whose size the plan reports; the data-path entry points (avc_forward* / avc_loss /
+ *    avc_backward / avc_clip_adam_step / avc_plan_pack_weights and every op-level call) never allocate, free or synchronise -- they only
+ *    enqueue work (graph-capture safe).  Three exceptions, all outside the per-step path, stated here because earlier revisions of this
+ *    header claimed there were none:
+ *      (1) avc_plan_create* allocates a small DEVICE table (hipMalloc: the weight-image descriptors of avc_plan_pack_weights, a few KB)
+ *          and fills it with a blocking hipMemcpy; avc_plan_destroy frees it.  Create plans outside captured / latency-critical regions.
+ *      (2) the FIRST plan created on a device creates that device's three helper HIP streams (below); they live until the process ends.
+ *      (3) avc_forward_ragged uploads its per-utterance length / offset / tile tables (a few KB) with hipMemcpyAsync from pageable host
+ *          memory: the call may block the host until the copy is staged and is NOT graph-capture safe (the uniform entry points are).
  *  - return value: 0 = ok, < 0 = bad argument / unsupported shape,
  *    > 0 = hipError_t.  avc_last_error() describes the last failure.
  *  - the stream is always an argument (backward runs on PyTorch's autograd
- *    thread).  A plan owns a few helper HIP streams and events
- *    (created by avc_plan_create on the device that is current at that moment,
- *    destroyed by avc_plan_destroy) on which it overlaps independent branches;
- *    every entry point joins them back into the caller's stream before it
- *    returns.  ONE call per plan may be in flight on the host at a time (two
- *    host threads need two plans); different plans are independent.
- *  - the library has NO process-wide mutable state.  Launch heuristics and
+ *    thread).  A plan overlaps independent branches on three helper HIP streams -- one "side" stream (the
+ *    speaker-encoder branch, the decoder's second half-batch chain) and two low-priority weight-gradient streams -- and on events of
+ *    its own (created by avc_plan_create*, destroyed by avc_plan_destroy); every entry point joins them back into the caller's stream
+ *    before it returns.  The three helper STREAMS are ONE set per device, created by the first plan on that device, shared by every
+ *    plan of the process and never destroyed (a second set lands on whatever hardware queues the runtime's round-robin has reached
+ *    and was measured 1.8 - 2.4x slower: scripts/two_plans_probe.py).  The side stream's priority is the FIRST plan's
+ *    avc_tuning.side_prio; later plans get that stream whatever they ask for (avc_plan_side_priority reports it).  ONE call per plan
+ *    may be in flight on the host at a time (two host threads need two plans); two plans driven from two threads are functionally
+ *    independent but share the helper streams, i.e. their side-branch / weight-gradient work is serialised stream by stream
+ *    (tests/test_engine.py::test_two_plans_from_two_threads: results bit-equal to the serial runs).
+ *  - the library has no process-wide mutable state that changes RESULTS or heuristics: the only process-lifetime objects are the helper
+ *    streams above.  Launch heuristics and
  *    diagnostic switches are an `avc_tuning` value that a plan captures at
  *    creation (avc_plan_create_tuned); the op-level entry points at the end of
  *    this header read a THREAD-LOCAL avc_tuning that avc_set_tuning edits for
@@ -82,6 +94,9 @@ int avc_plan_create(const avc_model_cfg* cfg, int B, int T, int T_cond, avc_plan
 #define AVC_PLAN_SPEAKER_ONLY 2
 int avc_plan_create_ex(const avc_model_cfg* cfg, int B, int T, int T_cond, int flags, avc_plan** out);
 int avc_plan_flags(const avc_plan* p);
+/* priority class of the device's shared side stream this plan runs its side branch on: 1 = highest, 0 = normal, -1 = the plan has no
+ * helper streams (no device at creation: every kernel goes to the caller's stream) */
+int avc_plan_side_priority(const avc_plan* p);
 void avc_plan_destroy(avc_plan* p);
 /* flat parameter buffer: the 166 state_dict tensors in reference
  * registration order, each at a 16-byte aligned offset */
@@ -142,9 +157,10 @@ typedef struct avc_tuning {
     int conv_ablation;      /* timing experiments only, WRONG results when set: bit0 no DMA, bit1 no MFMA, bit2 no barrier, bit3 no store */
     int wgrad_ablation;
     int op_compute_dtype;   /* op-level conv entry points: 0 fp32, 1 bf16 operands (plans: avc_plan_set_compute_dtype) */
-    int side_prio;          /* 1 (default since round 5): the plan's side stream (speaker-encoder branch, the longer pole of forward and backward) is
+    int side_prio;          /* 1 (default since round 5): the device's side stream (speaker-encoder branch, the longer pole of forward and backward) is
                              * created with the highest stream priority -- its kernels are dispatched ahead of the weight-gradient launches and the
-                             * other branch's when CU slots free up (-2.2 % on the B = 256 step); 0: normal priority */
+                             * other branch's when CU slots free up (-2.2 % on the B = 256 step); 0: normal priority.  Honoured by the FIRST plan
+                             * created on a device only: the helper streams are one set per device and process (see "Conventions") */
     int tile12_wgs;         /* 64 x 128 column tiles (two fragments per wave share each weight fragment) for stride-1 k = 5 layers whose launch still has
                              * at least this many workgroups; 0 = never */
     long wgrad_batch_units; /* pending (tile x K-chunk) units that trigger a batched launch early (1 << 40 = never) */

@@ -346,7 +346,17 @@ WG = [
     (8, 16, 32, 16, 5, 1),       # whole short samples per chunk
     (8, 16, 32, 32, 5, 2),
     (7, 16, 32, 16, 5, 1),
-    (4, 64, 64, 64, 5, 1),       # whole 32-column chunks (ds_read_b128 path)
+    (4, 64, 64, 64, 5, 1),       # whole 32-column chunks (ds_read_b128 path; round 6: 16-byte staged rows, first + last chunk of a sample)
+    (3, 64, 64, 32, 5, 1),       # ... one chunk per sample: both mirrored edges in the same fragment set
+    (2, 128, 64, 96, 5, 1),      # ... three chunks per sample (an interior chunk), two ci tiles
+    (2, 64, 128, 64, 1, 1),      # ... 1x1 (no halo pieces read)
+    (1, 256, 128, 64, 1, 1),     # ... 1x1 on the 128 x 128 four-accumulator tile
+    (2, 80, 128, 32, 8, 1),      # ... run-time tap counts (the bank's instance): fragments read at a dword-aligned LDS address, mirrored frames by (padL, padR)
+    (1, 80, 64, 64, 3, 1),
+    (1, 16, 32, 96, 6, 1),
+    (2, 80, 32, 64, 5, 1),
+    (1, 16, 32, 64, 2, 1),
+    (1, 16, 32, 64, 7, 1),
     pytest.param(16, 128, 128, 128, 5, 1, marks=GPU),
     pytest.param(16, 128, 128, 128, 5, 2, marks=GPU),
     pytest.param(64, 128, 256, 16, 5, 1, marks=GPU),

@@ -479,3 +479,63 @@ def test_partial_gradient_events_order_a_consumer_stream(part):
         torch.cuda.synchronize()
         assert torch.isfinite(early).all()
         assert torch.equal(early, grads[off:off + n])
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 2, 32), pytest.param("gpu", "m80", 32, 128, marks=pytest.mark.gpu)])
+def test_two_plans_from_two_threads(kind, cfgname, B, T):
+    """VERDICT r5 item 4c.  include/avc_hip.h: "two host threads need two plans"; since round 5 the helper streams are ONE set per device
+    that every plan shares.  Two plans of different shapes, each driven by its own host thread on its own caller stream, several steps
+    concurrently: every result must be bit-equal to the same plan run alone -- the shared streams may serialise the two, never mix them.
+    Also: the side stream's priority is the first plan's (avc_plan_side_priority), whatever a later plan asks for."""
+    import threading
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 5)
+    shapes = [(B, T), (B + 1, T + (8 if kind == "emu" else 64))]
+    plans = [Plan(cfg, b, t, lib=lib, tuning=({"side_prio": 0} if i else None)) for i, (b, t) in enumerate(shapes)]
+    assert lib.avc_plan_side_priority(plans[0].h) == lib.avc_plan_side_priority(plans[1].h)   # one side stream per device and process
+    params = flat_params(plans[0], sd, dev)
+    data = [tuple(t.to(dev) for t in O.make_inputs(cfg, b, t, 7 + i)) for i, (b, t) in enumerate(shapes)]
+    streams = [torch.cuda.Stream(device=dev) if kind == "gpu" else None for _ in plans]
+
+    def step(i):
+        plan, (x, eps) = plans[i], data[i]
+        ws = torch.zeros(plan.workspace_floats, device=dev)
+        g = torch.zeros(plan.param_floats, device=dev)
+        ctx = torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()
+        with ctx:
+            plan.forward(params, x, None, eps, ws)
+            plan.loss(x, 10.0, ws)
+            plan.backward(params, x, None, eps, g, ws, lambda_kl=1.0)
+        if streams[i] is not None:
+            streams[i].synchronize()
+        return g.cpu(), plan.view(ws, "dec", (x.shape[0], cfg["Decoder"]["c_out"], plan.out_len)).cpu()
+
+    import contextlib
+    if kind == "gpu":
+        torch.cuda.synchronize()
+    alone = [step(0), step(1)]
+    nsteps = 4 if kind == "gpu" else 1
+    out = [[None] * nsteps, [None] * nsteps]
+    err = []
+
+    def worker(i):
+        try:
+            for k in range(nsteps):
+                out[i][k] = step(i)
+        except Exception as e:   # noqa: BLE001
+            err.append(e)
+    if kind == "gpu":
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+    else:   # the CPU simulator runs kernels on fibers of ONE host thread: its twin interleaves the two plans' steps instead
+        for i in (1, 0):
+            worker(i)
+    assert not err, err
+    for i in range(2):
+        for k in range(nsteps):
+            assert torch.equal(out[i][k][0], alone[i][0]), f"plan {i}, concurrent step {k}: gradients differ from the serial run"
+            assert torch.equal(out[i][k][1], alone[i][1]), f"plan {i}, concurrent step {k}: dec differs from the serial run"
