@@ -527,6 +527,10 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
                     for (int r = 0; r < 16; ++r) red[((wm * WN + wn) * 16 + r) * 64] = acc[wm][wn][r];
         }
         __syncthreads();
+        // (the waves of groups kg > 0 END here; the remaining four waves still meet at workgroup barriers below -- the fused InstanceNorm
+        // epilogues' and the one in front of them.  s_barrier on gfx9 counts the waves of the workgroup that have not terminated, so a barrier
+        // behind an exited wave is well defined on this target -- the only one this file is written for; ADVICE r5 notes that the HIP
+        // language itself leaves it undefined.)
         if (kg > 0) return;
 #pragma unroll
         for (int k2 = 1; k2 < KG; ++k2) {
@@ -549,9 +553,10 @@ __global__ void __launch_bounds__(AVC_THREADS * KG) conv_gemm_kernel(const ConvA
         return;
     }
     if constexpr (INB) {
-        static_assert(WM == 1 && WN == 1 && BF == 0 && !RAG && !WALK && !INF, "fused InstanceNorm-backward epilogue: exact-fp32 input gradient, 64 x 64 tiles");
+        static_assert(WM == 1 && WN == 1 && (BF == 0 || BF == 2) && !RAG && !WALK && !INF, "fused InstanceNorm-backward epilogue: input gradient on 64 x 64 tiles, fp32 or bf16 pairs");
         if (KG > 1) __syncthreads();
-        conv_epilogue_in_bwd(a, g, acc[0][0], smem, tid, wave_m, h, m_tile0, q.b0, q.t0, colb[0] - q.b0, colt[0], colv[0]);
+        if constexpr (BF == 2) conv_epilogue_in_bwd_pairs(a, g, acc[0][0], smem, tid, wave_m, h, m_tile0, q.b0, q.t0, colb[0] - q.b0, colt[0], colv[0]);
+        else conv_epilogue_in_bwd(a, g, acc[0][0], smem, tid, wave_m, h, m_tile0, q.b0, q.t0, colb[0] - q.b0, colt[0], colv[0]);
         return;
     }
     if (!(a.dbg & 8)) {
@@ -853,17 +858,17 @@ static void conv_launch_inf(const ConvArgs& a, int fast, dim3 grid, dim3 block, 
 }
 // fused InstanceNorm-backward epilogue (ConvINBwd): input-gradient launches on 64 x 64 tiles -- the mirrored k = 5 chunk at 8 / 16 channels with
 // and without the stride-2 column-parity split, the 1x1 chunk, the generic chunk loop, each with one or two split-K wave groups
-template <int KG>
+template <int KG, int BF>
 static void conv_launch_inb(const ConvArgs& a, bool mir, int fast, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    if (a.par && mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
-    else if (a.par && mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
-    else if (a.par && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
-    else if (a.par) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, 0, true, false, false, false, true>), grid, block, lds, stream, a);
-    else if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
-    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
-    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 0, 0, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
-    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, 0, false, false, false, false, true>), grid, block, lds, stream, a);
+    if (a.par && mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par && mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 1, KG, BF, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (a.par) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 5, 2, KG, BF, true, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir && fast == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 1, KG, BF, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir && fast == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 5, 2, KG, BF, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (mir) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, true, 0, 0, KG, BF, false, false, false, false, true>), grid, block, lds, stream, a);
+    else if (fast == 14) hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 1, 4, KG, BF, false, false, false, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, false, 0, 0, KG, BF, false, false, false, false, true>), grid, block, lds, stream, a);
 }
 static bool conv_walk_instance(int tile, bool mir, int fast) {
     return (tile == 11 && (fast == 1 || ((fast == -1 || fast == 14) && !mir))) || (tile == 21 && fast == 14 && !mir);
@@ -909,17 +914,20 @@ bool avc_conv_in_fusable(const ConvArgs& a, const avc_tuning& tun, int res_mode,
 // ... and of an input-gradient launch: may the InstanceNorm BACKWARD of its output rows run in its epilogue (ConvINBwd)?  Exact-fp32 dgrad on
 // 64 x 64 tiles whose columns are whole rows; contiguous [B][M][T] output and residual-gradient rows; only the "to primary" join.
 bool avc_conv_inb_fusable(const ConvArgs& a, const avc_tuning& tun) {
-    if (!tun.conv_in_fuse || a.mode != 1 || a.ngroups != 1 || a.rag.tile || a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4 || a.pairs) return false;
+    if (!tun.conv_in_fuse || a.mode != 1 || a.ngroups != 1 || a.rag.tile) return false;
+    const bool bh = a.bf16 == AVC_COMPUTE_BF16S;   // bf16 pair storage (round 6): pair rows in, pair rows out; strides in dwords over M / 2 pair rows per sample
+    if (bh ? (a.img != AVC_IMG_K4H || !a.pairs || (a.M & 1) || a.x.ps != 1 || a.x.st != 1) : (a.bf16 != AVC_COMPUTE_F32 || a.img != AVC_IMG_K4 || a.pairs)) return false;
     if (a.Tout != 16 && a.Tout != 32 && a.Tout != 64) return false;
     if (a.ops != 1 || a.act || a.g[0].out2 || a.g[0].mask || a.g[0].bias) return false;
-    if (a.ot != 1 || a.oc != a.Tout || a.ob != (long)a.M * a.Tout) return false;
+    const long Mr = bh ? a.M / 2 : a.M;
+    if (a.ot != 1 || a.oc != a.Tout || a.ob != Mr * a.Tout) return false;
     if (a.res_mode != AVC_RES_NONE) {
-        if (!a.res_to_primary || a.rt != 1 || a.rc != a.Tres || a.rb != (long)a.M * a.Tres) return false;
+        if (!a.res_to_primary || a.rt != 1 || a.rc != a.Tres || a.rb != Mr * a.Tres) return false;
         if (!((a.res_mode == AVC_RES_IDENTITY && a.Tres == a.Tout) || (a.res_mode == AVC_RES_POOLT && 2 * a.Tres == a.Tout) ||
               (a.res_mode == AVC_RES_UPT && a.Tres == 2 * a.Tout))) return false;
     }
     if (conv_geom(1, a.stride, a.Tout, a.g[0].KS, 64, 0).SPT != 64 / a.Tout) return false;
-    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS) == 11;
+    return avc_conv_pick_tile(tun, a.Mp, a.B, a.Tout, 1, a.Cred * a.g[0].KS * (bh ? 2 : 1)) == 11;
 }
 
 // returns 0 on success, negative on unsupported geometry
@@ -1021,8 +1029,9 @@ int avc_launch_conv(const ConvArgs& a_in, hipStream_t stream, int force_tile, co
         else { CALL_(0); }                   \
     } while (0)
     if (a.inb.dy) {
-        if (kgroups == 2) conv_launch_inb<2>(a, mir, fast, grid, block, lds, stream);
-        else conv_launch_inb<1>(a, mir, fast, grid, block, lds, stream);
+        if (bf == 2) conv_launch_inb<1, 2>(a, mir, fast, grid, block, lds, stream);   // (pair storage runs without split-K wave groups)
+        else if (kgroups == 2) conv_launch_inb<2, 0>(a, mir, fast, grid, block, lds, stream);
+        else conv_launch_inb<1, 0>(a, mir, fast, grid, block, lds, stream);
     } else if (a.in.out) {
         const int f = (fast == 1 || fast == 2 || fast == 14) ? fast : 0;   // (the k = 5 chunk at 32 channels takes the generic loop)
         if (bf == 2) conv_launch_inf<1, 2>(a, f, grid, block, lds, stream);   // (pair storage runs without split-K wave groups)

@@ -514,6 +514,134 @@ static __device__ void conv_epilogue_in_pairs(const ConvArgs& a, const ConvGroup
     }
 }
 
+// ... the backward twin on bf16 PAIR tensors (round 6).  g = conv^T(dy) [+ residual-gradient join] is rounded to bf16 FIRST -- what the
+// two-launch path stores and instnorm_bwd_pairs_kernel reads back -- and the InstanceNorm / AdaIN / activation backward is taken from the
+// rounded values; y, the join source, g (where kept) and dy are pair rows [B][C/2][T].  A lane owns 16 frames of ONE channel row for the
+// arithmetic (conv_epilogue_in_bwd's layout); the lanes of rows (2p, 2p + 1) exchange halves for the stores, each packing 8 frames of both.
+static __device__ void conv_epilogue_in_bwd_pairs(const ConvArgs& a, const ConvGroup& g, const f32x16& acc, float* tile, int tid, int wave_m, int h,
+                                                  int m_tile0, int b0, int t0_tile, int bl_lane, int t_lane, bool col_valid) {
+    const ConvINBwd& f = a.inb;
+    const int Tout = a.Tout, lpr = Tout >> 4;
+    if (col_valid) {
+        const int col = bl_lane * Tout + (t_lane - t0_tile);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[row * AVC_IN_LDT + col] = acc[r];
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 2, qd = tid & 3;
+    const int m = m_tile0 + r, odd = m & 1;
+    const int bl = (16 * qd) / Tout, t0 = 16 * qd - bl * Tout;
+    const int b = b0 + bl;
+    const bool valid = m < a.M && b < a.B;
+    const int mc = m < a.M ? m : a.M - 1, bc = b < a.B ? b : a.B - 1;   // (clamped: every lane takes part in the exchanges)
+    float gv[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 x = *(const float4*)(tile + r * AVC_IN_LDT + 16 * qd + 4 * k);
+        gv[4 * k] = x.x; gv[4 * k + 1] = x.y; gv[4 * k + 2] = x.z; gv[4 * k + 3] = x.w;
+    }
+    const int C2 = f.C >> 1;
+    const long prow = (long)bc * C2 + (mc >> 1);       // the pair row of this lane's channel
+    const long rowi = (long)bc * f.C + mc;
+    // this lane's channel of the saved forward rows: its half of the 16 dwords (the partner lane reads the same dwords: one cache line)
+    float yv[16];
+    const unsigned* yrow = (const unsigned*)f.y + prow * Tout + t0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const conv_u32x4 v = *(const conv_u32x4*)(yrow + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[4 * k + e] = odd ? bh_hi(v[e]) : bh_lo(v[e]);
+    }
+    const float mean = f.mean[rowi], rstd = f.rstd[rowi];
+    float gamma = 1.f, beta = 0.f;
+    if (f.cond) {
+        const float* cr = f.cond + (long)bc * f.cond_sb + f.cond_off;
+        beta = cr[mc];
+        gamma = cr[f.C + mc];
+    }
+    if (a.res_mode != AVC_RES_NONE) {   // residual-gradient join (pair rows [B][M/2][Tres]; res_to_primary)
+        const unsigned* rrow = (const unsigned*)g.res + ((long)bc * (a.M >> 1) + (mc >> 1)) * a.Tres;
+        if (a.res_mode == AVC_RES_IDENTITY) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const conv_u32x4 v = *(const conv_u32x4*)(rrow + t0 + 4 * k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[4 * k + e] += odd ? bh_hi(v[e]) : bh_lo(v[e]);
+            }
+        } else if (a.res_mode == AVC_RES_POOLT) {   // adjoint of the ceil-mode pool: g[t / 2] / 2 (Tout even: no clipped window)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const conv_u32x4 v = *(const conv_u32x4*)(rrow + (t0 >> 1) + 4 * k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = (odd ? bh_hi(v[e]) : bh_lo(v[e])) * 0.5f;
+                    gv[8 * k + 2 * e] += x;
+                    gv[8 * k + 2 * e + 1] += x;
+                }
+            }
+        } else {   // AVC_RES_UPT: adjoint of nearest x2: g[2t] + g[2t + 1]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const conv_u32x4 v = *(const conv_u32x4*)(rrow + 2 * t0 + 4 * k);
+                gv[2 * k] += odd ? bh_hi(v[0]) + bh_hi(v[1]) : bh_lo(v[0]) + bh_lo(v[1]);
+                gv[2 * k + 1] += odd ? bh_hi(v[2]) + bh_hi(v[3]) : bh_lo(v[2]) + bh_lo(v[3]);
+            }
+        }
+    }
+    // g as the two-launch path stores it: ONE rounding of (accumulator + join)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gv[i] = bh_lo(bh_pack(gv[i], 0.f));
+    // pack helper: rows (2p, 2p + 1) -- the even row's lane keeps frames [0, 8) of its 16, the odd row's lane frames [8, 16), each with BOTH channels
+    auto store_pairs = [&](unsigned* base, const float (&v)[16]) {
+        float lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float rcv = __shfl_xor(odd ? v[i] : v[8 + i], 4);
+            lo[i] = odd ? rcv : v[i];
+            hi[i] = odd ? v[8 + i] : rcv;
+        }
+        if (!valid) return;
+        unsigned* drow = base + prow * Tout + t0 + 8 * odd;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            conv_u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = bh_pack(lo[4 * k + e], hi[4 * k + e]);
+            *(conv_u32x4*)(drow + 4 * k) = w;
+        }
+    };
+    if (g.out) store_pairs((unsigned*)g.out, gv);   // the block's residual path reads g too (launch-uniform)
+    float xh[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float hh = in_xhat(yv[i], mean, rstd);
+        const float w = in_preact(hh, gamma, beta);
+        const float gme = avc_act_grad(gv[i], !f.relu || w > 0.f, a.slope);
+        xh[i] = hh;
+        gv[i] = gme;
+        s1 += gme;
+        s2 += gme * hh;
+    }
+    for (int o = 1; o < lpr; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (valid && f.dcond && qd % lpr == 0) {
+        float* dc = f.dcond + (long)b * f.dcond_sb + f.dcond_off;
+        dc[m] = s1;
+        dc[f.C + m] = s2;
+    }
+    const float invT = 1.0f / (float)Tout;
+    const float m1 = gamma * s1 * invT, m2 = gamma * s2 * invT;
+    float dv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dv[i] = rstd * (gv[i] * gamma - m1 - xh[i] * m2);
+    store_pairs((unsigned*)f.dy, dv);
+}
+
 // ---- the same epilogue on bf16 PAIR tensors (bf16_pairs.h): rows m (even) and m + 1 of the lane's column are one dword.
 // Strides are dword strides of the [B][C/2][T] tensors; M is even; time stride 1.
 // the (up to two) dwords of a residual pair row that conv_res_value's modes combine, as element offsets inside the row (time stride 1)

@@ -309,7 +309,14 @@ extern "C" int avc_plan_create_tuned(const avc_model_cfg* cfg, int B, int T, int
         p->compute = AVC_COMPUTE_BF16S;
         p->tun.conv_x3 = 0;
         p->tun.wgrad_x3 = 0;
+        // schedule defaults of THIS mode (round 6, profiles/r06_bf16_schedule_sweep.log; the fp32 step measured both neutral or worse):
+        // its weight gradients cost an eighth of the fp32 ones' matrix time, so (a) the decoder's go out UNDER the decoder's own latency-bound
+        // backward chain, six layers at a time on 192 CUs, instead of being held behind the dense-stack kernel (2.44 - 2.46 vs 2.48 - 2.51 ms),
+        // and (b) batches of 16 layers per stream-K launch (2.46 - 2.47 ms).  A caller's own values win: -1 = "held", any other batch size.
+        if (p->tun.dec_wgrad_flush == 0) { p->tun.dec_wgrad_flush = 6; p->tun.dec_wgrad_wgs = 192; }
+        if (p->tun.wgrad_batch == avc_default_tuning().wgrad_batch) p->tun.wgrad_batch = 16;
     }
+    if (p->tun.dec_wgrad_flush < 0) p->tun.dec_wgrad_flush = 0;   // (-1: held, explicitly)
 
     // ---- parameters in reference registration order
     build_enc_params(p, p->spk, cfg->spk, true);
@@ -1446,9 +1453,9 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             // An input-gradient launch whose output rows are the d(out) of the NEXT phase's InstanceNorm layer runs that layer's backward
             // in its epilogue where the tile holds whole rows (rows of 16 / 32 / 64 frames, fp32: avc_conv_inb_fusable); the next phase
             // then skips its row kernel.  `keep_g`: the launch's own output is read again (the block's skip path).
-            auto dgrad_inb = [&](ConvArgs& a, bool keep_g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy) -> int {
+            auto dgrad_inb = [&](ConvArgs& a, bool keep_g, long off, long yoff, long stoff, int T, int coff, bool cond, float* dy, bool planar = false) -> int {
                 st.fused = false;
-                if (!bh && a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {
+                if (!planar && a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {   // (pair tensors too since round 6; the "planar" rows behind a pixel shuffle keep the row kernel)
                     a.inb.dy = dy + off; a.inb.y = ws + yoff + off;
                     a.inb.mean = ws + stoff + (long)b0 * Cc; a.inb.rstd = ws + stoff + (long)B * Cc + (long)b0 * Cc;
                     a.inb.cond = cond ? ws + d.cond + (long)b0 * csb : nullptr; a.inb.cond_sb = csb; a.inb.cond_off = coff;
@@ -1465,7 +1472,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
                 ConvArgs a = mk_dgrad(SL, Lo, ws, ddec + oi, Mr * To, To, 1, 1, Bn, To, To, st.gA + oo, (long)C * To, To, 1);
                 // next: the AdaIN backward of the last block's second conv (rows of To frames)
                 const int ln = d.n - 1;
-                RUN(dgrad_inb(a, true, oo, d.y2[ln], d.st2[ln], d.T[ln + 1], (2 * ln + 1) * 2 * Cc, true, dy2[ln]));
+                RUN(dgrad_inb(a, true, oo, d.y2[ln], d.st2[ln], d.T[ln + 1], (2 * ln + 1) * 2 * Cc, true, dy2[ln], bh && d.c.upsample[ln] > 1));
                 return 0;
             }
             if (ph == 2 * d.n + 1) {
@@ -1494,7 +1501,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
             ConvArgs a = mk_dgrad(SL, p->layers[d.c1[l]], ws, dy1[l] + o1, (long)C * Ti, Ti, 1, 1, Bn, Ti, Ti, st.gC + o1, (long)C * Ti, Ti, 1);
             set_res(a, st.gA + o2, up > 1 ? AVC_RES_UPT : AVC_RES_IDENTITY, (long)C * T2, T2, 1, T2);
             // next: the AdaIN backward of the previous block's second conv, or the in_conv's InstanceNorm (rows of Ti frames); gC feeds the skip path too
-            if (l > 0) RUN(dgrad_inb(a, true, o1, d.y2[l - 1], d.st2[l - 1], Ti, (2 * (l - 1) + 1) * 2 * Cc, true, dy2[l - 1]));
+            if (l > 0) RUN(dgrad_inb(a, true, o1, d.y2[l - 1], d.st2[l - 1], Ti, (2 * (l - 1) + 1) * 2 * Cc, true, dy2[l - 1], bh && d.c.upsample[l - 1] > 1));
             else RUN(dgrad_inb(a, true, o1, d.y0, d.st0, Tb, 0, false, dy0));
             float* t = st.gA; st.gA = st.gC; st.gC = t;
             return 0;
@@ -1595,7 +1602,7 @@ int avc_backward_impl(const avc_plan* p, const float* params, const float* x, lo
         // epilogue where the tile holds whole rows (avc_conv_inb_fusable); the row kernel then stays out of the chain.
         auto dgrad_inb = [&](ConvArgs& a, bool keep_g, const float* y, const float* st, int T, float* dy) -> bool {
             bool fused = false;
-            if (!bh && a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {
+            if (a.Tout == T && avc_conv_inb_fusable(a, p->tun)) {   // (pair tensors too since round 6)
                 a.inb.dy = dy; a.inb.y = y; a.inb.mean = st; a.inb.rstd = st + (long)B * Cc;
                 a.inb.C = Cc; a.inb.relu = 1;
                 if (!keep_g) a.g[0].out = nullptr;

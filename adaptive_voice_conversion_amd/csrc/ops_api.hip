@@ -257,26 +257,28 @@ int avc_conv1d_dgrad_in_bwd(const float* dy, long syb, long syc, int syt, int yp
                             int stride, int Tin, float* g_out, const float* res, int res_mode, int Tres, const float* y, const float* mean,
                             const float* rstd, const float* cond, long cond_sb, int cond_off, int relu, float* dy_out, float* dcond,
                             long dcond_sb, int dcond_off, int* fused, void* stream) {
-    if (op_bh()) return -2;
+    const bool bh = op_bh();   // op_compute_dtype 3: dy / res / y / g_out / dy_out are bf16 pair tensors (dwords [B][C/2][T]), wpd a pair image
+    if (bh && (avc_op_tuning().op_compute_dtype != AVC_COMPUTE_BF16S || (Cin & 1) || (Cout & 1))) return -2;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     op_compute(a);
     a.x.ptr = dy; a.x.sb = syb; a.x.sc = syc; a.x.st = syt; a.x.ps = yps;
-    a.B = B; a.Cred = Cout; a.Tsrc = Tdy;
+    a.B = B; a.Cred = bh ? Cout / 2 : Cout; a.Tsrc = Tdy;
     a.mode = 1; a.stride = stride;
     const int padL = KS / 2, padR = (KS % 2 == 0) ? KS / 2 - 1 : KS / 2;
     a.mirror = (KS > 1) ? 1 : 0;
     a.M = Cin; a.Mp = avc_cdiv(Cin, 128) * 128;
     a.Tout = Tin;
-    a.ob = (long)Cin * Tin; a.oc = Tin; a.ot = 1; a.ops = 1;
+    const long Cr = bh ? Cin / 2 : Cin;   // rows per sample of the [B, Cin, T] tensors (pair rows with bh)
+    a.ob = Cr * Tin; a.oc = Tin; a.ot = 1; a.ops = 1;
     a.slope = relu == 2 ? AVC_LRELU_SLOPE : 0.f;
     a.res_mode = res ? res_mode : AVC_RES_NONE; a.res_to_primary = 1;
-    a.rb = (long)Cin * Tres; a.rc = Tres; a.rt = 1; a.Tres = Tres;
+    a.rb = Cr * Tres; a.rc = Tres; a.rt = 1; a.Tres = Tres;
     a.ngroups = 1;
     a.g[0].CK = avc_conv_ck(avc_op_tuning(), KS);
     a.g[0].wp = wpd; a.g[0].out = g_out; a.g[0].res = res;
-    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(Cout, a.g[0].CK);
-    a.img = AVC_IMG_K4;
+    a.g[0].KS = KS; a.g[0].padL = padL; a.g[0].padR = padR; a.g[0].nchunk = avc_cdiv(a.Cred, a.g[0].CK);
+    a.img = bh ? AVC_IMG_K4H : AVC_IMG_K4;
     const bool fuse = avc_conv_inb_fusable(a, avc_op_tuning());
     if (fused) *fused = fuse ? 1 : 0;
     if (fuse) {
@@ -289,6 +291,7 @@ int avc_conv1d_dgrad_in_bwd(const float* dy, long syb, long syc, int syt, int yp
     if (!g_out) return -1;
     int rc = avc_launch_conv(a, (hipStream_t)stream, 0, avc_op_tuning());
     if (rc) return rc;
+    if (bh) return avc_instnorm_bwd_pairs(g_out, y, mean, rstd, B, Cin, Tin, cond, cond_sb, cond_off, relu, 0, dy_out, dcond, dcond_sb, dcond_off, stream);
     return avc_instnorm_bwd(g_out, y, mean, rstd, B, Cin, Tin, cond, cond_sb, cond_off, relu, dy_out, dcond, dcond_sb, dcond_off, stream);
 }
 

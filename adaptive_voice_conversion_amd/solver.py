@@ -233,7 +233,7 @@ class Solver(object):
         packed = (pk is not None and pk[0] is plan and pk[1] is ws and pk[2] is flat and pk[3] == model.weights_version()
                   and not self.config.get("repack_every_step", False))
         if packed and self.config.get("verify_packed_weights", False):
-            if float(flat.double().sum()) != pk[4]:
+            if self._param_fingerprint(flat) != pk[4]:
                 raise RuntimeError("the parameters changed behind the version counters since the weight images were packed "
                                    "(in-place edit through .data, a foreign kernel, a collective): call AE.weights_changed() after such writes")
         plan.forward(flat, x, None, eps, ws, weights_packed=packed)
@@ -249,12 +249,20 @@ class Solver(object):
         gnorm = self.opt.step(self.config["optimizer"]["grad_norm"], grad_prescale=prescale)
         plan.pack_weights(flat, ws)    # the next step opens with its first convolution (engine.Plan.forward, weights_packed)
         self._packed = (plan, ws, flat, model.weights_version(),
-                        float(flat.double().sum()) if self.config.get("verify_packed_weights", False) else None)
+                        self._param_fingerprint(flat) if self.config.get("verify_packed_weights", False) else None)
         losses = plan.view(ws, "losses", (2,))
         if not sync:
             return {"loss_rec": losses[0], "loss_kl": losses[1], "grad_norm": gnorm[0]}
         vals = torch.cat([losses, gnorm]).tolist()  # one D2H sync (the reference does .item() x2, solver.py:94-95)
         return {"loss_rec": vals[0], "loss_kl": vals[1], "grad_norm": vals[2]}
+
+    @staticmethod
+    def _param_fingerprint(flat):
+        """Position-dependent fingerprint of the flat parameter buffer (`verify_packed_weights`): the BITS of every element, multiplied by an odd
+        per-position weight, summed modulo 2^64.  A plain sum misses sum-preserving edits -- two swapped weights, a permuted row."""
+        bits = flat.view(torch.int32).to(torch.int64)
+        pos = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64)
+        return int(((bits + 0x9E3779B9) * (2 * pos + 1)).sum().item())
 
     def kl_weight(self, iteration):
         """solver.py:101-104 linear annealing."""

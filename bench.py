@@ -251,7 +251,7 @@ def instnorm_all_shapes(plan, reps=8, pairs=False):
     return out
 
 
-PMC_SUMMARIES = ("r05_pmc_fetch_write_summary.json", "r04_pmc_fetch_write_summary.json")
+PMC_SUMMARIES = ("r06_pmc_fetch_write_summary.json", "r05_pmc_fetch_write_summary.json")
 
 
 def build_fingerprint():
@@ -326,7 +326,7 @@ def pmc_class_traffic(cls):
     return (tot / launches, src) if launches else (None, None)
 
 
-SQ_SUMMARIES = ("r05_sq_step.json",)
+SQ_SUMMARIES = ("r06_sq_step.json", "r05_sq_step.json")
 _SQ_NOTE = [None]
 
 
@@ -781,6 +781,23 @@ def workload_label(a, world):
     return metric, f"{tag}: {what}", idx
 
 
+def bind_rank_to_cores(local_rank, local_world):
+    """N ranks x ~200 kernel launches per 2.5 - 6 ms step share one host: give every rank its own contiguous slice of the cores this
+    process may run on (on a two-socket node contiguous core numbers are one NUMA node, so a rank's launch thread, its RCCL proxy thread and
+    their memory stay on one socket) instead of letting N launch threads migrate over all of them.  Best effort: no-op where
+    sched_setaffinity is unavailable or the slice would be empty."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // max(local_world, 1)
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
+
+
 def relaunch_ranks(a):
     """``python bench.py --gpus N`` without a launcher: start N ranks (one per GPU) on this node."""
     import socket
@@ -845,6 +862,8 @@ def main():
         local = local % torch.cuda.device_count()   # ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        bind_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -10,8 +10,8 @@ one() { local label="$1"; local lib="$2"; shift; shift
   python -c "
 import json; d=json.loads(open('/tmp/b.json').read()); print('$label'.ljust(48), round(d['ms_per_step'],3), d['config'].get('final_losses'))" | tee -a $OUT/ab.log; }
 for rep in 1 2 3; do
-  one "bf16 HEAD (dword staging)" $HEAD --dtype bf16
-  one "bf16 16-byte staging" $NEW --dtype bf16
+  one "bf16 HEAD (previous commit)" $HEAD --dtype bf16
+  one "bf16 working tree" $NEW --dtype bf16
   one "bf16 16-byte staging, wgrad_batch_wgs=512" $NEW --dtype bf16 --tune wgrad_batch_wgs=512
   one "bf16 B=4 16-byte staging" $NEW --dtype bf16 --batch 4 --steps 200 --warmup 20
   one "f32 (unchanged)" $NEW

@@ -252,6 +252,70 @@ def test_conv_dgrad_in_bwd_fused_epilogue(kind, B, Cin, Cout, T, KS, stride, res
         torch.testing.assert_close(c1, c2, rtol=1e-4, atol=1e-4)
 
 
+# ... on bf16 pair tensors (round 6): g is rounded to bf16 first (what the two-launch path stores and the pair row kernel reads back), the
+# InstanceNorm backward taken from the rounded values; g bit for bit, dy within a bf16 ulp of the two-launch path (a row sum that differs in its
+# last bit may move an element across a rounding boundary), dcond to summation order.
+PAIR_BWD_CASES = [
+    (3, 32, 16, 64, 5, 1, 0, False, 1),
+    (5, 40, 16, 32, 5, 1, 1, True, 1),       # two samples per tile, ragged last tile, 40 of 64 rows, AdaIN gradients, identity join
+    (6, 64, 24, 16, 5, 1, 4, True, 2),       # four samples per tile, the upsample's adjoint, LeakyReLU
+    (3, 32, 16, 64, 5, 2, 3, False, 1),      # stride-2 conv: columns dealt to the waves by parity; pool^T join
+    (4, 32, 16, 32, 5, 2, 0, False, 1),
+    (2, 32, 48, 32, 1, 1, 0, True, 1),       # 1x1
+    pytest.param(64, 128, 128, 64, 5, 1, 1, True, 1, marks=GPU),
+    pytest.param(256, 128, 128, 32, 5, 2, 3, False, 1, marks=GPU),
+    pytest.param(128, 128, 256, 16, 5, 1, 4, True, 1, marks=GPU),
+]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,stride,res_mode,affine,relu", PAIR_BWD_CASES)
+def test_conv_dgrad_in_bwd_fused_epilogue_on_pair_tensors(kind, B, Cin, Cout, T, KS, stride, res_mode, affine, relu):
+    from tests.test_bf16_pairs import bf16r, close_bf16, from_pairs, op_dtype, to_pairs
+    if kind == "emu" and B * Cin * Cout * T * KS > 3e7:
+        pytest.skip("gpu-sized")
+    lib, dev = backend(kind)
+    g = torch.Generator().manual_seed(B * 11 + T)
+    Tdy = O.pad_conv(torch.zeros(1, Cin, T), torch.zeros(Cout, Cin, KS), None, stride).shape[2]
+    w = (torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5).to(dev)
+    dy = to_pairs(torch.randn(B, Cout, Tdy, generator=g)).to(dev)
+    y = bf16r(torch.randn(B, Cin, T, generator=g))
+    mean = y.mean(2).reshape(-1).to(dev)
+    rstd = (1.0 / torch.sqrt(y.var(2, unbiased=False) + 1e-5)).reshape(-1).to(dev)
+    yp = to_pairs(y).to(dev)
+    cond = torch.randn(B, 2 * Cin + 6, generator=g).to(dev) if affine else None
+    coff = 6 if affine else 0
+    Tres = {0: 0, 1: T, 3: T // 2, 4: 2 * T}[res_mode]
+    res = to_pairs(torch.randn(B, Cin, Tres, generator=g)).to(dev) if res_mode else None
+
+    def go():
+        wpd = pack(lib, dev, [w], 1)
+        gout = torch.zeros(B, Cin // 2, T, dtype=torch.int32, device=dev)
+        dyo = torch.zeros(B, Cin // 2, T, dtype=torch.int32, device=dev)
+        dcond = torch.zeros_like(cond) if affine else None
+        fused = ctypes.c_int(-1)
+        rc = lib.avc_conv1d_dgrad_in_bwd(P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cout, Tdy, P(wpd), Cin, KS, stride, T, P(gout), P(res),
+                                         res_mode, Tres, P(yp), P(mean), P(rstd), P(cond), cond.stride(0) if affine else 0, coff, relu, P(dyo),
+                                         P(dcond), dcond.stride(0) if affine else 0, coff, ctypes.byref(fused), None)
+        assert rc == 0, rc
+        return from_pairs(gout.cpu()), from_pairs(dyo.cpu()), (dcond.cpu() if affine else None), fused.value
+
+    with op_dtype(lib, 3):
+        g1, d1, c1, fused = go()
+        assert fused == 1
+        assert lib.avc_set_tuning(b"conv_in_fuse", 0) == 0
+        try:
+            g2, d2, c2, fused2 = go()
+        finally:
+            lib.avc_set_tuning(b"conv_in_fuse", 1)
+        assert fused2 == 0
+    assert torch.isfinite(d1).all() and torch.isfinite(g1).all()
+    assert torch.equal(g1, g2)                                  # the same accumulators + the same join, rounded once
+    close_bf16(d1, d2, ulps=2.0, atol=1e-6 * max(d2.abs().max().item(), 1.0))
+    if affine:
+        torch.testing.assert_close(c1, c2, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_fused_epilogues_keep_their_tile_under_the_wide_tile_switch(kind):
     """avc_tuning.tile12_wgs (opt-in: 64 x 128 tiles for k = 5 layers that keep the chip full) must not pull a launch that carries a fused

@@ -42,6 +42,40 @@ def test_device_feed_equals_reference_collate(kind, M, seg):
     assert next(feed).shape[0] == 8                               # wraps around like infinite_iter
 
 
+def test_host_loader_equals_reference_collate(tmp_path):
+    """The host-side loader (data_utils.py:10-57: PickleDataset + CollateFn + get_data_loader) as ONE vectorised gather per batch: every batch
+    equals the reference's `torch.from_numpy(np.array([data[u][t:t + seg] ...])).view(B, T, M).transpose(1, 2)` -- values, shape AND the
+    strides of the [B, M, T] view ((T*M, 1, M)); an epoch covers every index entry once, the last batch is short (drop_last ignored)."""
+    import json
+    import pickle
+    from adaptive_voice_conversion_amd.data_utils import PickleDataset, get_data_loader
+    data, indexes = _corpus(M=16, seg=24, n_idx=23)
+    with open(tmp_path / "train.pkl", "wb") as f:
+        pickle.dump(data, f)
+    with open(tmp_path / "idx.json", "w") as f:
+        json.dump(indexes, f)
+    ds = PickleDataset(str(tmp_path / "train.pkl"), str(tmp_path / "idx.json"), segment_size=24)
+    assert len(ds) == 23
+    for i in (0, 7, 22):
+        u, t = indexes[i]
+        assert np.array_equal(ds[i], data[u][t:t + 24])                      # data_utils.py:51-54
+    loader = get_data_loader(ds, batch_size=8, frame_size=1, shuffle=False, num_workers=4, drop_last=False)
+    batches = [b.clone() for b in loader]
+    assert [b.shape for b in batches] == [(8, 16, 24), (8, 16, 24), (7, 16, 24)] and len(loader) == 3
+    for bi, b in enumerate(loader):
+        items = [data[u][t:t + 24] for u, t in indexes[bi * 8:(bi + 1) * 8]]
+        ref = torch.from_numpy(np.array(items))                                # data_utils.py:19-22
+        ref = ref.view(ref.size(0), ref.size(1), ref.size(2)).transpose(1, 2)
+        assert torch.equal(b, ref) and b.stride() == ref.stride()
+        assert torch.equal(CollateFn(1)(items), ref) and CollateFn(1)(items).stride() == ref.stride()
+    sh = get_data_loader(ds, batch_size=8, frame_size=1, shuffle=True)
+    seen = torch.cat([b.reshape(b.shape[0], -1).sum(1) for b in sh])
+    want = torch.tensor([float(data[u][t:t + 24].sum()) for u, t in indexes])
+    assert torch.allclose(seen.sort().values, want.sort().values, rtol=1e-5, atol=1e-4)   # a permutation of the index entries
+    with pytest.raises(ValueError):
+        PickleDataset.from_memory(data, [["u0", 30]], 24)                      # u0 has 40 rows: 30 + 24 runs past its end
+
+
 def test_device_feed_shards_are_disjoint_and_equal():
     lib, dev = backend("emu")
     data, indexes = _corpus()

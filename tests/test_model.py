@@ -487,3 +487,11 @@ def test_packed_weights_promise_fails_safe(tmp_path):
     with pytest.raises(RuntimeError, match="changed behind the version counters"):
         run({"verify_packed_weights": True})
     assert run({"verify_packed_weights": True}, edit=False) == clean
+
+    def swap_two(s):   # a SUM-PRESERVING edit (a plain sum of the parameters misses it): two weights trade places
+        w = s.model.decoder.out_conv_layer.weight.data
+        a_, b_ = w[0, 0, 0].clone(), w[1, 1, 0].clone()
+        assert a_ != b_
+        w[0, 0, 0], w[1, 1, 0] = b_, a_
+    with pytest.raises(RuntimeError, match="changed behind the version counters"):
+        run({"verify_packed_weights": True}, after_edit=swap_two, edit=False)
