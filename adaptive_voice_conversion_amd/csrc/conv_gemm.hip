@@ -52,6 +52,8 @@
 #ifndef AVC_CONV_STAGES_BH
 #define AVC_CONV_STAGES_BH 2
 #endif
+// (round 6: three stages for the 1x1 / 32-dword-channel chunk instance ALONE -- the 1104 -> 128 in_conv: 18 chunks of 24 KB with 0.12 us of
+// products each -- measured slower too: 39.7 vs 35.5 us at the op level, 2.46 vs 2.37 ms per step, profiles/r06_conv_1x1_three_stages.log)
 
 // s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (here: LDS-DMA loads, which complete in issue order)
 // still outstanding; lgkmcnt / expcnt untouched.  gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0].

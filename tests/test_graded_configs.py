@@ -96,7 +96,7 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
             continue
         e_eng, e_ref = e_eng / d, e_ref / d
         errs.append(e_eng)
-        floor = _FLOOR[0] if (not _FLOOR_ONLY[0] or k.startswith(_FLOOR_ONLY[0])) else 1e-4
+        floor = _FLOOR[0]
         if e_eng > max(floor, 2.0 * e_ref):   # (collected: a failure names every tensor over its bar, not the first one)
             over.append(f"{k}: engine {e_eng:.3e} vs fp64, fp32 oracle {e_ref:.3e}, floor {floor:.0e}")
         worst_e, worst_r = max(worst_e, e_eng), max(worst_r, e_ref)
@@ -109,7 +109,6 @@ def test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, label):
 
 
 _FLOOR = [1e-4]   # per-tensor gradient floor of test_train_step_matches_oracle_at_graded_shape (the fp32x3 test states its one known deviation through it)
-_FLOOR_ONLY = [None]   # ... and the name prefix of the tensors that relaxed floor applies to (None: all)
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 5, 32), pytest.param("gpu", "m80", 256, 128, marks=GPU), pytest.param("gpu", "m80", 4, 1024, marks=GPU),
@@ -130,13 +129,11 @@ def test_fp32x3_mode_meets_the_same_bars(kind, cfgname, B, T):
     #  collected: at this size MOST conv weight tensors of the content encoder and the decoder sit between 1.1e-4 and 2.9e-4 -- 65,536-term
     #  reductions of split-bf16 products -- so the 4e-4 floor is a property of the MODE at this size, not of one layer; it stays on all
     #  tensors of this case, and the docs say so.)
-    _FLOOR_ONLY[0] = None
     try:
         test_train_step_matches_oracle_at_graded_shape(kind, cfgname, B, T, f"fp32x3 mode at B={B}, T={T}")
     finally:
         _COMPUTE[0] = "fp32"
         _FLOOR[0] = 1e-4
-        _FLOOR_ONLY[0] = None
 
 
 def _rel(a, b):
@@ -262,6 +259,65 @@ def test_bf16_storage_mode_at_graded_shape(kind, cfgname, B, T):
           f"whole-gradient cosine {cos:.6f}")
     assert errs[len(errs) // 2] < (5e-2 if kind == "emu" else 6e-3)
     assert cos > (0.995 if kind == "emu" else 0.9995)
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T,mode", [("emu", "tiny", 5, 32, "fp32x3"), ("emu", "tiny", 5, 32, "bf16s"),
+                                                   pytest.param("gpu", "m80", 64, 1024, "fp32x3", marks=GPU), pytest.param("gpu", "m80", 64, 1024, "bf16s", marks=GPU)])
+def test_optin_modes_at_config4_batch_against_the_exact_fp32_engine(kind, cfgname, B, T, mode):
+    """BASELINE configs[4]'s own batch (T = 1024, B = 64) in the opt-in modes, cheap enough for the driver's `-m gpu` run (VERDICT r5 item 4a /
+    ADVICE r5: their fp64-oracle versions cost 100-130 s of host time each and live in the `gpu and slow` half).  The checker here is the
+    EXACT-fp32 ENGINE on the same inputs -- itself compared with the fp32 and fp64 oracle at this very shape in the same run
+    (test_train_step_matches_oracle_at_graded_shape[... 64-1024 ...]) -- so what this test adds is the launcher's tile / split / batching choices
+    of the mode at this size.  Bars (2x what was measured on MI355X, printed by the test): fp32x3 -- forward atol 4e-5 / rtol 2e-4; gradients with NO branch
+    matching: whole-gradient rel-L2 <= 5e-4 (measured 2.0e-4), median tensor <= 1e-4 (2.0e-5), worst tensor <= 1e-2 (3.5e-3: the content
+    encoder's conv bank, the far end of the longest backward chain, where a handful of flipped kink sites shows first; every other tensor
+    <= 1e-4; the branch-matched fp64 version keeps the mode's 4e-4 floor per tensor); bf16 storage -- forward rel-L2 <= 3e-2, whole-gradient
+    cosine >= 0.9995 (0.99985) and rel-L2 <= 4e-2 (1.7e-2), median tensor <= 1e-2 (4.0e-3), worst tensor <= 6e-1 (3.3e-1, the same bank: no branch
+    matching -- the two engines take different ReLU branches at ~1 % of the sites, which the branch-matched oracle test removes and this one cannot)."""
+    from tests.test_engine import zero_grad_bias
+    _COMPUTE[0] = "fp32"
+    cfg, sd, x, eps, plan32, ws32, out32, g32 = _fwd_bwd(kind, cfgname, B, T)
+    g32 = g32.cpu().double()
+    info = list(zip(plan32.param_info, sd))
+    del ws32
+    _COMPUTE[0] = mode
+    try:
+        _, _, _, _, plan, ws, out, g = _fwd_bwd(kind, cfgname, B, T)
+    finally:
+        _COMPUTE[0] = "fp32"
+    g = g.cpu().double()
+    assert torch.isfinite(g).all()
+    if mode == "fp32x3":
+        for k in ("emb", "muls", "dec"):
+            torch.testing.assert_close(out[k], out32[k], rtol=2e-4, atol=4e-5)
+    else:
+        assert plan.compute_dtype == "bf16" and plan.pair_storage
+        e = {k: _rel(out[k], out32[k]) for k in ("emb", "muls", "dec")}
+        assert max(e.values()) < 3e-2, e
+    per = []
+    for (off, n, shape), k in info:
+        a, b = g[off:off + n], g32[off:off + n]
+        if zero_grad_bias(k, cfg):
+            if mode == "fp32x3":
+                assert (a - b).abs().max().item() <= 4e-6, k
+            continue
+        per.append((((a - b).norm() / b.norm().clamp_min(1e-30)).item(), k))
+    per.sort(reverse=True)
+    errs = sorted(r for r, _ in per)
+    worst, wname = per[0]
+    worst_w = max(r for r, k in per if k.endswith("weight"))
+    cos = torch.nn.functional.cosine_similarity(g, g32, dim=0).item()
+    whole = ((g - g32).norm() / g32.norm()).item()
+    print(f"[{kind}/{cfgname} B={B} T={T}] {mode} vs the exact-fp32 engine: per-tensor gradient rel-L2 worst {worst:.2e} ({wname}) / worst weight tensor "
+          f"{worst_w:.2e} / median {errs[len(errs) // 2]:.2e}; whole gradient rel-L2 {whole:.2e}, cosine {cos:.6f}; top: "
+          + ", ".join(f"{k} {r:.1e}" for r, k in per[:6]))
+    if mode == "fp32x3":
+        # (bias gradients are 65,536-term sums over (b, t) that mostly cancel: without branch matching a handful of flipped kink sites shows there first)
+        assert worst <= 1e-2 and errs[len(errs) // 2] <= 1e-4 and whole <= 5e-4, (wname, worst, worst_w, whole)
+    else:
+        loose = kind == "emu"   # (the 5-sample tiny twin averages less)
+        assert cos >= (0.99 if loose else 0.9995) and whole <= (1.5e-1 if loose else 4e-2), (cos, whole)
+        assert errs[len(errs) // 2] <= (8e-2 if loose else 1e-2) and worst <= 6e-1, (errs[len(errs) // 2], worst, wname)
 
 
 @pytest.mark.parametrize("kind,cfgname,B,T", [("emu", "tiny", 3, 32), pytest.param("gpu", "m80", 32, 128, marks=GPU),
