@@ -68,7 +68,8 @@ def declare(lib):
     lib.avc_plan_create.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.avc_plan_create_ex.argtypes = [ctypes.POINTER(ModelCfg), c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.avc_plan_flags.argtypes = [c_void_p]
-    lib.avc_plan_side_priority.argtypes = [c_void_p]
+    if hasattr(lib, "avc_plan_side_priority"):   # (absent from pre-round-6 builds loaded through AVC_HIP_LIB for same-box A/B runs)
+        lib.avc_plan_side_priority.argtypes = [c_void_p]
     lib.avc_plan_param_range.argtypes = [c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
     lib.avc_plan_stream_wait_grads.argtypes = [c_void_p, c_int, c_void_p]
     lib.avc_set_tuning.argtypes = [ctypes.c_char_p, c_int]
