@@ -32,47 +32,21 @@ static constexpr __host__ __device__ int wg_xrow_lin(int KS) {
 #define WG_THREADS 512   // 4 consumer waves (MFMA) + 4 producer waves (LDS-DMA issue); CW = 8 instances: 8 + 4 waves = 768 threads
 static constexpr __host__ __device__ int wg_threads(int CW) { return (CW + 4) * 64; }
 
-// LDS stages per operand.  fp32 / bf16-operand / fp32x3 products: 2 -- chunk c + 1 lands while chunk c multiplies (40 us of MFMA per layer
-// hide a round trip per chunk; three / four stages measured neutral there, profiles/r03_wgrad_stages_ab.log).  bf16 PAIR storage (BF == 2,
-// round 6): a chunk multiplies for ~0.15 us and one 9-KB chunk in flight per CU is a LATENCY bound (8.7 KB per ~1-us round trip x 256 CUs
-// = 2 TB/s: the class ran 10x above both its roofs, profiles/r06_*).  So the producers of those instances run NSTG - 1 chunks ahead through a
-// ring of NSTG stages: the wait in front of a chunk's barrier is a PARTIAL s_waitcnt vmcnt(n) -- LDS-DMA loads complete in issue order, so
-// "at most n of this wave's DMA instructions outstanding" with n = (chunks issued behind chunk c + 1) x (this wave's instructions per
-// chunk) says chunk c + 1 has landed -- and the barrier itself is a bare s_barrier (the compiler's own drains vmcnt(0)).
-#ifndef AVC_WGRAD_STAGES_BH
-#define AVC_WGRAD_STAGES_BH 4
-#endif
-static constexpr __host__ __device__ int wg_stages(int BF) { return BF == 2 ? AVC_WGRAD_STAGES_BH : 2; }
+// LDS stage slots per operand and chunks per barrier.  fp32 / bf16-operand / fp32x3 products: two slots, one chunk per barrier -- chunk c + 1
+// lands while chunk c multiplies (40 us of MFMA per layer hide a round trip per chunk; three / four stages measured neutral there,
+// profiles/r03_wgrad_stages_ab.log).  bf16 PAIR storage (BF == 2, round 6): a chunk multiplies for ~0.15 us, so what a 32-column chunk costs is
+// everything around the products -- the rendezvous of eight waves (~0.27 us) and the producers' per-chunk round trip
+// (profiles/r06_wgrad_steady_*.txt: 0.5 us of "neither" per chunk against 0.15 us of MFMA).  Those instances therefore work in GROUPS of G
+// chunks: the producers issue the G chunks of group g + 1 into one half of 2 G slots while the consumers multiply the G chunks of group g out
+// of the other half, and the two roles meet ONCE per group (the draining __syncthreads: everything of group g + 1 has landed).  G chunks
+// (36 - 48 KB) in flight per workgroup instead of one.  [First built as a 4-slot ring with the producers three chunks ahead, partial
+// s_waitcnt vmcnt(n) and bare s_barrier, one barrier per chunk: 2.58 -> 2.54 ms per step -- the in-flight bytes were not the bound, the
+// barrier count was.]
+static constexpr __host__ __device__ int wg_group(int BF, int NB) { return BF == 2 ? (NB >= 4 ? 2 : 4) : 1; }   // (the 128 x 128 1x1 tile: 20 KB per slot)
+static constexpr __host__ __device__ int wg_stages(int BF, int NB) { return 2 * wg_group(BF, NB); }
 #ifndef AVC_WGRAD_BHX_WAVES
 #define AVC_WGRAD_BHX_WAVES 3   // minimum waves per SIMD of the bf16 k = 5 whole-chunk instance: 3 = 168 registers (it takes 137)
 #endif
-
-// s_waitcnt vmcnt(n), n = 0..63 (gfx9 encoding: vmcnt = simm16[15:14] : simm16[3:0]; expcnt / lgkmcnt untouched).  A larger request waits
-// for 63 -- stricter than asked, still correct.
-static __device__ __forceinline__ void wg_wait_dma(int n) {
-#ifndef AVC_EMU
-#define WG_W1(k) case (k): __builtin_amdgcn_s_waitcnt(((k) & 15) | (((k) >> 4) << 14) | (7 << 4) | (15 << 8)); break;
-#define WG_W4(k) WG_W1(k) WG_W1((k) + 1) WG_W1((k) + 2) WG_W1((k) + 3)
-#define WG_W16(k) WG_W4(k) WG_W4((k) + 4) WG_W4((k) + 8) WG_W4((k) + 12)
-    switch (n < 63 ? n : 63) {
-        WG_W16(0) WG_W16(16) WG_W16(32) WG_W16(48)
-    }
-#undef WG_W16
-#undef WG_W4
-#undef WG_W1
-#else
-    (void)n;   // (the simulator's LDS-DMA is synchronous)
-#endif
-}
-// workgroup barrier WITHOUT the compiler's vmcnt(0) drain.  LDS is written by the DMAs (waited for above) and by no ds_write on the
-// paths that use this barrier; ds_reads are consumed by the MFMAs in front of it.
-static __device__ __forceinline__ void wg_bare_barrier() {
-#ifdef AVC_EMU
-    emu::block_barrier();
-#else
-    asm volatile("s_barrier" ::: "memory");
-#endif
-}
 
 static inline __device__ long src_chan_off(const ConvSrc& s, int c) {
     return (s.ps == 1) ? (long)c * s.sc : (long)(c / s.ps) * s.sc + (c % s.ps);
@@ -171,7 +145,8 @@ struct WgCfg {
     static constexpr int TPR = 256 / RCO;  // producer threads per dy row in the bias-gradient partial sum
     static constexpr int CPT = 32 / TPR;
     static constexpr int NBROW = BH ? 16 : 32;   // LDS rows between the ci blocks of a wave
-    static constexpr int NSTG = wg_stages(BF);   // LDS stages per operand (wg_stages)
+    static constexpr int GRP = wg_group(BF, NB);        // chunks per barrier (wg_group)
+    static constexpr int NSTG = wg_stages(BF, NB);      // LDS stage slots per operand
     // ---- 16-BYTE staging of the bf16 whole-chunk instances (round 6; `wide` layers, wg_wide16 below).  The dword LDS-DMA that builds the
     // padded rows above costs one instruction per 256 bytes: 36 instructions per 9-KB chunk, and their issue / landing cadence -- not
     // latency, not HBM -- was the bf16 weight gradient's bound (0.83 us per chunk with the products ablated, 2.7 TB/s chip-wide:
@@ -201,7 +176,7 @@ template <int KS, bool RT, int NB, int WCO, bool LIN, int BF, int CW>
 static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* smem, int tid, int lane, int wave) {
     using C = WgCfg<KS, RT, NB, WCO, LIN, BF, CW>;
     constexpr int TCO = C::TCO, TCI = C::TCI, RCO = C::RCO, RCI = C::RCI, WG_DYROW = C::WG_DYROW, NPD = C::NPD, NPX = C::NPX, TPR = C::TPR, CPT = C::CPT;
-    constexpr int NSTG = C::NSTG, DIST = NSTG - 1;   // chunk c + DIST is issued while chunk c multiplies
+    constexpr int NSTG = C::NSTG, GRP = C::GRP;   // group g + 1 (GRP chunks) is issued while group g multiplies
     constexpr bool BH = C::BH;
     const int dbg = bt.dbg;
     const int ptid = tid & 255;   // thread index inside the producer group (CW * 64 is a multiple of 256; the mask tells the compiler the range)
@@ -423,61 +398,39 @@ static __device__ __forceinline__ void wg_producer(const WgradBatch& bt, float* 
             }
         };
 
-        // deep pipeline (NSTG > 2, the fast staging paths: every LDS write of a chunk is a DMA, and every chunk costs this wave the same
-        // number of DMA instructions): partial vmcnt waits + bare barriers; everything else keeps the draining barrier
-        const bool deep = NSTG > 2 && fastp && !(dbg & 5);   // (ablation bits 1 "no DMA" and 4 "no barrier" change the producer's flow: shallow path)
-        int ndma = 0;   // this wave's DMA instructions per chunk (issue_fast)
-        if (wide) {
-#pragma unroll
-            for (int i = 0; i < C::NPD16; ++i) ndma += (wave + 4 * i < C::ND16) ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < C::NPX16; ++i) ndma += (wave + 4 * i < C::NX16) ? 1 : 0;
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPD; ++i) ndma += ((wave + 4 * i) * 64 < DYSP) ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < NPX; ++i) ndma += ((wave + 4 * i) * 64 < XSP) ? 1 : 0;
-        }
         const int nck = c_end - c_begin;
-        __syncthreads();  // the zero fill / the previous segment's last reads are complete before the first DMA of this one lands
-        if (deep) {
-            const int pre = nck < DIST ? nck : DIST;
-            for (int k = 0; k < pre; ++k) issue_fast(c_begin + k, k);
-            wg_wait_dma((pre - 1) * ndma);   // the first chunk has landed
-            wg_bare_barrier();
-        } else {
-            issue(c_begin, 0);
-            __syncthreads();  // (drains the DMA: the compiler's barrier waits for vmcnt(0))
-        }
-        for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const int rel = chunk - c_begin;
-            const int buf = NSTG == 2 ? (rel & 1) : rel % NSTG;
-            if (deep) {
-                if (rel + DIST < nck) issue_fast(chunk + DIST, (rel + DIST) % NSTG);   // (that stage was last read during chunk c - 1: free since its barrier)
-            } else {
-                const bool more = (chunk + 1 < c_end) && !((dbg & 1) && chunk > c_begin);
-                if (more) issue(chunk + 1, NSTG == 2 ? (buf ^ 1) : (rel + 1) % NSTG);
-            }
-            if (do_db) {   // bias gradient = row sums of the dy tile that is in LDS anyway
-                const float* dr = dyT + buf * DYSP + (ptid / TPR) * DYROWW + (ptid % TPR) * CPT;
+        const int ngr = (nck + GRP - 1) / GRP;
+        auto issue_group = [&](int gi) {   // the chunks of group gi into slots (gi & 1) GRP ...
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) {
-                    if constexpr (BH) {
-                        const unsigned d = bh_as_u32(dr[k]);
-                        dbsum += bh_lo(d);
-                        dbsum1 += bh_hi(d);
-                    } else {
-                        dbsum += dr[k];
+            for (int i = 0; i < GRP; ++i) {
+                const int chunk = c_begin + gi * GRP + i;
+                if (chunk < c_end) issue(chunk, (gi & 1) * GRP + i);
+            }
+        };
+        __syncthreads();  // the zero fill / the previous segment's last reads are complete before the first DMA of this one lands
+        issue_group(0);
+        __syncthreads();  // (drains the DMA: the compiler's barrier waits for vmcnt(0))
+        for (int gi = 0; gi < ngr; ++gi) {
+            const bool more = (gi + 1 < ngr) && !((dbg & 1) && gi > 0);
+            if (more) issue_group(gi + 1);
+            if (do_db) {   // bias gradient = row sums of the dy tiles that are in LDS anyway
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    if (gi * GRP + i >= nck) break;
+                    const float* dr = dyT + ((gi & 1) * GRP + i) * DYSP + (ptid / TPR) * DYROWW + (ptid % TPR) * CPT;
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        if constexpr (BH) {
+                            const unsigned d = bh_as_u32(dr[k]);
+                            dbsum += bh_lo(d);
+                            dbsum1 += bh_hi(d);
+                        } else {
+                            dbsum += dr[k];
+                        }
                     }
                 }
             }
-            if (deep) {
-                // chunk c + 1 must have landed by this barrier; behind it, chunks c + 2 .. min(c + DIST, last) may still be in flight
-                const int last_issued = rel + DIST < nck - 1 ? rel + DIST : nck - 1;
-                const int behind = last_issued - (rel + 1);
-                wg_wait_dma(behind > 0 ? behind * ndma : 0);
-                wg_bare_barrier();
-            } else if (!(dbg & 4)) __syncthreads();
+            if (!(dbg & 4)) __syncthreads();
         }
         // ---- segment end
         auto store_db = [&](float v0, float v1) {   // finished bias gradient of this workgroup's co rows
@@ -558,8 +511,10 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
         // (v_mfma ... v[98:113], ..., v[66:81]: round 6, the consumers alone 764 instead of 418 ns per chunk).
         auto chunk_loop = [&](auto wtag) {
         constexpr bool WIDE = decltype(wtag)::value;
+        constexpr int GRP = C::GRP;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const int buf = NSTG == 2 ? ((chunk - c_begin) & 1) : (chunk - c_begin) % NSTG;
+            const int rel = chunk - c_begin;
+            const int buf = GRP == 1 ? (rel & 1) : ((rel / GRP) & 1) * GRP + rel % GRP;   // slot of the chunk: half (group & 1), place in the group
             const bool first_c = tcs == 0, last_c = tcs == a.chunks_per_sample - 1;
             if (WIDE && ++tcs == a.chunks_per_sample) tcs = 0;
             if (!(dbg & 2)) {
@@ -865,7 +820,7 @@ static __device__ __forceinline__ void wg_consumer(const WgradBatch& bt, float* 
                 static_assert(!RT || KS == 8, "run-time tap counts are built for up to 8 taps");
                 body(KTag<KS>{});
             }
-            if (!(dbg & 4)) __syncthreads();
+            if (!(dbg & 4) && (GRP == 1 || rel % GRP == GRP - 1 || chunk + 1 == c_end)) __syncthreads();   // once per group
         }
         };
         if constexpr (C::BHX) {
@@ -988,7 +943,7 @@ static size_t wgrad_lds_bytes_for(const WgradArgs& a, int NB, int WCO, int CW) {
         const size_t s16 = (size_t)((TCO * 40 + 255) & ~255) + ((TCI * 40 + 255) & ~255);
         stage = s16 > stage ? s16 : stage;
     }
-    return (size_t)wg_stages(half == 2 ? 2 : 0) * stage * 4 + 64;
+    return (size_t)wg_stages(half == 2 ? 2 : 0, NB) * stage * 4 + 64;
 }
 static WgradKey wgrad_key(const WgradArgs& a) {
     WgradKey k;

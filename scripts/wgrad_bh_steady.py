@@ -23,7 +23,8 @@ def run(B, Cin, Cout, T, KS):
     ws = torch.zeros(lib.avc_conv1d_wgrad_ws_floats(B, Cin, Cout, T, KS), device=dev)
     dW, db = torch.zeros(Cout, Cin, KS, device=dev), torch.zeros(Cout, device=dev)
     res = []
-    chunks_per_wg = 4 * (B * T // 32) / 256.0   # 64 x 64 tiles: 4 per layer
+    tiles = 4 if Cin % 64 == 0 else 3 * (Cout // 128)   # 64 x 64 tiles, or 128 co x 32 ci (Cin = 80: three ci tiles)
+    chunks_per_wg = tiles * (B * T // 32) / 256.0
     for dbg, name in ((0, "full"), (2, "noMFMA"), (1, "noDMA"), (3, "neither"), (15, "empty")):
         lib.avc_set_tuning(b"wgrad_ablation", dbg)
         f = lambda: lib.avc_conv1d_wgrad(P(x), x.stride(0), x.stride(1), 1, P(dy), dy.stride(0), dy.stride(1), 1, 1, B, Cin, Cout, T, T, KS, 1, P(dW), P(db), P(ws), None)
@@ -42,3 +43,5 @@ if __name__ == "__main__":
         run(B, 128, 128, 128, 5)
     run(2048, 128, 128, 32, 5)
     run(2048, 128, 128, 16, 5)
+    for k in (8, 4, 1):
+        run(2048, 80, 128, 128, k)     # a conv-bank member (the run-time-taps instance for k != 1, 5)
