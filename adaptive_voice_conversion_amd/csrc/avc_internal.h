@@ -12,6 +12,7 @@ struct PackArgs {
     int dgrad, CK, nchunk, M, Mp;
     float* dst;
     int img;      // AVC_IMG_*
+    int mb;       // one-launch table only: rows per staged piece (avc_pack_stage_rows), 0 = legacy pieces
 };
 
 // library defaults / the calling thread's op-level tuning (ops_api.hip)
@@ -47,7 +48,10 @@ int avc_launch_dsp_deemph(const float* x, long L, float a, float* out, hipStream
 int avc_launch_dsp_frame_power(const float* y, long L, int frame_length, int hop, int n_frames, float* out, hipStream_t s);
 #define AVC_PACK_BATCH 16
 int avc_launch_pack_batch(const PackArgs* ps, int n, hipStream_t stream);
-#define AVC_PACK_PIECE 2048   // image elements per block of the one-launch pack (8 per thread)
+#define AVC_PACK_PIECE 2048   // image elements per block of the one-launch pack (8 per thread): legacy pieces
+#define AVC_PACK_STAGE 8192   // floats of LDS stage per block: staged pieces
+int avc_pack_stage_rows(const PackArgs& p);
+long avc_pack_pieces(const PackArgs& p);
 int avc_launch_pack_table(const PackArgs* dev_tab, const void* dev_blk, int nblk, double bytes, const float* params, float* ws, hipStream_t stream);
 
 void avc_wgrad_geometry(WgradArgs& a);

@@ -639,13 +639,127 @@ __global__ void __launch_bounds__(AVC_THREADS) pack_weight_batch_kernel(const Pa
 
 // ONE launch for every image of a plan: the descriptors live in a device table the plan owns (built once at plan creation); their
 // pointers are stored as BYTE OFFSETS from the caller's parameter buffer (sources) and workspace (destinations), rebased here.
-// Work is dealt in equal pieces: block b handles piece blk[b].y (AVC_PACK_PIECE consecutive image elements) of image blk[b].x --
-// the gather is latency-bound (one scattered 4-byte read per element), so it wants every CU full of waves whatever the image sizes are.
-__global__ void __launch_bounds__(AVC_THREADS) pack_weight_table_kernel(const PackArgs* tab, const int2* blk, const float* params, float* ws) {
+// Block b handles piece blk[b].y of image blk[b].x.
+//   * staged pieces (PackArgs.mb > 0; round 6): one reduction chunk x `mb` consecutive output rows.  Its source elements are a few
+//     CONTIGUOUS runs of the state_dict tensor -- forward: per row m the chunk's channels x taps (CK KS floats); input gradient: per
+//     reduction row the block's columns x taps (mb KS floats) -- read coalesced into LDS; the image order is then a gather from LDS and
+//     the block's stores are contiguous runs of mb 16-byte groups.  (The round-5 kernel gathered from global memory, one scattered
+//     4-byte read per element: every wave instruction touched 64 cache lines, 87 us per step at 0.85 TB/s of useful bytes.)
+//   * legacy pieces (mb == 0: the split-bf16 images, and any image whose chunk does not fit the stage): AVC_PACK_PIECE consecutive
+//     image elements, gathered from global memory.
+static __device__ __forceinline__ void pack_staged(const PackArgs* __restrict__ gp, const float* __restrict__ params, float* __restrict__ ws, int piece, float* stage) {
+    // (every field is read once from the table entry -- a block-uniform address -- into a scalar: a by-value PackArgs whose `src` is indexed
+    // at run time lives in scratch memory)
+    const int tid = threadIdx.x;
+    const int MB = gp->mb, Mp = gp->Mp, M = gp->M, KS = gp->KS, CK = gp->CK, Cin = gp->Cin, Cout = gp->Cout, img = gp->img;
+    const int nsrc = gp->nsrc, rows_per_src = gp->rows_per_src;
+    const bool dgrad = gp->dgrad != 0;
+    float* dst = (float*)((char*)ws + (size_t)gp->dst);
+    const char* pbase = (const char*)params;
+    const int nmb = (Mp + MB - 1) / MB;
+    const int chunk = piece / nmb, m0 = (piece - chunk * nmb) * MB;
+    const bool pairs = img == AVC_IMG_K4H;   // (CK counts dword channels = bf16 pairs of channels there)
+    const int CKr = pairs ? 2 * CK : CK, c0 = chunk * CKr;
+    const int seglen = dgrad ? MB * KS : CKr * KS, nseg = dgrad ? CKr : MB;
+    const int pitch = seglen | 1;   // (odd: the forward gather below walks the segments lane by lane)
+    const int n = nseg * seglen;
+    const float inv_seglen = 1.0f / (float)seglen, inv_rows = 1.0f / (float)rows_per_src;
+    // segment = forward: output row m0 + seg, elements W[m][c0 ...][*]; input gradient: reduction row c0 + seg (a forward output channel),
+    // elements W[c][m0 ...][*].  Either way a run of `seglen` consecutive floats that starts at (row Cin + col0) KS.
+    const int row0 = dgrad ? c0 : m0, col0 = dgrad ? m0 : c0;
+    const int row_end = dgrad ? Cout : M, off_end = ((dgrad ? M : Cin) - col0) * KS;   // (valid: row < row_end and off < off_end)
+    // 16 independent, UNCONDITIONAL reads in flight per thread and round (an out-of-range element reads element 0 of the tensor and is
+    // replaced by zero afterwards): as a loop of guarded reads every element was its own round trip -- 55 us per step.
+    constexpr int U = 16;
+    for (int e0 = tid; e0 < n; e0 += U * AVC_THREADS) {
+        float v[U];
+        int at_[U];
+        bool ok[U];
+        long idx[U];
+        const float* w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // (index arithmetic + the table reads of the stacked tensors' base pointers: no branch, no wait in between)
+            const int e = e0 + u * AVC_THREADS;
+            const int seg = avc_fastdiv(e, seglen, inv_seglen), off = e - seg * seglen;
+            const int row = row0 + seg;
+            ok[u] = e < n && row < row_end && off < off_end;
+            at_[u] = e < n ? seg * pitch + off : -1;
+            int s_ = avc_fastdiv(row, rows_per_src, inv_rows);   // stacked tensors: which one holds forward output row `row`
+            s_ = s_ < nsrc ? s_ : nsrc - 1;
+            w[u] = (const float*)(pbase + (size_t)gp->src[s_]);
+            idx[u] = ok[u] ? ((long)(row - s_ * rows_per_src) * Cin + col0) * KS + off : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = w[u][idx[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (at_[u] >= 0) stage[at_[u]] = ok[u] ? v[u] : 0.f;
+    }
+    __syncthreads();
+    const int lg = 31 - __builtin_clz(MB);
+    auto at = [&](int mi, int cc, int j) -> float {   // (row m0 + mi, reduction channel c0 + cc, tap j)
+        return dgrad ? stage[cc * pitch + mi * KS + (KS - 1 - j)] : stage[mi * pitch + cc * KS + j];
+    };
+    if (img == AVC_IMG_K4 || img == AVC_IMG_K4H) {
+        const int GR = CK >> 3, ngr = KS * GR * 2 * MB;
+        const float inv_GR = 1.0f / (float)GR;
+        for (int idx = tid; idx < ngr; idx += AVC_THREADS) {
+            const int mi = idx & (MB - 1);
+            int q = idx >> lg;
+            const int h = q & 1;
+            q >>= 1;
+            const int j = avc_fastdiv(q, GR, inv_GR), unit = q - j * GR;
+            if (m0 + mi >= Mp) continue;
+            const long g4 = ((((long)chunk * KS + j) * GR + unit) * 2 + h) * Mp + m0 + mi;
+            const int r0 = 8 * unit + h;   // reduction channel (K4H: dword channel) of u = 0 inside the chunk; u steps it by 2
+            if (pairs) {
+                unsigned w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = bh_pack(at(mi, 2 * (r0 + 2 * u), j), at(mi, 2 * (r0 + 2 * u) + 1, j));
+                *(avc_u32x4*)((unsigned*)dst + 4 * g4) = avc_u32x4{w[0], w[1], w[2], w[3]};
+            } else {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = at(mi, r0 + 2 * u, j);
+                *(f32x4*)(dst + 4 * g4) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    } else {   // AVC_IMG_PLAIN: Wp[chunk][j][r][m]
+        const int nel = KS * CK * MB;
+        const float inv_CK = 1.0f / (float)CK;
+        for (int idx = tid; idx < nel; idx += AVC_THREADS) {
+            const int mi = idx & (MB - 1), q = idx >> lg;
+            const int j = avc_fastdiv(q, CK, inv_CK), r = q - j * CK;
+            if (m0 + mi >= Mp) continue;
+            dst[(((long)chunk * KS + j) * CK + r) * Mp + m0 + mi] = at(mi, r, j);
+        }
+    }
+}
+
+// rows of a staged piece: the largest power of two <= 128 whose chunk slab fits the stage; 0 = the image takes legacy pieces
+int avc_pack_stage_rows(const PackArgs& p) {
+    if (p.img != AVC_IMG_K4 && p.img != AVC_IMG_K4H && p.img != AVC_IMG_PLAIN) return 0;
+    const long per_row = (long)(p.img == AVC_IMG_K4H ? 2 * p.CK : p.CK) * p.KS;
+    if (p.rows_per_src <= 0 || (long)p.Cout * p.Cin * p.KS >= (1L << 22)) return 0;   // (float-reciprocal divisions)
+    for (int mb = 128; mb >= 8; mb >>= 1)
+        if (mb * per_row <= AVC_PACK_STAGE) return mb;
+    return 0;
+}
+long avc_pack_pieces(const PackArgs& p) {
+    if (p.mb > 0) return (long)p.nchunk * ((p.Mp + p.mb - 1) / p.mb);
+    return (avc_pack_total(p) + AVC_PACK_PIECE - 1) / AVC_PACK_PIECE;
+}
+
+__global__ void __launch_bounds__(AVC_THREADS) pack_weight_table_kernel(const PackArgs* __restrict__ tab, const int2* __restrict__ blk, const float* __restrict__ params, float* __restrict__ ws) {
+    __shared__ float stage[AVC_PACK_STAGE + 128];
     const int2 bi = blk[blockIdx.x];
+    if (tab[bi.x].mb > 0) {
+        pack_staged(tab + bi.x, params, ws, bi.y, stage);
+        return;
+    }
     PackArgs p = tab[bi.x];
-    for (int k = 0; k < p.nsrc; ++k) p.src[k] = (const float*)((const char*)params + (size_t)p.src[k]);
     p.dst = (float*)((char*)ws + (size_t)p.dst);
+    for (int k = 0; k < p.nsrc; ++k) p.src[k] = (const float*)((const char*)params + (size_t)p.src[k]);
     const int unit = (p.img == AVC_IMG_K4 || p.img == AVC_IMG_K4H) ? AVC_PACK_PIECE / 4 : AVC_PACK_PIECE;   // (K4 images are packed in 16-byte groups)
     pack_one(p, (long)bi.y * unit + threadIdx.x, AVC_THREADS, (long)(bi.y + 1) * unit);
 }

@@ -656,9 +656,10 @@ static void plan_init_pack_table(avc_plan* p) {
     std::vector<int> blk;   // (image, piece) pairs
     for (size_t i = 0; i < all.size(); ++i) {
         if ((int)i == p->pack_early_imgs) p->pack_nblk_early = (int)(blk.size() / 2);
-        const long t = avc_pack_total(all[i]);
-        bytes += 8.0 * t;
-        for (long q = 0; q * AVC_PACK_PIECE < t; ++q) {
+        all[i].mb = avc_pack_stage_rows(all[i]);
+        bytes += 8.0 * avc_pack_total(all[i]);
+        const long np = avc_pack_pieces(all[i]);
+        for (long q = 0; q < np; ++q) {
             blk.push_back((int)i);
             blk.push_back((int)q);
         }
@@ -1132,7 +1133,7 @@ static int enc_front(const avc_plan* p, const EncNet& e, const float* params, fl
 
 static bool side_ready(const avc_plan* p);
 static int pack_all(const avc_plan* p, const float* params, float* ws, hipStream_t s) {
-    if (p->pack_tab_dev) {
+    if (p->pack_tab_dev && !(p->tun.dbg_streams & 16)) {   // (bit 16, diagnostic: the per-image gather kernels the table launch is tested against)
         // ONE launch on the caller's stream.  (Round 4 ran the tail of the table on a helper stream under the next step's bank convs:
         // measured neutral -- 6.000 vs 6.009 ms/step -- and its read of `params` was ordered only against a later forward of the SAME
         // plan, a formal read / write race with an optimizer step or a parameter write that follows on another plan; removed.)

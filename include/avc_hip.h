@@ -186,7 +186,8 @@ typedef struct avc_tuning {
                              * (the 64-column tile holds whole rows; csrc/conv_shared.h: conv_epilogue_in) instead of a row kernel of their own */
     long dbg_streams;       /* diagnostic (scripts/bf16_repro_probe2.py): bit 0 = the backward pass launches its weight gradients on the stream that
                              * produced their operands (no weight-gradient streams); bit 1 = the backward pass runs the speaker branch and the
-                             * decoder's second half-batch chain on the caller's stream (no side stream).  0 = the product schedule */
+                             * decoder's second half-batch chain on the caller's stream (no side stream); bit 4 (16) = avc_plan_pack_weights packs image by image with
+                             * the op-level gather kernel instead of the plan's one-launch table (tests/test_engine.py compares the two).  0 = the product schedule */
 } avc_tuning;
 void avc_tuning_init(avc_tuning* t);
 /* avc_plan_create_ex with explicit tuning (NULL = defaults).  Additional flags: AVC_PLAN_X3 = compute mode "fp32x3"

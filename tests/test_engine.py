@@ -539,3 +539,35 @@ def test_two_plans_from_two_threads(kind, cfgname, B, T):
         for k in range(nsteps):
             assert torch.equal(out[i][k][0], alone[i][0]), f"plan {i}, concurrent step {k}: gradients differ from the serial run"
             assert torch.equal(out[i][k][1], alone[i][1]), f"plan {i}, concurrent step {k}: dec differs from the serial run"
+
+
+@pytest.mark.parametrize("kind,cfgname,B,T,compute,mode", [
+    ("emu", "tiny", 2, 32, "fp32", "train"), ("emu", "tiny", 2, 32, "bf16s", "train"), ("emu", "tiny128", 2, 32, "fp32", "train"),
+    ("emu", "tiny128", 2, 32, "bf16s", "train"), ("emu", "tiny8", 2, 64, "fp32", "inference"),
+    pytest.param("gpu", "m80", 256, 128, "fp32", "train", marks=GPU), pytest.param("gpu", "m80", 256, 128, "bf16s", "train", marks=GPU),
+    pytest.param("gpu", "m80", 4, 128, "fp32x3", "train", marks=GPU), pytest.param("gpu", "m80", 4, 128, "bf16r", "train", marks=GPU),
+    pytest.param("gpu", "m512", 8, 128, "fp32", "train", marks=GPU), pytest.param("gpu", "m80", 64, 1024, "fp32", "train", marks=GPU),
+    pytest.param("gpu", "m80", 1024, 128, "fp32", "inference", marks=GPU), pytest.param("gpu", "m80", 3, 40, "fp32", "train", marks=GPU)])
+def test_one_launch_weight_pack_equals_the_per_image_kernels(kind, cfgname, B, T, compute, mode):
+    """avc_plan_pack_weights is ONE launch over a device table; since round 6 its blocks read the state_dict tensors in contiguous runs into
+    LDS and gather the image order from there (csrc/conv_gemm.hip: pack_staged).  Every byte it writes must equal what the op-level gather
+    kernel writes image by image (`dbg_streams` bit 4 selects that path) -- over every image type of a plan: fp32 / bf16-pair 16-byte
+    images, forward and transposed tap-flipped input-gradient images, the stacked AdaIN affines and their bias rows, plain images, the
+    split-bf16 images of fp32x3 (legacy pieces), the 1104-channel in_conv whose input gradient covers only its first 1024 rows."""
+    lib, dev = backend(kind)
+    cfg = get_cfg(cfgname)
+    sd = O.make_state_dict(cfg, 11)
+    out = []
+    for tuning in (None, {"dbg_streams": 16}):
+        plan = Plan(cfg, B, T, lib=lib, compute_dtype=compute, mode=mode, tuning=tuning)
+        params = flat_params(plan, sd, dev)
+        ws = torch.full((plan.workspace_floats,), -3.0, device=dev)   # (bytes a path does not write stay -3: both must write the same set)
+        plan.pack_weights(params, ws)
+        if kind == "gpu":
+            torch.cuda.synchronize()
+        out.append(ws.view(torch.int32).cpu())
+        plan.close()
+    assert out[0].numel() == out[1].numel()
+    written = int((out[1] != torch.tensor(-3.0).view(torch.int32)).sum())
+    assert written > 0
+    assert torch.equal(out[0], out[1]), f"{int((out[0] != out[1]).sum())} of {written} packed dwords differ"
